@@ -1,0 +1,661 @@
+// rptree_oracle.cpp — CPU ORACLE (test infrastructure, see rptree_oracle.h for the rules).
+//
+// Restates ocramz/rp-tree v0.7.1 for the random-projection hot path.  Citations are
+// file:line in the reference checkout.  Compile with -O2 -ffp-contract=off, never
+// -ffast-math: GHC emits separate IEEE double multiply and add (no FMA), and the reference's
+// summation ORDER (right-nested for innerSD/innerSS, left fold for innerDD) is part of the
+// contract that makes leaf assignments reproducible.
+#include "rptree_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <set>
+#include <utility>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// SplitMix64 (third-party `splitmix`, restated from the published algorithm)
+// ------------------------------------------------------------------------------------------
+inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 33)) * 0xff51afd7ed558ccdULL;
+  z = (z ^ (z >> 33)) * 0xc4ceb9fe1a85ec53ULL;
+  return z ^ (z >> 33);
+}
+inline uint64_t mix64v13(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+inline uint64_t mix_gamma(uint64_t z) {
+  uint64_t g = mix64v13(z) | 1ULL;
+  int n = __builtin_popcountll(g ^ (g >> 1));
+  return n >= 24 ? g : g ^ 0xaaaaaaaaaaaaaaaaULL;
+}
+
+// Gen.hs:178-195 sparseVG: for i in [0,d): flag <- bernoulli p; if flag: x <- rand; emit (i,x)
+template <class Rand>
+int64_t sparse_vg(rpo_gen* g, double p, int32_t d, int32_t* idx, double* val, Rand rand) {
+  int64_t m = 0;
+  for (int32_t i = 0; i < d; ++i) {
+    if (rpo_bernoulli(g, p)) {
+      double x = rand();
+      idx[m] = i;
+      val[m] = x;
+      ++m;
+    }
+  }
+  return m;
+}
+
+// ------------------------------------------------------------------------------------------
+// Topology: data independent.  Internal.hs:289 (leaf iff level >= maxDepth || n <= minLeaf),
+// :495,503 (left child takes n div 2, right child the rest).
+// ------------------------------------------------------------------------------------------
+inline bool is_leaf(int32_t level, int64_t n, int32_t L, int32_t minLeaf) {
+  return level >= L || n <= (int64_t)minLeaf;
+}
+
+struct SparseVec {  // one hyperplane (SVector Double): sorted (idx,val) pairs
+  std::vector<int32_t> idx;
+  std::vector<double> val;
+};
+
+std::vector<SparseVec> sparsify(const double* R, int32_t T, int32_t L, int32_t d) {
+  std::vector<SparseVec> out((size_t)T * L);
+  for (int64_t v = 0; v < (int64_t)T * L; ++v) {
+    const double* r = R + v * d;
+    for (int32_t i = 0; i < d; ++i)
+      if (r[i] != 0.0) {
+        out[v].idx.push_back(i);
+        out[v].val.push_back(r[i]);
+      }
+  }
+  return out;
+}
+
+// A data accessor abstracts DVector rows vs SVector (CSR) rows so that the tree code is
+// written once, like the reference's `Inner SVector v` constraint (Internal.hs:316-341).
+struct DenseData {
+  const double* X;
+  int64_t N;
+  int32_t d;
+  double inner(const SparseVec& r, int64_t id) const {  // Inner SVector DVector, :332-333
+    return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, X + id * d);
+  }
+};
+struct CsrData {
+  const int64_t* rowptr;
+  const int32_t* col;
+  const double* val;
+  int64_t N;
+  int32_t d;
+  double inner(const SparseVec& r, int64_t id) const {  // Inner SVector SVector, :322-323
+    int64_t a = rowptr[id], b = rowptr[id + 1];
+    return rpo_inner_ss((int64_t)r.idx.size(), r.idx.data(), r.val.data(), b - a, col + a,
+                        val + a);
+  }
+};
+
+struct FlatTree {
+  int32_t* perm;  // [N]
+  double* thr;    // [2^L-1]
+  double* mglo;
+  double* mghi;
+};
+
+// Internal.hs:258-297 `insert` on an empty Tip (= batch `create`, :223-225), recursion
+// restated over id lists.  `ids` holds the node's points in the node's current order.
+template <class Data>
+void build_node(const Data& D, const std::vector<SparseVec>& rvs /*L vectors of this tree*/,
+                int32_t L, int32_t minLeaf, int32_t level, int64_t heap, int64_t off,
+                std::vector<int32_t>& ids, FlatTree& ft, double* proj_tree /*[L][N] or null*/) {
+  const int64_t n = (int64_t)ids.size();
+  if (is_leaf(level, n, L, minLeaf)) {  // :289-290 Tip () xs'
+    for (int64_t i = 0; i < n; ++i) ft.perm[off + i] = ids[i];
+    return;
+  }
+  // partitionAtMedian r xs, Internal.hs:491-505
+  const SparseVec& r = rvs[level];  // :270 rvs ! ixLev
+  std::vector<std::pair<double, int32_t>> projs((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {  // :504 map (\xe -> (xe, r `inner` eEmbed xe))
+    double p = D.inner(r, ids[i]);
+    projs[i] = {p, ids[i]};
+    if (proj_tree) proj_tree[(int64_t)level * D.N + ids[i]] = p;
+  }
+  // :504,509-512 sortByVG snd = STABLE merge sort, `comparing` on Double (-0.0 == 0.0)
+  std::stable_sort(projs.begin(), projs.end(),
+                   [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) {
+                     return a.first < b.first;
+                   });
+  const int64_t nh = n / 2;  // :503
+  double mgl, mgr;
+  if (n >= 3) {  // :497
+    mgl = projs[nh - 1].first;
+    mgr = projs[nh + 1].first;
+  } else if (n == 2) {  // :498
+    mgl = projs[0].first;
+    mgr = projs[1].first;
+  } else {  // :499
+    mgl = mgr = projs[0].first;
+  }
+  ft.thr[heap] = projs[nh].first;  // :501
+  ft.mglo[heap] = mgl;
+  ft.mghi[heap] = mgr;
+  std::vector<int32_t> ll((size_t)nh), rr((size_t)(n - nh));  // :495 take nh / drop nh
+  for (int64_t i = 0; i < nh; ++i) ll[i] = projs[i].second;
+  for (int64_t i = nh; i < n; ++i) rr[i - nh] = projs[i].second;
+  std::vector<std::pair<double, int32_t>>().swap(projs);
+  std::vector<int32_t>().swap(ids);
+  build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 1, off, ll, ft, proj_tree);       // :296
+  build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 2, off + nh, rr, ft, proj_tree);  // :297
+}
+
+template <class Data>
+void forest_build(const Data& D, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                  int32_t* perm, double* thr, double* mglo, double* mghi, double* proj_out) {
+  const int64_t nodes = ((int64_t)1 << L) - 1;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  std::vector<SparseVec> all = sparsify(R, T, L, D.d);
+  for (int32_t t = 0; t < T; ++t) {  // createMulti, Internal.hs:234-240 (ascending key)
+    for (int64_t h = 0; h < nodes; ++h)
+      thr[t * nodes + h] = mglo[t * nodes + h] = mghi[t * nodes + h] = nan;
+    std::vector<SparseVec> rvs(all.begin() + (size_t)t * L, all.begin() + (size_t)(t + 1) * L);
+    std::vector<int32_t> ids((size_t)D.N);
+    for (int64_t i = 0; i < D.N; ++i) ids[i] = (int32_t)i;  // dataset in input order
+    FlatTree ft{perm + (int64_t)t * D.N, thr + t * nodes, mglo + t * nodes, mghi + t * nodes};
+    build_node(D, rvs, L, minLeaf, 0, 0, 0, ids, ft,
+               proj_out ? proj_out + (int64_t)t * L * D.N : nullptr);
+  }
+}
+
+// RPTree.hs:297-314 `candidates`, on the flat layout.  projq[level] = r_level `inner` q.
+struct Cand {
+  const int32_t* perm;
+  const double *thr, *mglo, *mghi;
+  int32_t L, minLeaf;
+  const double* projq;
+  std::vector<int32_t>* out;
+  void go(int32_t level, int64_t heap, int64_t off, int64_t n) const {
+    if (is_leaf(level, n, L, minLeaf)) {  // :299 Tip
+      for (int64_t i = 0; i < n; ++i) out->push_back(perm[off + i]);
+      return;
+    }
+    const double proj = projq[level];              // :303-304
+    const double dl = std::fabs(mglo[heap] - proj);  // :306
+    const double dr = std::fabs(mghi[heap] - proj);  // :307
+    const double th = thr[heap];
+    const int64_t nh = n / 2;
+    const int64_t hl = 2 * heap + 1, hr = 2 * heap + 2;
+    if (proj < th && dl > dr) {  // :309-310 both
+      go(level + 1, hl, off, nh);
+      go(level + 1, hr, off + nh, n - nh);
+    } else if (proj < th) {  // :311
+      go(level + 1, hl, off, nh);
+    } else if (proj > th && dl < dr) {  // :312-313 both
+      go(level + 1, hl, off, nh);
+      go(level + 1, hr, off + nh, n - nh);
+    } else {  // :314 (includes proj == thr)
+      go(level + 1, hr, off + nh, n - nh);
+    }
+  }
+};
+
+template <class InnerQ>
+void tree_candidates(InnerQ innerq, const std::vector<SparseVec>& all, int32_t L, int32_t minLeaf,
+                     int64_t N, const int32_t* perm, const double* thr, const double* mglo,
+                     const double* mghi, int32_t t, std::vector<int32_t>& out) {
+  const int64_t nodes = ((int64_t)1 << L) - 1;
+  std::vector<double> projq((size_t)L);
+  // proj is the same for every node of a level (one vector per level, Internal.hs:171-175);
+  // the reference evaluates it lazily per visited Bin — values are identical.
+  for (int32_t l = 0; l < L; ++l) projq[l] = innerq(all[(size_t)t * L + l]);
+  Cand c{perm + (int64_t)t * N, thr + t * nodes, mglo + t * nodes, mghi + t * nodes,
+         L,    minLeaf,           projq.data(),     &out};
+  c.go(0, 0, 0, N);
+}
+
+struct DistId {
+  double dist;
+  int32_t id;
+};
+
+// RPTree.hs:174 `take k $ sortByVG fst cs` (stable), optional de-duplication extension.
+int32_t topk_from(std::vector<DistId>& cs, int32_t k, int32_t dedup, int32_t* out_ids,
+                  double* out_dist) {
+  std::stable_sort(cs.begin(), cs.end(),
+                   [](const DistId& a, const DistId& b) { return a.dist < b.dist; });
+  int32_t m = 0;
+  std::set<int32_t> seen;
+  for (size_t i = 0; i < cs.size() && m < k; ++i) {
+    if (dedup) {
+      if (seen.count(cs[i].id)) continue;
+      seen.insert(cs[i].id);
+    }
+    out_ids[m] = cs[i].id;
+    out_dist[m] = cs[i].dist;
+    ++m;
+  }
+  return m;
+}
+
+double true_l2_ss(int64_t n1, const int32_t* i1, const double* v1, int64_t n2, const int32_t* i2,
+                  const double* v2) {
+  int64_t a = 0, b = 0;
+  double s = 0;
+  while (a < n1 || b < n2) {
+    double x;
+    if (a < n1 && (b >= n2 || i1[a] < i2[b])) x = v1[a++];
+    else if (b < n2 && (a >= n1 || i2[b] < i1[a])) x = -v2[b++];
+    else x = v1[a++] - v2[b++];
+    s += x * x;
+  }
+  return std::sqrt(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------- RNG -------------------------------------------------------
+void rpo_gen_init(rpo_gen* g, uint64_t s) {  // mkSMGen
+  g->seed = mix64(s);
+  g->gamma = mix_gamma(s + 0x9e3779b97f4a7c15ULL);
+}
+uint64_t rpo_next_word64(rpo_gen* g) {
+  g->seed += g->gamma;
+  return mix64(g->seed);
+}
+double rpo_next_double(rpo_gen* g) {
+  return (double)(rpo_next_word64(g) >> 11) * 0x1.0p-53;
+}
+int rpo_bernoulli(rpo_gen* g, double p) { return rpo_next_double(g) < p; }
+double rpo_normal(rpo_gen* g, double mu, double sig) {  // Box–Muller, u1 then u2
+  double u1 = rpo_next_double(g);
+  double u2 = rpo_next_double(g);
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2) * sig + mu;
+}
+double rpo_uniform_r(rpo_gen* g, double lo, double hi) {
+  return rpo_next_double(g) * (hi - lo) + lo;
+}
+
+int64_t rpo_sparse_normal(rpo_gen* g, double p, int32_t d, double mu, double sig, int32_t* idx,
+                          double* val) {
+  return sparse_vg(g, p, d, idx, val, [&] { return rpo_normal(g, mu, sig); });
+}
+int64_t rpo_sparse_uniform(rpo_gen* g, double p, int32_t d, double lo, double hi, int32_t* idx,
+                           double* val) {
+  return sparse_vg(g, p, d, idx, val, [&] { return rpo_uniform_r(g, lo, hi); });
+}
+
+// Batch.hs:57-61: sample seed $ replicateM ntrees $ V.replicateM maxd (sparse pnz dim stdNormal)
+void rpo_forest_hyperplanes(uint64_t seed, int32_t T, int32_t L, double pnz, int32_t d, double* R,
+                            int32_t* nnz) {
+  rpo_gen g;
+  rpo_gen_init(&g, seed);
+  std::vector<int32_t> idx((size_t)d);
+  std::vector<double> val((size_t)d);
+  std::memset(R, 0, sizeof(double) * (size_t)T * L * d);
+  for (int32_t t = 0; t < T; ++t)
+    for (int32_t l = 0; l < L; ++l) {
+      int64_t m = rpo_sparse_normal(&g, pnz, d, 0.0, 1.0, idx.data(), val.data());
+      double* r = R + ((int64_t)t * L + l) * d;
+      for (int64_t j = 0; j < m; ++j) r[idx[j]] = val[j];
+      if (nnz) nnz[(int64_t)t * L + l] = (int32_t)m;
+    }
+}
+
+// Gen.hs:132-137 normalDense2: b <- bernoulli 0.5; dense d (normal 0 0.5) | dense d (normal 2 0.5)
+void rpo_data_normal_dense2(uint64_t seed, int64_t n, int32_t d, double* X) {
+  rpo_gen g;
+  rpo_gen_init(&g, seed);
+  for (int64_t i = 0; i < n; ++i) {
+    double mu = rpo_bernoulli(&g, 0.5) ? 0.0 : 2.0;
+    for (int32_t j = 0; j < d; ++j) X[i * d + j] = rpo_normal(&g, mu, 0.5);
+  }
+}
+
+// test/Data/RPTreeSpec.hs:112-120 circle2d2 over Gen.hs:115-123 circle2d (note: the test
+// `x**2 + y**2 <= r` compares with r, not r^2 — restated as written; r = 1 so no difference)
+void rpo_data_circle2d2(uint64_t seed, int64_t n, double* X) {
+  rpo_gen g;
+  rpo_gen_init(&g, seed);
+  const double r = 1.0;
+  for (int64_t i = 0; i < n; ++i) {
+    int b = rpo_bernoulli(&g, 0.5);
+    double x, y;
+    for (;;) {
+      x = rpo_uniform_r(&g, -r, r);
+      y = rpo_uniform_r(&g, -r, r);
+      if (std::pow(x, 2.0) + std::pow(y, 2.0) <= r) break;
+    }
+    if (b) {
+      X[2 * i] = x;
+      X[2 * i + 1] = y;
+    } else {  // (^+^ d) with d = [2,3]: zipWith (+) d c, Internal.hs:340
+      X[2 * i] = 2.0 + x;
+      X[2 * i + 1] = 3.0 + y;
+    }
+  }
+}
+
+int64_t rpo_data_normal_sparse2(uint64_t seed, int64_t n, int32_t d, double pnz, int64_t* rowptr,
+                                int32_t* col, double* val, int64_t cap) {
+  rpo_gen g;
+  rpo_gen_init(&g, seed);
+  std::vector<int32_t> idx((size_t)d);
+  std::vector<double> v((size_t)d);
+  int64_t nnz = 0;
+  rowptr[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {  // Gen.hs:125-130
+    double mu = rpo_bernoulli(&g, 0.5) ? 0.0 : 2.0;
+    int64_t m = rpo_sparse_normal(&g, pnz, d, mu, 0.5, idx.data(), v.data());
+    for (int64_t j = 0; j < m && nnz + j < cap; ++j) {
+      col[nnz + j] = idx[j];
+      val[nnz + j] = v[j];
+    }
+    nnz += m;
+    rowptr[i + 1] = nnz;
+  }
+  return nnz;
+}
+
+int64_t rpo_data_sparse_uniform(uint64_t seed, int64_t n, int32_t d, double pnz, int64_t* rowptr,
+                                int32_t* col, double* val, int64_t cap) {
+  rpo_gen g;
+  rpo_gen_init(&g, seed);
+  std::vector<int32_t> idx((size_t)d);
+  std::vector<double> v((size_t)d);
+  int64_t nnz = 0;
+  rowptr[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    // values in (0,1]: 1 - u with u in [0,1)   (toUnitRange-like, bench/time/Main.hs:124-125)
+    int64_t m = sparse_vg(&g, pnz, d, idx.data(), v.data(),
+                          [&] { return 1.0 - rpo_next_double(&g); });
+    for (int64_t j = 0; j < m && nnz + j < cap; ++j) {
+      col[nnz + j] = idx[j];
+      val[nnz + j] = v[j];
+    }
+    nnz += m;
+    rowptr[i + 1] = nnz;
+  }
+  return nnz;
+}
+
+// ------------------------------- algebra ---------------------------------------------------
+// Internal.hs:351-366 innerSS: sorted-index merge join, RIGHT-nested sum with terminal 0:
+//   EQ -> (xl * xr +) $ go (succ i1) (succ i2)
+double rpo_inner_ss(int64_t n1, const int32_t* i1, const double* v1, int64_t n2, const int32_t* i2,
+                    const double* v2) {
+  // collect the matched products in visit order, then fold from the right
+  static thread_local std::vector<double> prods;
+  prods.clear();
+  int64_t a = 0, b = 0;
+  while (a < n1 && b < n2) {  // :358
+    if (i1[a] == i2[b]) {     // :364
+      prods.push_back(v1[a] * v2[b]);
+      ++a;
+      ++b;
+    } else if (i1[a] < i2[b]) {  // :365
+      ++a;
+    } else {  // :366
+      ++b;
+    }
+  }
+  const int64_t m = (int64_t)prods.size();
+  double acc = 0.0;
+  for (int64_t j = m - 1; j >= 0; --j) acc = prods[j] + acc;
+  return acc;
+}
+
+// Internal.hs:369-382 innerSD: go i | i >= nz1 || i >= nz2 = 0 ; (xl * xr +) $ go (succ i)
+// NB the guard compares the NONZERO COUNTER with the dense length (:376) — restated as is.
+double rpo_inner_sd(int64_t n1, const int32_t* i1, const double* v1, int64_t n2, const double* x) {
+  int64_t m = n1 < n2 ? n1 : n2;
+  double acc = 0.0;
+  for (int64_t j = m - 1; j >= 0; --j) acc = v1[j] * x[i1[j]] + acc;
+  return acc;
+}
+
+// Internal.hs:384-385 innerDD = VG.sum $ VG.zipWith (*): left fold from 0
+double rpo_inner_dd(int64_t n, const double* a, const double* b) {
+  double acc = 0.0;
+  for (int64_t j = 0; j < n; ++j) acc = acc + a[j] * b[j];
+  return acc;
+}
+
+// Internal.hs:403-406 metricDDL2 = sqrt $ VG.sum $ VG.map (** 2) (zipWith (-) u v)
+double rpo_metric_dd(int64_t n, const double* u, const double* v) {
+  double acc = 0.0;
+  for (int64_t j = 0; j < n; ++j) acc = acc + std::pow(u[j] - v[j], 2.0);
+  return std::sqrt(acc);
+}
+
+// Internal.hs:455-470 binSDD f z: stops when EITHER operand is exhausted (:462)
+static int64_t bin_sdd(bool minus, int64_t n1, const int32_t* i1, const double* v1, int64_t n2,
+                       const double* x, double* out) {
+  int64_t a = 0, b = 0, m = 0;
+  while (a < n1 && b < n2) {
+    double xl, xr;
+    if (i1[a] == b) {  // EQ :468
+      xl = v1[a];
+      xr = x[b];
+      ++a;
+      ++b;
+    } else if (i1[a] < b) {  // LT :469 f xl z
+      xl = v1[a];
+      xr = 0.0;
+      ++a;
+    } else {  // GT :470 f z xr
+      xl = 0.0;
+      xr = x[b];
+      ++b;
+    }
+    out[m++] = minus ? xl - xr : xl + xr;
+  }
+  return m;
+}
+int64_t rpo_sum_sd(int64_t n1, const int32_t* i1, const double* v1, int64_t n2, const double* x,
+                   double* out) {
+  return bin_sdd(false, n1, i1, v1, n2, x, out);
+}
+int64_t rpo_diff_sd(int64_t n1, const int32_t* i1, const double* v1, int64_t n2, const double* x,
+                    double* out) {
+  return bin_sdd(true, n1, i1, v1, n2, x, out);
+}
+
+// Internal.hs:396-400 metricSDL2 u v = sqrt $ sum $ map (**2) (u `diffSD` v)
+double rpo_metric_sd(int64_t n1, const int32_t* i1, const double* v1, int64_t n2,
+                     const double* x) {
+  std::vector<double> duv((size_t)n2);
+  int64_t m = bin_sdd(true, n1, i1, v1, n2, x, duv.data());
+  double acc = 0.0;
+  for (int64_t j = 0; j < m; ++j) acc = acc + std::pow(duv[j], 2.0);
+  return std::sqrt(acc);
+}
+
+// Internal.hs:389-393 metricSSL2 over :435-450 binSS (-) 0 (stops when either is exhausted)
+double rpo_metric_ss(int64_t n1, const int32_t* i1, const double* v1, int64_t n2,
+                     const int32_t* i2, const double* v2) {
+  int64_t a = 0, b = 0;
+  double acc = 0.0;
+  while (a < n1 && b < n2) {  // :442
+    double y;
+    if (i1[a] == i2[b]) y = v1[a++] - v2[b++];  // :448
+    else if (i1[a] < i2[b]) y = v1[a++] - 0.0;  // :449
+    else y = 0.0 - v2[b++];                     // :450
+    acc = acc + std::pow(y, 2.0);
+  }
+  return std::sqrt(acc);
+}
+
+// Conduit.hs:132-141
+void rpo_tree_cfg(int32_t minLeaf, int64_t n, int32_t d, int32_t* maxDepth, int64_t* chunk,
+                  double* pnz) {
+  double x = std::log((double)n / (double)minLeaf) / std::log(2.0);  // logBase 2 (n / minl)
+  *maxDepth = (int32_t)std::ceil(x);
+  *chunk = (int64_t)std::ceil((double)n / 100.0);
+  double pnzMin = 1.0 / (std::log((double)d) / std::log(10.0));  // 1 / logBase 10 d
+  *pnz = pnzMin < 1.0 ? pnzMin : 1.0;
+}
+
+// Internal.hs:486-512 on precomputed projections
+int64_t rpo_partition_at_median(int64_t n, const double* p, int32_t* order, double* thr_mg) {
+  if (n < 1) return -1;  // :492 Nothing
+  std::vector<std::pair<double, int32_t>> projs((size_t)n);
+  for (int64_t i = 0; i < n; ++i) projs[i] = {p[i], (int32_t)i};
+  std::stable_sort(projs.begin(), projs.end(),
+                   [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) {
+                     return a.first < b.first;
+                   });
+  const int64_t nh = n / 2;
+  for (int64_t i = 0; i < n; ++i) order[i] = projs[i].second;
+  thr_mg[0] = projs[nh].first;
+  if (n >= 3) {
+    thr_mg[1] = projs[nh - 1].first;
+    thr_mg[2] = projs[nh + 1].first;
+  } else if (n == 2) {
+    thr_mg[1] = projs[0].first;
+    thr_mg[2] = projs[1].first;
+  } else {
+    thr_mg[1] = thr_mg[2] = projs[0].first;
+  }
+  return nh;
+}
+
+// ------------------------------- build -----------------------------------------------------
+void rpo_forest_build_dense(const double* X, int64_t N, int32_t d, const double* R, int32_t T,
+                            int32_t L, int32_t minLeaf, int32_t* perm, double* thr, double* mglo,
+                            double* mghi, double* proj_out) {
+  DenseData D{X, N, d};
+  forest_build(D, R, T, L, minLeaf, perm, thr, mglo, mghi, proj_out);
+}
+void rpo_forest_build_csr(const int64_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                          int32_t d, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                          int32_t* perm, double* thr, double* mglo, double* mghi,
+                          double* proj_out) {
+  CsrData D{rowptr, col, val, N, d};
+  forest_build(D, R, T, L, minLeaf, perm, thr, mglo, mghi, proj_out);
+}
+
+// ------------------------------- queries ---------------------------------------------------
+int64_t rpo_candidates_dense(const double* q, int32_t d, const double* R, int32_t T, int32_t L,
+                             int32_t minLeaf, int64_t N, const int32_t* perm, const double* thr,
+                             const double* mglo, const double* mghi, int32_t t, int32_t* out,
+                             int64_t cap) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<int32_t> c;
+  tree_candidates(
+      [&](const SparseVec& r) {
+        return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+      },
+      all, L, minLeaf, N, perm, thr, mglo, mghi, t, c);
+  for (int64_t i = 0; i < (int64_t)c.size() && i < cap; ++i) out[i] = c[i];
+  return (int64_t)c.size();
+}
+
+int64_t rpo_candidates_sparse(int64_t qn, const int32_t* qi, const double* qv, int32_t d,
+                              const double* R, int32_t T, int32_t L, int32_t minLeaf, int64_t N,
+                              const int32_t* perm, const double* thr, const double* mglo,
+                              const double* mghi, int32_t t, int32_t* out, int64_t cap) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<int32_t> c;
+  tree_candidates(
+      [&](const SparseVec& r) {
+        return rpo_inner_ss((int64_t)r.idx.size(), r.idx.data(), r.val.data(), qn, qi, qv);
+      },
+      all, L, minLeaf, N, perm, thr, mglo, mghi, t, c);
+  for (int64_t i = 0; i < (int64_t)c.size() && i < cap; ++i) out[i] = c[i];
+  return (int64_t)c.size();
+}
+
+// RPTree.hs:174-176: cs = map (\xe -> (eEmbed xe `distf` q, xe)) $ fold $ (`candidates` q) <$> tts
+int32_t rpo_knn_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                      int32_t T, int32_t L, int32_t minLeaf, const int32_t* perm,
+                      const double* thr, const double* mglo, const double* mghi, int32_t k,
+                      int32_t dedup, int32_t* out_ids, double* out_dist) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<int32_t> c;
+  for (int32_t t = 0; t < T; ++t)  // fold over the IntMap: ascending key, concatenation
+    tree_candidates(
+        [&](const SparseVec& r) {
+          return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+        },
+        all, L, minLeaf, N, perm, thr, mglo, mghi, t, c);
+  std::vector<DistId> cs(c.size());
+  for (size_t i = 0; i < c.size(); ++i)
+    cs[i] = {rpo_metric_dd(d, X + (int64_t)c[i] * d, q), c[i]};  // metricL2 DVector DVector :339
+  return topk_from(cs, k, dedup, out_ids, out_dist);
+}
+
+int32_t rpo_knn_csr(const int64_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                    int32_t d, int64_t qn, const int32_t* qi, const double* qv, const double* R,
+                    int32_t T, int32_t L, int32_t minLeaf, const int32_t* perm, const double* thr,
+                    const double* mglo, const double* mghi, int32_t k, int32_t dedup,
+                    int32_t true_l2, int32_t* out_ids, double* out_dist) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<int32_t> c;
+  for (int32_t t = 0; t < T; ++t)
+    tree_candidates(
+        [&](const SparseVec& r) {
+          return rpo_inner_ss((int64_t)r.idx.size(), r.idx.data(), r.val.data(), qn, qi, qv);
+        },
+        all, L, minLeaf, N, perm, thr, mglo, mghi, t, c);
+  std::vector<DistId> cs(c.size());
+  for (size_t i = 0; i < c.size(); ++i) {
+    int64_t a = rowptr[c[i]], b = rowptr[c[i] + 1];
+    double dist = true_l2 ? true_l2_ss(b - a, col + a, val + a, qn, qi, qv)
+                          : rpo_metric_ss(b - a, col + a, val + a, qn, qi, qv);  // :324
+    cs[i] = {dist, c[i]};
+  }
+  return topk_from(cs, k, dedup, out_ids, out_dist);
+}
+
+// RPTree.hs:259-282
+double rpo_recall_with_dense(const double* X, int64_t N, int32_t d, const double* q,
+                             const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                             const int32_t* perm, const double* thr, const double* mglo,
+                             const double* mghi, int32_t k) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  double sum = 0.0;
+  for (int32_t t = 0; t < T; ++t) {  // :265-268 mean over trees
+    std::vector<int32_t> c;
+    tree_candidates(
+        [&](const SparseVec& r) {
+          return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+        },
+        all, L, minLeaf, N, perm, thr, mglo, mghi, t, c);
+    std::set<int32_t> aa(c.begin(), c.end());  // :279
+    // :280-282 dists = sortBy (comparing snd) over `points tt` (leaf order = perm order)
+    std::vector<DistId> ds((size_t)N);
+    const int32_t* pt = perm + (int64_t)t * N;
+    for (int64_t i = 0; i < N; ++i) ds[i] = {rpo_metric_dd(d, X + (int64_t)pt[i] * d, q), pt[i]};
+    std::stable_sort(ds.begin(), ds.end(),
+                     [](const DistId& a, const DistId& b) { return a.dist < b.dist; });
+    std::set<int32_t> kk;
+    for (int64_t i = 0; i < k && i < N; ++i) kk.insert(ds[i].id);
+    int64_t inter = 0;
+    for (int32_t id : kk) inter += aa.count(id);
+    sum += (double)inter / (double)k;  // :276-278
+  }
+  return sum / (double)T;
+}
+
+void rpo_brute_knn_dense(const double* X, int64_t N, int32_t d, const double* q, int32_t k,
+                         int32_t* out_ids, double* out_dist) {
+  std::vector<DistId> ds((size_t)N);
+  for (int64_t i = 0; i < N; ++i) ds[i] = {rpo_metric_dd(d, X + i * d, q), (int32_t)i};
+  int64_t kk = k < N ? k : N;
+  std::partial_sort(ds.begin(), ds.begin() + kk, ds.end(), [](const DistId& a, const DistId& b) {
+    return a.dist < b.dist || (a.dist == b.dist && a.id < b.id);
+  });
+  for (int64_t i = 0; i < kk; ++i) {
+    out_ids[i] = ds[i].id;
+    out_dist[i] = ds[i].dist;
+  }
+}
+
+}  // extern "C"

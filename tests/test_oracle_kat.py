@@ -1,0 +1,160 @@
+"""Pins the CPU oracle against the reference's own known-answer tests
+(test/Data/RPTreeSpec.hs:21-45) and structural invariants (:66-85)."""
+import math
+
+import numpy as np
+
+# test/Data/RPTreeSpec.hs:22-27
+VS0 = ([1, 4], [3.4, 2.1])          # fromListSv 5 [(1, 3.4), (4, 2.1)]
+VS1 = ([0, 3], [6.7, 5.5])          # fromListSv 5 [(0, 6.7), (3, 5.5)]
+V1 = [1.0, 2.0, 3.0, 4.0, 5.0]      # fromListDv [1,2,3,4,5]
+
+
+def test_kat_sum_sparse_dense(oracle):      # RPTreeSpec.hs:28-32, exact Double equality
+    got = oracle.sum_sd(*VS0, V1)
+    assert got.tolist() == [1, 5.4, 3, 4, 7.1]
+
+
+def test_kat_diff_sparse_dense(oracle):     # RPTreeSpec.hs:33-37
+    got = oracle.diff_sd(*VS0, V1)
+    assert got.tolist() == [-1, 1.4, -3, -4, -2.9]
+
+
+def test_kat_inner_sparse_sparse(oracle):   # RPTreeSpec.hs:38-41
+    assert oracle.inner_ss(*VS0, *VS1) == 0
+
+
+def test_kat_inner_sparse_dense(oracle):    # RPTreeSpec.hs:42-45
+    assert oracle.inner_sd(*VS0, V1) == 17.3
+
+
+def test_summation_orders(oracle):
+    # innerSD/innerSS are right-nested, innerDD a left fold (Internal.hs:364,382,385):
+    # with these values the two orders give different doubles.
+    idx = [0, 1, 2]
+    a = [1e16, 1.0, 1.0]
+    x = [1.0, 1.0, 1.0]
+    assert oracle.inner_sd(idx, a, x) == 1e16 + (1.0 + (1.0 + 0.0))
+    assert oracle.inner_dd(a, x) == ((0.0 + 1e16) + 1.0) + 1.0
+    assert oracle.inner_sd(idx, a, x) != oracle.inner_dd(a, x)
+    assert oracle.inner_ss(idx, a, idx, x) == oracle.inner_sd(idx, a, x)
+
+
+def test_inner_sd_counter_guard(oracle):
+    # Internal.hs:376 compares the nonzero COUNTER with the dense length
+    assert oracle.inner_sd([0, 0, 0], [1.0, 2.0, 4.0], [10.0, 20.0]) == 1.0 * 10 + 2.0 * 10
+
+
+def test_metric_truncation_quirk(oracle):
+    # binSDD stops when either operand is exhausted (Internal.hs:462): the dense tail past
+    # the sparse vector's last index is dropped.
+    assert oracle.metric_sd([1], [3.0], [1.0, 1.0, 100.0]) == math.sqrt(1.0 + 4.0)
+    assert oracle.metric_dd([0.0, 3.0], [4.0, 0.0]) == 5.0
+    assert oracle.metric_ss([0, 2], [1.0, 1.0], [2, 5], [1.0, 9.0]) == 1.0
+
+
+def test_tree_cfg(oracle):
+    # Conduit.hs:132-141; the SURVEY §8d table values
+    assert oracle.tree_cfg(20, 10000, 2)[0] == 9
+    md, chunk, pnz = oracle.tree_cfg(128, 1_000_000, 128)
+    assert (md, chunk) == (13, 10000)
+    assert abs(pnz - 0.4746) < 1e-4
+    assert oracle.tree_cfg(20, 10000, 2)[2] == 1.0
+
+
+def test_partition_at_median_small(oracle):
+    # Internal.hs:496-503 incl. the n==1 / n==2 special cases and -0.0 == 0.0 ties
+    nh, order, thr, lo, hi = oracle.partition_at_median([5.0])
+    assert (nh, order.tolist(), thr, lo, hi) == (0, [0], 5.0, 5.0, 5.0)
+    nh, order, thr, lo, hi = oracle.partition_at_median([2.0, 1.0])
+    assert (nh, order.tolist(), thr, lo, hi) == (1, [1, 0], 2.0, 1.0, 2.0)
+    nh, order, thr, lo, hi = oracle.partition_at_median([3.0, 1.0, 2.0])
+    assert (nh, order.tolist(), thr, lo, hi) == (1, [1, 2, 0], 2.0, 1.0, 3.0)
+    nh, order, thr, lo, hi = oracle.partition_at_median([0.0, -0.0, 0.0, -1.0])
+    assert (nh, order.tolist()) == (2, [3, 0, 1, 2])
+    nh, order, thr, lo, hi = oracle.partition_at_median([1.0] * 7)
+    assert (nh, order.tolist(), thr, lo, hi) == (3, list(range(7)), 1.0, 1.0, 1.0)
+    assert oracle.partition_at_median([])[0] == -1
+
+
+def _check_forest_invariants(oracle, f):
+    topo = oracle.topology(f.N, f.L, f.min_leaf)
+    for t in range(f.T):
+        # test/Data/RPTreeSpec.hs:66-67 "all data points should appear in every tree"
+        assert sorted(f.perm[t].tolist()) == list(range(f.N))
+        for level, heap, off, n, leaf in topo:
+            if leaf:
+                if heap < f.thr.shape[1]:
+                    assert math.isnan(f.thr[t, heap])
+                continue
+            assert f.mglo[t, heap] <= f.thr[t, heap] <= f.mghi[t, heap] or n < 3
+            nh = n // 2
+            p = f.proj[t, level]
+            left = p[f.perm[t, off:off + nh]]
+            right = p[f.perm[t, off + nh:off + n]]
+            assert left.max() <= f.thr[t, heap] == right.min()
+            if n >= 3:
+                assert f.mglo[t, heap] == left.max()
+                assert f.mghi[t, heap] == np.sort(right)[1]
+
+
+def test_forest_invariants_dense(oracle):
+    X = oracle.data_normal_dense2(1234, 1000, 16)
+    L, _, pnz = oracle.tree_cfg(20, 1000, 16)
+    R, nnz = oracle.forest_hyperplanes(1235137, 3, L, pnz, 16)
+    assert ((R != 0).sum(axis=2) == nnz).all()
+    f = oracle.forest_build_dense(X, R, 20, want_proj=True)
+    _check_forest_invariants(oracle, f)
+    # projections are innerSD of the level's hyperplane (Internal.hs:504)
+    idx = np.nonzero(R[1, 2])[0]
+    for i in (0, 17, 999):
+        if not math.isnan(f.proj[1, 2, i]):
+            assert f.proj[1, 2, i] == oracle.inner_sd(idx, R[1, 2, idx], X[i])
+
+
+def test_forest_invariants_sparse_with_ties(oracle):
+    rowptr, col, val = oracle.data_normal_sparse2(1234, 600, 12, 0.25)
+    R, _ = oracle.forest_hyperplanes(7, 3, 5, 0.3, 12)
+    f = oracle.forest_build_csr(rowptr, col, val, 12, R, 10, want_proj=True)
+    _check_forest_invariants(oracle, f)
+    # the point of this case: many exact-zero projections (ties at the cut)
+    assert (f.proj[0, 0] == 0).sum() > 50
+
+
+def test_two_discs_knn(oracle):
+    # test/Data/RPTreeSpec.hs:50-85: n=10000 two unit discs, 10 trees, minLeaf 20, k=5,
+    # pnz=1.0, dim 2, query (0,0): all points in every tree; max knn distance < 1.
+    n, T, min_leaf, k = 10000, 10, 20, 5
+    X = oracle.data_circle2d2(42, n)
+    L, _, _ = oracle.tree_cfg(min_leaf, n, 2)
+    R, _ = oracle.forest_hyperplanes(42, T, L, 1.0, 2)
+    f = oracle.forest_build_dense(X, R, min_leaf)
+    for t in range(T):
+        assert np.array_equal(np.sort(f.perm[t]), np.arange(n))
+    ids, dist = oracle.knn_dense(f, X, [0.0, 0.0], k)
+    assert len(ids) == k and dist.max() < 1
+    assert (np.diff(dist) >= 0).all()
+    # knn keeps duplicates across trees (RPTree.hs:174-176); dedup is our extension
+    ids_d, dist_d = oracle.knn_dense(f, X, [0.0, 0.0], k, dedup=True)
+    assert len(set(ids_d.tolist())) == len(ids_d)
+    r = oracle.recall_with_dense(f, X, [0.0, 0.0], k)
+    assert 0.0 <= r <= 1.0
+
+
+def test_candidates_rule(oracle):
+    # hand-built 1-level tree: thr 0, margins (-1, +2) -> RPTree.hs:309-314
+    import numpy as np
+    from oracle.oracle import Forest
+    R = np.array([[[1.0]]])
+    f = Forest(4, 1, R, 1, 1, np.array([[0, 1, 2, 3]], dtype=np.int32),
+               np.array([[0.0]]), np.array([[-1.0]]), np.array([[2.0]]))
+    # proj < thr, dl=|−1−p|, dr=|2−p|: p=-0.2 -> dl=.8 < dr=2.2 -> left only
+    assert oracle.candidates_dense(f, [-0.2], 0).tolist() == [0, 1]
+    # p = 0 == thr -> otherwise-branch -> right
+    assert oracle.candidates_dense(f, [0.0], 0).tolist() == [2, 3]
+    # p = 0.4 > thr, dl=1.4 < dr=1.6 -> both
+    assert oracle.candidates_dense(f, [0.4], 0).tolist() == [0, 1, 2, 3]
+    # p = 0.6 > thr, dl=1.6 > dr=1.4 -> right only
+    assert oracle.candidates_dense(f, [0.6], 0).tolist() == [2, 3]
+    # p = -5: proj < thr, dl=4 < dr=7 -> left only
+    assert oracle.candidates_dense(f, [-5.0], 0).tolist() == [0, 1]
