@@ -1,0 +1,181 @@
+/*
+ * rptree_hip.h — C ABI of the MI355X (gfx950) implementation of rp-tree's random-projection
+ * hot path.  This is the drop-in boundary: the entry points are what a Haskell
+ * `foreign import ccall` layer under the unchanged Data.RPTree API binds.
+ *
+ * The reference (ocramz/rp-tree v0.7.1) is closed pure Haskell with no FFI or plugin
+ * interface; each entry point therefore names the reference FUNCTION it
+ * replaces (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *   - Plain C: opaque handles, raw pointers, sizes.  No torch / C++ types.
+ *   - Every function returns an int32 status: 0 = ok, negative = error (RPT_E_*).
+ *     rpt_last_error() returns a message for the calling thread.  Nothing throws or aborts
+ *     across the ABI.  There is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with RPT_E_HIP.
+ *   - Ownership: the caller owns every host buffer it passes or receives.  The library owns
+ *     device memory behind the opaque handles; release it with the matching *_free.
+ *   - Pointers named *_host are host memory, *_dev are device (HBM) addresses of the ctx's
+ *     device, e.g. torch tensor .data_ptr() values.
+ *   - Threading: re-entrant per rpt_ctx (one ctx = one device + one stream); a ctx is not
+ *     thread-safe.  All work of a ctx is enqueued on its stream; entry points that return
+ *     host data synchronise that stream, *_dev entry points do not (call rpt_ctx_sync).
+ *
+ * Flat forest layout (identical to oracle/rptree_oracle.h):
+ *   perm[T][N]  int32   point ids; per tree the concatenation of the leaf buckets in
+ *                       left-to-right order, each bucket in the reference's order
+ *                       (Internal.hs:495,504-505: children inherit the stably sorted order).
+ *   thr, mglo, mghi  double [T][2^L-1], heap order (root 0, children 2h+1, 2h+2); NaN where
+ *                       the slot is not a Bin.  = _rpThreshold / _rpMargin of `RPT`
+ *                       (Internal.hs:139-145), values per Internal.hs:496-501.
+ *   The topology (Bin vs Tip, every node's offset and size) is a pure function of
+ *   (N, minLeaf, maxDepth): Internal.hs:289 and :495,503; rpt_topology() enumerates it.
+ */
+#ifndef RPTREE_HIP_H
+#define RPTREE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPT_ABI_VERSION 1
+
+/* status codes */
+#define RPT_OK 0
+#define RPT_E_ARG (-1)      /* invalid argument */
+#define RPT_E_HIP (-2)      /* HIP runtime / device error (incl. no device) */
+#define RPT_E_NOMEM (-3)    /* host or device allocation failed */
+#define RPT_E_UNSUPPORTED (-4)
+#define RPT_E_INTERNAL (-5)
+
+/* element types of datasets / queries */
+#define RPT_F64 0           /* the reference's only type (Double) */
+#define RPT_F32 1           /* build extension */
+#define RPT_BF16 2          /* build extension */
+
+/* projection modes (rpt_project, rpt_forest_build flags) */
+#define RPT_PROJ_AUTO 0     /* f64 data: EXACT; f32/bf16 data: MFMA */
+#define RPT_PROJ_EXACT 1    /* f64 VALU, the reference's summation order and no FMA
+                               (Internal.hs:382): bit-identical to innerSD/innerSS */
+#define RPT_PROJ_MFMA 2     /* MFMA tiles (f64/f32/bf16 inputs), k-ordered fma chain:
+                               within 1e-5*|x||r| of the reference value */
+
+/* knn flags */
+#define RPT_KNN_KEEP_DUPLICATES 0 /* the reference: RPTree.hs:174-176 never de-duplicates */
+#define RPT_KNN_DEDUP 1           /* extension: each point id at most once */
+
+typedef struct rpt_ctx rpt_ctx;
+typedef struct rpt_dataset rpt_dataset;
+typedef struct rpt_forest rpt_forest;
+
+/* ---- library / context ---- */
+int32_t rpt_abi_version(void);
+const char* rpt_last_error(void);
+int32_t rpt_device_count(int32_t* count);
+int32_t rpt_ctx_create(int32_t device, rpt_ctx** out);
+int32_t rpt_ctx_destroy(rpt_ctx* ctx);
+int32_t rpt_ctx_sync(rpt_ctx* ctx);
+/* the hipStream_t all work of this ctx is enqueued on (for HIP-event timing by the caller) */
+int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
+
+/* ---- datasets: Embed / DVector / SVector carriers (Internal.hs:56-59,92-93,122) ----
+ * dense: row-major X[n][d] (`V.Vector (Embed DVector Double x)` packed once at the boundary).
+ * csr:   SVector rows: rowptr[n+1] (int64), col[nnz] (int32, ascending per row, < d), val.
+ * *_host variants copy to HBM; *_dev variants borrow device memory that must outlive the
+ * handle.  Query batches use the same handle type. */
+int32_t rpt_dataset_dense_host(rpt_ctx* ctx, const void* X_host, int64_t n, int32_t d,
+                               int32_t dtype, rpt_dataset** out);
+int32_t rpt_dataset_dense_dev(rpt_ctx* ctx, const void* X_dev, int64_t n, int32_t d,
+                              int32_t dtype, rpt_dataset** out);
+int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int32_t* col_host,
+                             const void* val_host, int64_t n, int32_t d, int32_t dtype,
+                             rpt_dataset** out);
+int32_t rpt_dataset_free(rpt_dataset* ds);
+int32_t rpt_dataset_info(const rpt_dataset* ds, int64_t* n, int32_t* d, int32_t* dtype,
+                         int32_t* is_csr, int64_t* nnz);
+
+/* ---- topology: Internal.hs:289 (leaf test), :495,503 (cut at n div 2) ----
+ * Enumerates the nodes in DFS (pre-)order.  Each record is 5 int64:
+ * {level, heap, offset, size, is_leaf}.  Pass out=NULL to get the count only. */
+int32_t rpt_topology(int64_t n, int32_t max_depth, int32_t min_leaf, int64_t* out,
+                     int64_t cap_records, int64_t* n_records);
+
+/* ---- projection batch: replaces the N `inner` calls of Internal.hs:504 ----
+ * P[c][i] = R[c] `inner` x_i  for C hyperplanes R_host[C][d] (dense-ified SVectors; zeros are
+ * skipped exactly like the sparse representation skips them).  Output in the compute type:
+ * double for F64 data, float for F32/BF16 data.  P_host / P_dev is [C][n]. */
+int32_t rpt_project_host(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,
+                         int32_t mode, void* P_host);
+int32_t rpt_project_dev(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,
+                        int32_t mode, void* P_dev);
+
+/* ---- forest build: replaces createMulti/create/insert/partitionAtMedian/sortByVG
+ * (Internal.hs:217-297,486-512) under forestBatch / treeBatch (Batch.hs:29-63) ----
+ * R_host[T][L][d]: the hyperplanes sampled by the HOST (Batch.hs:59-61), dense-ified.
+ * L = maxDepth.  flags: RPT_PROJ_* mode. */
+int32_t rpt_forest_build(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                         int32_t L, int32_t min_leaf, int32_t flags, rpt_forest** out);
+int32_t rpt_forest_free(rpt_forest* f);
+int32_t rpt_forest_info(const rpt_forest* f, int64_t* n, int32_t* d, int32_t* T, int32_t* L,
+                        int32_t* min_leaf);
+/* copy-out accessors so the host can rebuild ordinary `RPT` values (Internal.hs:139-149) */
+int32_t rpt_forest_get_perm(rpt_forest* f, int32_t* perm_host /*[T][N]*/);
+int32_t rpt_forest_get_nodes(rpt_forest* f, double* thr_host, double* mglo_host,
+                             double* mghi_host /* each [T][2^L-1] */);
+/* projections computed during the build, [T][L][N] in the compute type (parity tests) */
+int32_t rpt_forest_get_proj(rpt_forest* f, void* proj_host);
+/* import a forest built elsewhere (e.g. deserialiseRPForest, Internal.hs:191-196) */
+int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                          int32_t L, int32_t min_leaf, const int32_t* perm_host,
+                          const double* thr_host, const double* mglo_host,
+                          const double* mghi_host, rpt_forest** out);
+/* number of nodes whose cut went through the exact tie-resolution path (statistics) */
+int32_t rpt_forest_stats(rpt_forest* f, int64_t* tie_nodes, int64_t* big_mid_nodes);
+
+/* ---- split of one level on caller-supplied projections: partitionAtMedian
+ * (Internal.hs:486-505) for every node of a segment list, for integer parity on IDENTICAL
+ * projection inputs.  key_host[n]: projections indexed by point id.  seg_off/seg_len[S]:
+ * disjoint segments of perm_io_host[n] (ids).  On return every segment is stably sorted by
+ * key (ties: previous position), thr_mg_host[S][3] = {thr, mglo, mghi}. */
+int32_t rpt_split_segments(rpt_ctx* ctx, const double* key_host, int64_t n,
+                           int32_t* perm_io_host, const int64_t* seg_off_host,
+                           const int64_t* seg_len_host, int32_t S, double* thr_mg_host);
+
+/* ---- queries ----
+ * candidates (RPTree.hs:289-314): for every (query, tree) the leaf buckets reached, in
+ * left-to-right order.  Output is CSR-like: off_host[nq*T + 1] (int64) into ids_host.
+ * Two-call protocol: ids_host = NULL -> only *total is written. */
+int32_t rpt_candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* queries,
+                       int64_t* off_host, int32_t* ids_host, int64_t cap, int64_t* total);
+
+/* knn (RPTree.hs:168-176) with distf = metricL2 (Internal.hs:318, metricDDL2 :403-406 /
+ * true Euclidean distance for CSR data): per query the k best (distance, id), stable in
+ * candidate order (tree ascending, then leaf order).  ids/dist are [nq][k]; count[nq] is the
+ * number of valid entries (< k when fewer candidates).  Unused slots: id -1, dist +inf. */
+int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                     const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_host,
+                     double* dist_host, int32_t* count_host);
+int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                    const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_dev,
+                    double* dist_dev, int32_t* count_dev);
+/* statistics of the last rpt_knn_* call: total candidates visited (sum over queries) */
+int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total);
+
+/* multi-GPU merge: G per-shard results (shard g holds trees [g*T/G, (g+1)*T/G)), gathered
+ * shard-major as ids_dev[G][nq][k] etc. (e.g. by an RCCL all-gather), merged into the
+ * global top-k with the reference's stable order (shard ascending = tree ascending). */
+int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
+                          const int32_t* count_dev, int32_t G, int64_t nq, int32_t k,
+                          int32_t flags, int32_t* out_ids_dev, double* out_dist_dev,
+                          int32_t* out_count_dev);
+
+/* brute-force exact kNN on the device (evaluation of recall; ties by ascending id) */
+int32_t rpt_brute_knn_host(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* queries,
+                           int32_t k, int32_t* ids_host, double* dist_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

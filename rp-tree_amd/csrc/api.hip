@@ -1,0 +1,528 @@
+// api.hip — C-ABI entry points (include/rptree_hip.h): contexts, datasets, topology,
+// forest accessors and the thin wrappers around the kernels in project/split/knn.hip.
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "common.h"
+
+namespace rpt {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int32_t fail(int32_t code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+void enumerate_topology(int64_t N, int32_t L, int32_t min_leaf, std::vector<Node>& out) {
+  // iterative DFS, pre-order (left before right): Internal.hs:289 leaf test, :495,503 halves
+  struct Item { int32_t level; int64_t heap, off, n; };
+  std::vector<Item> stack;
+  stack.push_back({0, 0, 0, N});
+  while (!stack.empty()) {
+    Item it = stack.back();
+    stack.pop_back();
+    bool leaf = is_leaf(it.level, it.n, L, min_leaf);
+    out.push_back({it.level, it.heap, it.off, it.n, leaf});
+    if (!leaf) {
+      int64_t nh = it.n / 2;
+      stack.push_back({it.level + 1, 2 * it.heap + 2, it.off + nh, it.n - nh});
+      stack.push_back({it.level + 1, 2 * it.heap + 1, it.off, nh});
+    }
+  }
+}
+
+}  // namespace rpt
+
+using namespace rpt;
+
+extern "C" {
+
+int32_t rpt_abi_version(void) { return RPT_ABI_VERSION; }
+const char* rpt_last_error(void) { return g_err.c_str(); }
+
+int32_t rpt_device_count(int32_t* count) {
+  RPT_ARG(count, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(RPT_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = c;
+  return RPT_OK;
+}
+
+int32_t rpt_ctx_create(int32_t device, rpt_ctx** out) {
+  RPT_ARG(out, "out is NULL");
+  *out = nullptr;
+  int c = 0;
+  RPT_HIP(hipGetDeviceCount(&c));
+  if (c <= 0) return fail(RPT_E_HIP, "no HIP device available (there is no CPU fallback)");
+  RPT_ARG(device >= 0 && device < c, "device index out of range");
+  RPT_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  RPT_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RPT_E_UNSUPPORTED,
+                std::string("this library is built for gfx950 only, device is ") +
+                    prop.gcnArchName);
+  rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
+  if (!ctx) return fail(RPT_E_NOMEM, "out of host memory");
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(RPT_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  *out = ctx;
+  return RPT_OK;
+}
+
+int32_t rpt_ctx_destroy(rpt_ctx* ctx) {
+  if (!ctx) return RPT_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+  return RPT_OK;
+}
+
+int32_t rpt_ctx_sync(rpt_ctx* ctx) {
+  RPT_ARG(ctx, "ctx is NULL");
+  RPT_HIP(hipSetDevice(ctx->device));
+  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  return RPT_OK;
+}
+
+int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream) {
+  RPT_ARG(ctx && hip_stream, "NULL argument");
+  *hip_stream = (void*)ctx->stream;
+  return RPT_OK;
+}
+
+// ---- datasets -------------------------------------------------------------------------
+static int32_t check_dtype(int32_t dt) {
+  RPT_ARG(dt == RPT_F64 || dt == RPT_F32 || dt == RPT_BF16, "unknown dtype");
+  return RPT_OK;
+}
+
+int32_t rpt_dataset_dense_host(rpt_ctx* ctx, const void* X_host, int64_t n, int32_t d,
+                               int32_t dtype, rpt_dataset** out) {
+  RPT_ARG(ctx && out, "NULL argument");
+  *out = nullptr;
+  RPT_TRY(check_dtype(dtype));
+  RPT_ARG(n >= 0 && d >= 1, "n must be >= 0 and d >= 1");
+  RPT_ARG(n < (int64_t)0x7fffffff, "n must fit int32 point ids");
+  RPT_ARG(n == 0 || X_host, "X_host is NULL");
+  RPT_HIP(hipSetDevice(ctx->device));
+  rpt_dataset* ds = new (std::nothrow) rpt_dataset();
+  if (!ds) return fail(RPT_E_NOMEM, "out of host memory");
+  ds->ctx = ctx;
+  ds->n = n;
+  ds->d = d;
+  ds->dtype = dtype;
+  ds->owns = true;
+  size_t bytes = (size_t)n * d * dtype_size(dtype);
+  hipError_t e = hipMalloc(&ds->X, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    delete ds;
+    return fail(RPT_E_NOMEM, std::string("hipMalloc dataset: ") + hipGetErrorString(e));
+  }
+  if (bytes) {
+    e = hipMemcpyAsync(ds->X, X_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(ds->X);
+      delete ds;
+      return fail(RPT_E_HIP, std::string("H2D copy: ") + hipGetErrorString(e));
+    }
+  }
+  *out = ds;
+  return RPT_OK;
+}
+
+int32_t rpt_dataset_dense_dev(rpt_ctx* ctx, const void* X_dev, int64_t n, int32_t d,
+                              int32_t dtype, rpt_dataset** out) {
+  RPT_ARG(ctx && out, "NULL argument");
+  *out = nullptr;
+  RPT_TRY(check_dtype(dtype));
+  RPT_ARG(n >= 0 && d >= 1, "n must be >= 0 and d >= 1");
+  RPT_ARG(n < (int64_t)0x7fffffff, "n must fit int32 point ids");
+  RPT_ARG(n == 0 || X_dev, "X_dev is NULL");
+  RPT_ARG(((uintptr_t)X_dev & 15) == 0, "X_dev must be 16-byte aligned");
+  rpt_dataset* ds = new (std::nothrow) rpt_dataset();
+  if (!ds) return fail(RPT_E_NOMEM, "out of host memory");
+  ds->ctx = ctx;
+  ds->n = n;
+  ds->d = d;
+  ds->dtype = dtype;
+  ds->owns = false;
+  ds->X = const_cast<void*>(X_dev);
+  *out = ds;
+  return RPT_OK;
+}
+
+int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int32_t* col_host,
+                             const void* val_host, int64_t n, int32_t d, int32_t dtype,
+                             rpt_dataset** out) {
+  RPT_ARG(ctx && out, "NULL argument");
+  *out = nullptr;
+  RPT_TRY(check_dtype(dtype));
+  RPT_ARG(dtype != RPT_BF16, "CSR datasets are f64 or f32");
+  RPT_ARG(n >= 0 && d >= 1 && rowptr_host, "bad CSR arguments");
+  RPT_ARG(n < (int64_t)0x7fffffff, "n must fit int32 point ids");
+  RPT_ARG(rowptr_host[0] == 0, "rowptr[0] must be 0");
+  int64_t nnz = rowptr_host[n];
+  RPT_ARG(nnz >= 0, "rowptr[n] negative");
+  for (int64_t i = 0; i < n; ++i)
+    RPT_ARG(rowptr_host[i + 1] >= rowptr_host[i], "rowptr must be non-decreasing");
+  RPT_ARG(nnz == 0 || (col_host && val_host), "col/val NULL");
+  // SVector invariants (Internal.hs:99-105) are unchecked in the reference; the kernels
+  // index a dense hyperplane by col, so col < d is validated here to keep HBM accesses in
+  // bounds.
+  for (int64_t j = 0; j < nnz; ++j)
+    RPT_ARG(col_host[j] >= 0 && col_host[j] < d, "CSR column index out of range");
+  RPT_HIP(hipSetDevice(ctx->device));
+  rpt_dataset* ds = new (std::nothrow) rpt_dataset();
+  if (!ds) return fail(RPT_E_NOMEM, "out of host memory");
+  ds->ctx = ctx;
+  ds->n = n;
+  ds->d = d;
+  ds->dtype = dtype;
+  ds->csr = true;
+  ds->owns = true;
+  ds->nnz = nnz;
+  size_t vb = (size_t)nnz * dtype_size(dtype);
+  hipError_t e = hipMalloc((void**)&ds->rowptr, (size_t)(n + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&ds->col, nnz ? (size_t)nnz * 4 : 16);
+  if (e == hipSuccess) e = hipMalloc(&ds->val, vb ? vb : 16);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(ds->rowptr, rowptr_host, (size_t)(n + 1) * 8, hipMemcpyHostToDevice,
+                       ctx->stream);
+  if (e == hipSuccess && nnz)
+    e = hipMemcpyAsync(ds->col, col_host, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz)
+    e = hipMemcpyAsync(ds->val, val_host, vb, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    rpt_dataset_free(ds);
+    return fail(RPT_E_HIP, std::string("CSR upload: ") + hipGetErrorString(e));
+  }
+  *out = ds;
+  return RPT_OK;
+}
+
+int32_t rpt_dataset_free(rpt_dataset* ds) {
+  if (!ds) return RPT_OK;
+  if (ds->owns) {
+    (void)hipSetDevice(ds->ctx->device);
+    if (ds->X) (void)hipFree(ds->X);
+    if (ds->rowptr) (void)hipFree(ds->rowptr);
+    if (ds->col) (void)hipFree(ds->col);
+    if (ds->val) (void)hipFree(ds->val);
+  }
+  delete ds;
+  return RPT_OK;
+}
+
+int32_t rpt_dataset_info(const rpt_dataset* ds, int64_t* n, int32_t* d, int32_t* dtype,
+                         int32_t* is_csr, int64_t* nnz) {
+  RPT_ARG(ds, "ds is NULL");
+  if (n) *n = ds->n;
+  if (d) *d = ds->d;
+  if (dtype) *dtype = ds->dtype;
+  if (is_csr) *is_csr = ds->csr ? 1 : 0;
+  if (nnz) *nnz = ds->csr ? ds->nnz : ds->n * ds->d;
+  return RPT_OK;
+}
+
+// ---- topology -------------------------------------------------------------------------
+int32_t rpt_topology(int64_t n, int32_t max_depth, int32_t min_leaf, int64_t* out,
+                     int64_t cap_records, int64_t* n_records) {
+  RPT_ARG(n >= 0 && max_depth >= 0 && max_depth <= 30, "bad topology arguments");
+  RPT_ARG(n_records, "n_records is NULL");
+  std::vector<Node> nodes;
+  enumerate_topology(n, max_depth, min_leaf, nodes);
+  *n_records = (int64_t)nodes.size();
+  if (out) {
+    for (int64_t i = 0; i < (int64_t)nodes.size() && i < cap_records; ++i) {
+      out[5 * i + 0] = nodes[i].level;
+      out[5 * i + 1] = nodes[i].heap;
+      out[5 * i + 2] = nodes[i].off;
+      out[5 * i + 3] = nodes[i].n;
+      out[5 * i + 4] = nodes[i].leaf ? 1 : 0;
+    }
+  }
+  return RPT_OK;
+}
+
+// ---- projection -----------------------------------------------------------------------
+static int32_t upload_R(rpt_ctx* ctx, const double* R_host, size_t count, DevBuf<double>& buf) {
+  RPT_TRY(buf.alloc(count));
+  if (count) {
+    RPT_HIP(hipMemcpyAsync(buf.p, R_host, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    RPT_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return RPT_OK;
+}
+
+int32_t rpt_project_dev(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,
+                        int32_t mode, void* P_dev) {
+  RPT_ARG(ctx && ds && R_host && P_dev, "NULL argument");
+  RPT_ARG(C >= 1, "C must be >= 1");
+  RPT_HIP(hipSetDevice(ctx->device));
+  DevBuf<double> Rd;
+  RPT_TRY(upload_R(ctx, R_host, (size_t)C * ds->d, Rd));
+  RPT_TRY(project_columns(ctx, ds, Rd.p, C, mode, P_dev));
+  RPT_HIP(hipStreamSynchronize(ctx->stream));  // Rd is released on return
+  return RPT_OK;
+}
+
+int32_t rpt_project_host(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,
+                         int32_t mode, void* P_host) {
+  RPT_ARG(ctx && ds && R_host && P_host, "NULL argument");
+  RPT_ARG(C >= 1, "C must be >= 1");
+  RPT_HIP(hipSetDevice(ctx->device));
+  size_t esz = dtype_size(proj_dtype(ds->dtype));
+  DevBuf<char> P;
+  RPT_TRY(P.alloc((size_t)C * ds->n * esz));
+  RPT_TRY(rpt_project_dev(ctx, ds, R_host, C, mode, P.p));
+  if (ds->n)
+    RPT_HIP(hipMemcpy(P_host, P.p, (size_t)C * ds->n * esz, hipMemcpyDeviceToHost));
+  return RPT_OK;
+}
+
+// ---- forest ---------------------------------------------------------------------------
+static int32_t forest_alloc(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                            int32_t L, int32_t min_leaf, rpt_forest** out) {
+  RPT_ARG(ctx && ds && R_host && out, "NULL argument");
+  RPT_ARG(T >= 1, "T must be >= 1");
+  RPT_ARG(L >= 0 && L <= 30, "maxDepth must be in [0,30]");
+  RPT_ARG(min_leaf >= 0, "minLeaf must be >= 0");
+  RPT_ARG(ds->ctx == ctx, "dataset belongs to another context");
+  RPT_ARG((int64_t)T * ds->n < ((int64_t)1 << 40), "forest too large");
+  RPT_HIP(hipSetDevice(ctx->device));
+  rpt_forest* f = new (std::nothrow) rpt_forest();
+  if (!f) return fail(RPT_E_NOMEM, "out of host memory");
+  f->ctx = ctx;
+  f->n = ds->n;
+  f->d = ds->d;
+  f->T = T;
+  f->L = L;
+  f->min_leaf = min_leaf;
+  f->pdtype = proj_dtype(ds->dtype);
+  f->nodes = ((int64_t)1 << L) - 1;
+  int32_t s = f->perm.alloc((size_t)T * f->n);
+  if (s == RPT_OK) s = f->thr.alloc((size_t)T * f->nodes);
+  if (s == RPT_OK) s = f->mglo.alloc((size_t)T * f->nodes);
+  if (s == RPT_OK) s = f->mghi.alloc((size_t)T * f->nodes);
+  if (s == RPT_OK) s = upload_R(ctx, R_host, (size_t)T * L * f->d, f->R);
+  if (s != RPT_OK) {
+    delete f;
+    return s;
+  }
+  *out = f;
+  return RPT_OK;
+}
+
+int32_t rpt_forest_build(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                         int32_t L, int32_t min_leaf, int32_t flags, rpt_forest** out) {
+  RPT_ARG(out, "out is NULL");
+  *out = nullptr;
+  rpt_forest* f = nullptr;
+  RPT_TRY(forest_alloc(ctx, ds, R_host, T, L, min_leaf, &f));
+  int32_t s = build_forest(ctx, ds, f, flags);
+  if (s != RPT_OK) {
+    delete f;
+    return s;
+  }
+  *out = f;
+  return RPT_OK;
+}
+
+int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                          int32_t L, int32_t min_leaf, const int32_t* perm_host,
+                          const double* thr_host, const double* mglo_host,
+                          const double* mghi_host, rpt_forest** out) {
+  RPT_ARG(out, "out is NULL");
+  *out = nullptr;
+  RPT_ARG(perm_host && thr_host && mglo_host && mghi_host, "NULL argument");
+  rpt_forest* f = nullptr;
+  RPT_TRY(forest_alloc(ctx, ds, R_host, T, L, min_leaf, &f));
+  for (int64_t i = 0; i < (int64_t)T * f->n; ++i)
+    if (perm_host[i] < 0 || perm_host[i] >= f->n) {
+      delete f;
+      return fail(RPT_E_ARG, "perm entry out of range");
+    }
+  hipError_t e = hipSuccess;
+  if (f->n) e = hipMemcpy(f->perm.p, perm_host, (size_t)T * f->n * 4, hipMemcpyHostToDevice);
+  size_t nb = (size_t)T * f->nodes * 8;
+  if (e == hipSuccess && nb) e = hipMemcpy(f->thr.p, thr_host, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess && nb) e = hipMemcpy(f->mglo.p, mglo_host, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess && nb) e = hipMemcpy(f->mghi.p, mghi_host, nb, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete f;
+    return fail(RPT_E_HIP, std::string("forest import: ") + hipGetErrorString(e));
+  }
+  *out = f;
+  return RPT_OK;
+}
+
+int32_t rpt_forest_free(rpt_forest* f) {
+  if (!f) return RPT_OK;
+  (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
+  delete f;
+  return RPT_OK;
+}
+
+int32_t rpt_forest_info(const rpt_forest* f, int64_t* n, int32_t* d, int32_t* T, int32_t* L,
+                        int32_t* min_leaf) {
+  RPT_ARG(f, "forest is NULL");
+  if (n) *n = f->n;
+  if (d) *d = f->d;
+  if (T) *T = f->T;
+  if (L) *L = f->L;
+  if (min_leaf) *min_leaf = f->min_leaf;
+  return RPT_OK;
+}
+
+int32_t rpt_forest_get_perm(rpt_forest* f, int32_t* perm_host) {
+  RPT_ARG(f && perm_host, "NULL argument");
+  RPT_HIP(hipSetDevice(f->ctx->device));
+  RPT_HIP(hipStreamSynchronize(f->ctx->stream));
+  if (f->n)
+    RPT_HIP(hipMemcpy(perm_host, f->perm.p, (size_t)f->T * f->n * 4, hipMemcpyDeviceToHost));
+  return RPT_OK;
+}
+
+int32_t rpt_forest_get_nodes(rpt_forest* f, double* thr_host, double* mglo_host,
+                             double* mghi_host) {
+  RPT_ARG(f && thr_host && mglo_host && mghi_host, "NULL argument");
+  RPT_HIP(hipSetDevice(f->ctx->device));
+  RPT_HIP(hipStreamSynchronize(f->ctx->stream));
+  size_t nb = (size_t)f->T * f->nodes * 8;
+  if (nb) {
+    RPT_HIP(hipMemcpy(thr_host, f->thr.p, nb, hipMemcpyDeviceToHost));
+    RPT_HIP(hipMemcpy(mglo_host, f->mglo.p, nb, hipMemcpyDeviceToHost));
+    RPT_HIP(hipMemcpy(mghi_host, f->mghi.p, nb, hipMemcpyDeviceToHost));
+  }
+  return RPT_OK;
+}
+
+int32_t rpt_forest_get_proj(rpt_forest* f, void* proj_host) {
+  RPT_ARG(f && proj_host, "NULL argument");
+  RPT_ARG(f->proj.p, "this forest holds no projections (imported forest)");
+  RPT_HIP(hipSetDevice(f->ctx->device));
+  RPT_HIP(hipStreamSynchronize(f->ctx->stream));
+  size_t nb = (size_t)f->T * f->L * f->n * dtype_size(f->pdtype);
+  if (nb) RPT_HIP(hipMemcpy(proj_host, f->proj.p, nb, hipMemcpyDeviceToHost));
+  return RPT_OK;
+}
+
+int32_t rpt_forest_stats(rpt_forest* f, int64_t* tie_nodes, int64_t* big_mid_nodes) {
+  RPT_ARG(f, "forest is NULL");
+  if (tie_nodes) *tie_nodes = f->tie_nodes;
+  if (big_mid_nodes) *big_mid_nodes = f->big_mid_nodes;
+  return RPT_OK;
+}
+
+int32_t rpt_split_segments(rpt_ctx* ctx, const double* key_host, int64_t n,
+                           int32_t* perm_io_host, const int64_t* seg_off_host,
+                           const int64_t* seg_len_host, int32_t S, double* thr_mg_host) {
+  RPT_ARG(ctx && key_host && perm_io_host && seg_off_host && seg_len_host && thr_mg_host,
+          "NULL argument");
+  RPT_ARG(n >= 1 && S >= 1, "n and S must be >= 1");
+  RPT_HIP(hipSetDevice(ctx->device));
+  return split_segments(ctx, key_host, n, perm_io_host, seg_off_host, seg_len_host, S,
+                        thr_mg_host);
+}
+
+// ---- queries --------------------------------------------------------------------------
+static int32_t check_query(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q) {
+  RPT_ARG(ctx && f && q, "NULL argument");
+  RPT_ARG(f->ctx == ctx && q->ctx == ctx, "handles belong to another context");
+  RPT_ARG(q->d == f->d, "query dimension differs from the forest's");
+  RPT_HIP(hipSetDevice(ctx->device));
+  return RPT_OK;
+}
+
+int32_t rpt_candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* queries,
+                       int64_t* off_host, int32_t* ids_host, int64_t cap, int64_t* total) {
+  RPT_TRY(check_query(ctx, f, queries));
+  RPT_ARG(total, "total is NULL");
+  return candidates(ctx, f, queries, off_host, ids_host, cap, total);
+}
+
+int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                    const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_dev,
+                    double* dist_dev, int32_t* count_dev) {
+  RPT_TRY(check_query(ctx, f, queries));
+  RPT_ARG(data && data->ctx == ctx, "bad data handle");
+  RPT_ARG(data->n == f->n && data->d == f->d, "data shape differs from the forest's");
+  RPT_ARG(data->csr == queries->csr, "data and queries must both be dense or both CSR");
+  RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
+  RPT_ARG(ids_dev && dist_dev && count_dev, "NULL output");
+  return knn_dev(ctx, f, data, queries, k, flags, ids_dev, dist_dev, count_dev);
+}
+
+int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                     const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_host,
+                     double* dist_host, int32_t* count_host) {
+  RPT_TRY(check_query(ctx, f, queries));
+  RPT_ARG(ids_host && dist_host && count_host, "NULL output");
+  RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
+  int64_t nq = queries->n;
+  DevBuf<int32_t> ids, cnt;
+  DevBuf<double> dist;
+  RPT_TRY(ids.alloc((size_t)nq * k));
+  RPT_TRY(dist.alloc((size_t)nq * k));
+  RPT_TRY(cnt.alloc((size_t)nq));
+  RPT_TRY(rpt_knn_dev(ctx, f, data, queries, k, flags, ids.p, dist.p, cnt.p));
+  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  if (nq) {
+    RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    RPT_HIP(hipMemcpy(dist_host, dist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    RPT_HIP(hipMemcpy(count_host, cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  }
+  return RPT_OK;
+}
+
+int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total) {
+  RPT_ARG(ctx && total, "NULL argument");
+  *total = ctx->last_candidates;
+  return RPT_OK;
+}
+
+int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
+                          const int32_t* count_dev, int32_t G, int64_t nq, int32_t k,
+                          int32_t flags, int32_t* out_ids_dev, double* out_dist_dev,
+                          int32_t* out_count_dev) {
+  RPT_ARG(ctx && ids_dev && dist_dev && count_dev && out_ids_dev && out_dist_dev &&
+              out_count_dev,
+          "NULL argument");
+  RPT_ARG(G >= 1 && nq >= 0 && k >= 1 && k <= 1024, "bad merge arguments");
+  RPT_ARG((int64_t)G * k <= 8192, "G*k must be <= 8192");
+  RPT_HIP(hipSetDevice(ctx->device));
+  return knn_merge_dev(ctx, ids_dev, dist_dev, count_dev, G, nq, k, flags, out_ids_dev,
+                       out_dist_dev, out_count_dev);
+}
+
+int32_t rpt_brute_knn_host(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* queries,
+                           int32_t k, int32_t* ids_host, double* dist_host) {
+  RPT_ARG(ctx && data && queries && ids_host && dist_host, "NULL argument");
+  RPT_ARG(data->ctx == ctx && queries->ctx == ctx, "handles belong to another context");
+  RPT_ARG(!data->csr && !queries->csr, "brute-force kNN supports dense data only");
+  RPT_ARG(data->d == queries->d && data->dtype == queries->dtype, "shape/dtype mismatch");
+  RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
+  RPT_HIP(hipSetDevice(ctx->device));
+  return brute_knn(ctx, data, queries, k, ids_host, dist_host);
+}
+
+}  // extern "C"

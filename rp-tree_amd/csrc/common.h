@@ -1,0 +1,149 @@
+// common.h — internal declarations shared by the HIP translation units of librptree_hip.so.
+// gfx950 (MI355X) only: wave64, no portability layers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rptree_hip.h"
+
+namespace rpt {
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const std::string& msg);
+int32_t fail(int32_t code, const std::string& msg);
+
+#define RPT_HIP(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return ::rpt::fail(RPT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));  \
+  } while (0)
+
+#define RPT_TRY(expr)             \
+  do {                            \
+    int32_t s__ = (expr);         \
+    if (s__ != RPT_OK) return s__; \
+  } while (0)
+
+#define RPT_ARG(cond, msg) \
+  do {                     \
+    if (!(cond)) return ::rpt::fail(RPT_E_ARG, msg); \
+  } while (0)
+
+// ---- topology (Internal.hs:289,495,503) ---------------------------------------------
+struct Node {
+  int32_t level;
+  int64_t heap;
+  int64_t off;
+  int64_t n;
+  bool leaf;
+};
+inline bool is_leaf(int32_t level, int64_t n, int32_t L, int32_t min_leaf) {
+  return level >= L || n <= (int64_t)min_leaf;
+}
+void enumerate_topology(int64_t N, int32_t L, int32_t min_leaf, std::vector<Node>& out);
+
+// device-side segment descriptor (one per node of a launch; identical for every tree)
+struct Seg {
+  int64_t off;    // offset of the segment inside a tree's perm row
+  int32_t n;      // segment length
+  int32_t heap;   // heap index of the node (-1: none)
+};
+
+inline size_t dtype_size(int32_t dt) { return dt == RPT_F64 ? 8 : dt == RPT_F32 ? 4 : 2; }
+// compute/projection type: double for f64 data, float otherwise
+inline int32_t proj_dtype(int32_t dt) { return dt == RPT_F64 ? RPT_F64 : RPT_F32; }
+
+// simple owned device buffer
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t count = 0;
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  int32_t alloc(size_t n) {
+    release();
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e != hipSuccess)
+      return fail(RPT_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    count = n;
+    return RPT_OK;
+  }
+  int32_t ensure(size_t n) { return (n <= count && p) ? RPT_OK : alloc(n); }
+};
+
+}  // namespace rpt
+
+struct rpt_ctx {
+  int32_t device = 0;
+  hipStream_t stream = nullptr;
+  int64_t last_candidates = 0;
+  int32_t n_cu = 256;
+};
+
+struct rpt_dataset {
+  rpt_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int32_t d = 0;
+  int32_t dtype = RPT_F64;
+  bool csr = false;
+  bool owns = false;
+  void* X = nullptr;  // dense: [n][d]
+  int64_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  void* val = nullptr;
+  int64_t nnz = 0;
+};
+
+struct rpt_forest {
+  rpt_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int32_t d = 0, T = 0, L = 0, min_leaf = 0;
+  int32_t pdtype = RPT_F64;  // type of proj
+  int32_t mode = RPT_PROJ_AUTO;  // projection mode used by the build (queries reuse it)
+  int64_t nodes = 0;         // 2^L - 1
+  rpt::DevBuf<int32_t> perm;  // [T][N] final leaf-ordered permutation
+  rpt::DevBuf<double> thr, mglo, mghi;  // [T][nodes]
+  rpt::DevBuf<char> proj;               // [T][L][N] in pdtype
+  rpt::DevBuf<double> R;                // [T][L][d] hyperplanes (device copy)
+  int64_t tie_nodes = 0, big_mid_nodes = 0;
+};
+
+namespace rpt {
+
+// ---- projection (project.hip) -----------------------------------------------------------
+// P_dev[C][n] (compute type) = R_dev[C][d] applied to every row of ds.  R_dev is a device
+// copy of the dense-ified hyperplanes (double).
+int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
+                        int32_t mode, void* P_dev);
+
+// ---- split / build (split.hip) ----------------------------------------------------------
+int32_t build_forest(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode);
+int32_t split_segments(rpt_ctx* ctx, const double* key_host, int64_t n, int32_t* perm_io_host,
+                       const int64_t* seg_off, const int64_t* seg_len, int32_t S,
+                       double* thr_mg_host);
+
+// ---- queries (knn.hip) ------------------------------------------------------------------
+int32_t candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, int64_t* off_host,
+                   int32_t* ids_host, int64_t cap, int64_t* total);
+int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
+                int32_t k, int32_t flags, int32_t* ids_dev, double* dist_dev, int32_t* count_dev);
+int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
+                      const int32_t* count_dev, int32_t G, int64_t nq, int32_t k, int32_t flags,
+                      int32_t* out_ids, double* out_dist, int32_t* out_count);
+int32_t brute_knn(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* q, int32_t k,
+                  int32_t* ids_host, double* dist_host);
+
+}  // namespace rpt

@@ -1,0 +1,624 @@
+// knn.hip — query side of the hot path.
+//
+//   candidates (RPTree.hs:289-314): per tree a DFS from the root with the query's projection
+//       on the level's hyperplane; the 4-way rule may descend both children; the leaf buckets
+//       reached are concatenated left to right.
+//   knn (RPTree.hs:168-176): concatenate the candidates of all trees in ascending tree key
+//       (duplicates kept), distance of every candidate to the query (metricL2), stable sort
+//       by distance, take k.  Equivalent total order: (distance, candidate position).
+//
+// Kernels (wave64, one workgroup per query):
+//   count_kernel  : thread = tree; counts the leaf ranges / candidates each tree contributes
+//   ranges_kernel : same traversal, writes (perm offset, length, candidate position) ranges
+//   topk_kernel   : each wave streams candidate rows (whole-row coalesced gathers from HBM —
+//                   this is the bandwidth-bound part, d*sizeof(x) bytes per candidate),
+//                   wave-reduces the squared distance, and the block keeps the best k in LDS
+//                   by bitonic-merging batches of candidates
+//   expand_kernel : materialises candidate ids for rpt_candidates
+#include <hip/hip_bf16.h>
+
+#include <limits>
+
+#include "common.h"
+
+namespace rpt {
+namespace {
+
+constexpr int kBuf = 2048;  // LDS entries of the top-k merge buffer (best k + batch)
+
+struct Range {
+  int64_t poff;  // absolute offset into perm ([T][N] flattened)
+  int32_t n;
+  int32_t pos;   // position of the range's first candidate in the query's candidate list
+};
+
+// ---- traversal ---------------------------------------------------------------------------
+// emit(off, n) is called for every leaf reached, left to right.
+template <class TK, class Emit>
+__device__ inline void traverse(const double* __restrict__ thr, const double* __restrict__ mglo,
+                                const double* __restrict__ mghi, const TK* __restrict__ pq,
+                                int64_t pq_stride, int L, int min_leaf, int64_t N, Emit emit) {
+  int s_level[32];
+  unsigned int s_heap[32];
+  int s_off[32], s_n[32];
+  int sp = 0;
+  s_level[0] = 0;
+  s_heap[0] = 0;
+  s_off[0] = 0;
+  s_n[0] = (int)N;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    int level = s_level[sp];
+    unsigned int heap = s_heap[sp];
+    int off = s_off[sp], n = s_n[sp];
+    for (;;) {
+      if (level >= L || n <= min_leaf) {  // Tip (RPTree.hs:299)
+        emit(off, n);
+        break;
+      }
+      const double proj = (double)pq[(int64_t)level * pq_stride];  // RPTree.hs:303-304
+      const double th = thr[heap];
+      const double dl = fabs(mglo[heap] - proj);  // :306
+      const double dr = fabs(mghi[heap] - proj);  // :307
+      const int nh = n / 2;
+      const bool both = (proj < th && dl > dr) || (proj > th && dl < dr);  // :309-313
+      const bool left = proj < th;
+      if (both) {  // push right, continue left
+        s_level[sp] = level + 1;
+        s_heap[sp] = 2 * heap + 2;
+        s_off[sp] = off + nh;
+        s_n[sp] = n - nh;
+        ++sp;
+        heap = 2 * heap + 1;
+        n = nh;
+      } else if (left) {  // :311
+        heap = 2 * heap + 1;
+        n = nh;
+      } else {  // :314 (includes proj == thr)
+        heap = 2 * heap + 2;
+        off += nh;
+        n = n - nh;
+      }
+      ++level;
+    }
+  }
+}
+
+// per (query, tree) counts.  grid = nq blocks, blockDim >= T (multiple of 64).
+template <class TK>
+__global__ void count_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
+                             const double* __restrict__ mghi, int64_t nodes, const TK* Pq,
+                             int64_t nq, int T, int L, int min_leaf, int64_t N,
+                             int* __restrict__ cnt_cand /*[nq][T]*/,
+                             int* __restrict__ cnt_rng /*[nq][T]*/) {
+  const int64_t q = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int nc = 0, nr = 0;
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                 nq, L, min_leaf, N, [&](int, int n) {
+                   nc += n;
+                   ++nr;
+                 });
+    cnt_cand[q * T + t] = nc;
+    cnt_rng[q * T + t] = nr;
+  }
+}
+
+// exclusive scan of int32 counts into int64 offsets (single block; n is small: nq*T).
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ in, int64_t n,
+                                                    int64_t* __restrict__ out /*[n+1]*/) {
+  __shared__ long long part[1024];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const long long v = i < n ? in[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      long long add = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n) out[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
+template <class TK>
+__global__ void ranges_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
+                              const double* __restrict__ mghi, int64_t nodes, const TK* Pq,
+                              int64_t nq, int T, int L, int min_leaf, int64_t N,
+                              const int64_t* __restrict__ cand_off /*[nq*T+1]*/,
+                              const int64_t* __restrict__ rng_off /*[nq*T+1]*/,
+                              Range* __restrict__ ranges) {
+  const int64_t q = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int64_t r = rng_off[q * T + t];
+    int64_t pos = cand_off[q * T + t] - cand_off[q * T];
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                 nq, L, min_leaf, N, [&](int off, int n) {
+                   ranges[r++] = Range{(int64_t)t * N + off, n, (int)pos};
+                   pos += n;
+                 });
+  }
+}
+
+// candidate ids for rpt_candidates: one block per (query, tree) range list
+__global__ void expand_kernel(const int32_t* __restrict__ perm, const Range* __restrict__ ranges,
+                              const int64_t* __restrict__ rng_off, const int64_t* __restrict__ cand_off,
+                              int T, int32_t* __restrict__ ids) {
+  const int64_t q = blockIdx.x;
+  const int64_t qbase = cand_off[q * T];
+  for (int64_t r = rng_off[q * T]; r < rng_off[(q + 1) * T]; ++r) {
+    const Range rg = ranges[r];
+    for (int i = threadIdx.x; i < rg.n; i += blockDim.x)
+      ids[qbase + rg.pos + i] = perm[rg.poff + i];
+  }
+}
+
+// ---- distance + top-k --------------------------------------------------------------------
+struct Entry {
+  double dist;
+  int pos;
+  int id;
+};
+__device__ inline bool entry_less(const Entry& a, const Entry& b) {
+  return a.dist < b.dist || (a.dist == b.dist && a.pos < b.pos);
+}
+
+__device__ inline void bitonic_entries(Entry* e, int np) {
+  for (int k = 2; k <= np; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (np >> 1); i += blockDim.x) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const Entry a = e[lo], b = e[hi];
+        if (up ? entry_less(b, a) : entry_less(a, b)) {
+          e[lo] = b;
+          e[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// Merge step: sort buf[0, np) and keep the best k (optionally unique ids) at the front.
+// Returns the number of valid best entries.  All threads call; `scratch` is int[kBuf].
+__device__ int merge_best(Entry* buf, int filled, int k, bool dedup, int* scratch) {
+  int np = 1;
+  while (np < filled) np <<= 1;
+  for (int i = filled + threadIdx.x; i < np; i += blockDim.x)
+    buf[i] = Entry{__longlong_as_double(0x7ff0000000000000LL), 0x7fffffff, -1};
+  __syncthreads();
+  bitonic_entries(buf, np);
+  if (!dedup) return filled < k ? filled : k;
+  // same id => same distance (deterministic distance function): a duplicate sits in the run
+  // of equal distances before it
+  for (int i = threadIdx.x; i < filled; i += blockDim.x) {
+    int dup = 0;
+    for (int j = i - 1; j >= 0 && buf[j].dist == buf[i].dist; --j)
+      if (buf[j].id == buf[i].id) {
+        dup = 1;
+        break;
+      }
+    scratch[i] = dup;
+  }
+  __syncthreads();
+  // thread 0 compacts the first k unique entries (k is small; filled <= kBuf)
+  __shared__ int s_kept;
+  if (threadIdx.x == 0) {
+    int w = 0;
+    for (int i = 0; i < filled && w < k; ++i)
+      if (!scratch[i]) {
+        if (w != i) buf[w] = buf[i];
+        ++w;
+      }
+    s_kept = w;
+  }
+  __syncthreads();
+  return s_kept;
+}
+
+template <class TD>
+struct AccOf { typedef float type; };
+template <>
+struct AccOf<double> { typedef double type; };
+
+template <class TD>
+__device__ inline typename AccOf<TD>::type ld(const TD* p) { return (typename AccOf<TD>::type)*p; }
+template <>
+__device__ inline float ld<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+
+template <class TA>
+__device__ inline TA wave_sum(TA v) {
+  // fixed butterfly: the result does not depend on which wave computes it
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// dense data.  One block (256 threads) per query.  Candidate list given as ranges.
+// `identity`: the candidate list is the whole dataset in id order (brute force), perm unused.
+template <class TD>
+__global__ __launch_bounds__(256) void topk_dense_kernel(
+    const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
+    const Range* __restrict__ ranges, const int64_t* __restrict__ rng_off, int T, int64_t N,
+    int identity, int k, int dedup, int32_t* __restrict__ out_ids, double* __restrict__ out_dist,
+    int32_t* __restrict__ out_cnt) {
+  typedef typename AccOf<TD>::type TA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Entry* buf = reinterpret_cast<Entry*>(smem);                       // [kBuf]
+  int* scratch = reinterpret_cast<int*>(smem + sizeof(Entry) * kBuf);  // [kBuf]
+  TA* qs = reinterpret_cast<TA*>(smem + (sizeof(Entry) + 4) * kBuf);   // [d]
+  const int64_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) qs[j] = ld<TD>(Q + q * d + j);
+  __syncthreads();
+
+  int best = 0;    // valid best entries at buf[0, best)
+  int filled = 0;  // entries in buf (block-uniform)
+  const int cap = kBuf;
+  const int64_t r0 = identity ? 0 : rng_off[q * T];
+  const int64_t r1 = identity ? 1 : rng_off[(q + 1) * T];
+  for (int64_t r = r0; r < r1; ++r) {
+    Range rg;
+    if (identity) rg = Range{0, (int32_t)N, 0};
+    else rg = ranges[r];
+    int done = 0;
+    while (done < rg.n) {
+      int take = rg.n - done;
+      if (take > cap - filled) take = cap - filled;
+      // each wave handles candidates wave, wave+4, ... of this slice, four rows in flight
+      for (int i0 = wave; i0 < take; i0 += 16) {
+        int idv[4];
+        TA s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 4 * u;
+          const int c = done + (i < take ? i : i0);
+          idv[u] = identity ? c : perm[rg.poff + c];
+          s[u] = (TA)0;
+        }
+        for (int j = lane; j < d; j += 64) {
+          const TA qj = qs[j];
+          TA x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = ld<TD>(X + (int64_t)idv[u] * d + j);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const TA df = x[u] - qj;
+            s[u] += df * df;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 4 * u;
+          const TA tot = wave_sum(s[u]);
+          if (lane == 0 && i < take)
+            buf[filled + i] = Entry{(double)sqrt((double)tot), rg.pos + done + i, idv[u]};
+        }
+      }
+      filled += take;
+      done += take;
+      __syncthreads();
+      if (filled == cap) {
+        best = merge_best(buf, filled, k, dedup != 0, scratch);
+        filled = best;
+        __syncthreads();
+      }
+    }
+  }
+  if (filled > best || best == 0) {
+    best = merge_best(buf, filled, k, dedup != 0, scratch);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    const bool ok = i < best;
+    out_ids[q * k + i] = ok ? buf[i].id : -1;
+    out_dist[q * k + i] = ok ? buf[i].dist : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  if (threadIdx.x == 0) out_cnt[q] = best;
+}
+
+// CSR data and CSR queries: the query is densified into LDS; distance of a sparse row x:
+// d^2 = |q|^2 + sum_{j in nz(x)} ((x_j - q_j)^2 - q_j^2)   (true Euclidean distance)
+template <class TD>
+__global__ __launch_bounds__(256) void topk_csr_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const TD* __restrict__ val, int d, const int64_t* __restrict__ qrowptr,
+    const int32_t* __restrict__ qcol, const TD* __restrict__ qval,
+    const int32_t* __restrict__ perm, const Range* __restrict__ ranges,
+    const int64_t* __restrict__ rng_off, int T, int k, int dedup, int32_t* __restrict__ out_ids,
+    double* __restrict__ out_dist, int32_t* __restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Entry* buf = reinterpret_cast<Entry*>(smem);
+  int* scratch = reinterpret_cast<int*>(smem + sizeof(Entry) * kBuf);
+  double* qs = reinterpret_cast<double*>(smem + (sizeof(Entry) + 4) * kBuf);  // [d]
+  __shared__ double s_qn2;
+  const int64_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) qs[j] = 0.0;
+  __syncthreads();
+  for (int64_t j = qrowptr[q] + threadIdx.x; j < qrowptr[q + 1]; j += blockDim.x)
+    qs[qcol[j]] = (double)qval[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double s = 0;
+    for (int j = lane; j < d; j += 64) s += qs[j] * qs[j];
+    s = wave_sum(s);
+    if (lane == 0) s_qn2 = s;
+  }
+  __syncthreads();
+  const double qn2 = s_qn2;
+  int best = 0, filled = 0;
+  const int cap = kBuf;
+  for (int64_t r = rng_off[q * T]; r < rng_off[(q + 1) * T]; ++r) {
+    const Range rg = ranges[r];
+    int done = 0;
+    while (done < rg.n) {
+      int take = rg.n - done;
+      if (take > cap - filled) take = cap - filled;
+      for (int i = wave; i < take; i += 4) {
+        const int c = done + i;
+        const int id = perm[rg.poff + c];
+        double s = 0;
+        for (int64_t j = rowptr[id] + lane; j < rowptr[id + 1]; j += 64) {
+          const double qj = qs[col[j]];
+          const double df = (double)val[j] - qj;
+          s += df * df - qj * qj;
+        }
+        s = wave_sum(s) + qn2;
+        if (lane == 0) buf[filled + i] = Entry{sqrt(s > 0 ? s : 0.0), rg.pos + c, id};
+      }
+      filled += take;
+      done += take;
+      __syncthreads();
+      if (filled == cap) {
+        best = merge_best(buf, filled, k, dedup != 0, scratch);
+        filled = best;
+        __syncthreads();
+      }
+    }
+  }
+  if (filled > best || best == 0) {
+    best = merge_best(buf, filled, k, dedup != 0, scratch);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    const bool ok = i < best;
+    out_ids[q * k + i] = ok ? buf[i].id : -1;
+    out_dist[q * k + i] = ok ? buf[i].dist : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  if (threadIdx.x == 0) out_cnt[q] = best;
+}
+
+// multi-GPU merge: G shard results per query, shard-major [G][nq][k]
+__global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ ids,
+                                                    const double* __restrict__ dist,
+                                                    const int32_t* __restrict__ cnt, int G,
+                                                    int64_t nq, int k, int dedup,
+                                                    int32_t* __restrict__ out_ids,
+                                                    double* __restrict__ out_dist,
+                                                    int32_t* __restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int total = G * k;
+  int np = 1;
+  while (np < total) np <<= 1;
+  Entry* buf = reinterpret_cast<Entry*>(smem);
+  int* scratch = reinterpret_cast<int*>(smem + sizeof(Entry) * np);
+  const int64_t q = blockIdx.x;
+  // invalid slots sort last: dist = +inf, pos keeps shard order
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int g = i / k, r = i % k;
+    const bool ok = r < cnt[(int64_t)g * nq + q];
+    const int64_t src = ((int64_t)g * nq + q) * k + r;
+    buf[i] = Entry{ok ? dist[src] : __longlong_as_double(0x7ff0000000000000LL), i,
+                   ok ? ids[src] : -1};
+  }
+  __syncthreads();
+  int valid = 0;
+  for (int g = 0; g < G; ++g) valid += cnt[(int64_t)g * nq + q];
+  int best = merge_best(buf, total, k, dedup != 0, scratch);
+  // merge_best counted +inf padding as entries: clamp to the valid ones (dedup can only
+  // shrink further; invalid entries have id -1 and sort last)
+  __syncthreads();
+  int m = 0;
+  for (int i = 0; i < best; ++i) m += buf[i].id >= 0;  // every thread computes the same
+  best = m < valid ? m : valid;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    const bool ok = i < best;
+    out_ids[q * k + i] = ok ? buf[i].id : -1;
+    out_dist[q * k + i] = ok ? buf[i].dist : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  if (threadIdx.x == 0) out_cnt[q] = best;
+}
+
+// ---- host side ----------------------------------------------------------------------------
+struct QueryPlan {
+  DevBuf<char> Pq;  // [T][L][nq] projections of the queries
+  DevBuf<int> cnt_cand, cnt_rng;
+  DevBuf<int64_t> cand_off, rng_off;
+  DevBuf<Range> ranges;
+  int64_t total_cand = 0, total_rng = 0;
+};
+
+template <class TK>
+int32_t make_plan_t(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, QueryPlan& pl) {
+  const int64_t nq = q->n;
+  const int T = f->T, L = f->L;
+  hipStream_t st = ctx->stream;
+  RPT_TRY(pl.Pq.alloc((size_t)T * L * nq * sizeof(TK) + 16));
+  if (L > 0 && nq > 0) RPT_TRY(project_columns(ctx, q, f->R.p, T * L, f->mode, pl.Pq.p));
+  const int64_t m = nq * T;
+  RPT_TRY(pl.cnt_cand.alloc((size_t)m));
+  RPT_TRY(pl.cnt_rng.alloc((size_t)m));
+  RPT_TRY(pl.cand_off.alloc((size_t)m + 1));
+  RPT_TRY(pl.rng_off.alloc((size_t)m + 1));
+  if (nq == 0) return RPT_OK;
+  const int threads = T <= 64 ? 64 : (T <= 128 ? 128 : 256);
+  const TK* Pq = reinterpret_cast<const TK*>(pl.Pq.p);
+  hipLaunchKernelGGL(count_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                     f->mglo.p, f->mghi.p, f->nodes, Pq, nq, T, L, f->min_leaf, f->n,
+                     pl.cnt_cand.p, pl.cnt_rng.p);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, pl.cnt_cand.p, m, pl.cand_off.p);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, pl.cnt_rng.p, m, pl.rng_off.p);
+  RPT_HIP(hipGetLastError());
+  int64_t tot[2];
+  RPT_HIP(hipMemcpyAsync(&tot[0], pl.cand_off.p + m, 8, hipMemcpyDeviceToHost, st));
+  RPT_HIP(hipMemcpyAsync(&tot[1], pl.rng_off.p + m, 8, hipMemcpyDeviceToHost, st));
+  RPT_HIP(hipStreamSynchronize(st));
+  pl.total_cand = tot[0];
+  pl.total_rng = tot[1];
+  RPT_TRY(pl.ranges.alloc((size_t)pl.total_rng));
+  hipLaunchKernelGGL(ranges_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                     f->mglo.p, f->mghi.p, f->nodes, Pq, nq, T, L, f->min_leaf, f->n,
+                     pl.cand_off.p, pl.rng_off.p, pl.ranges.p);
+  RPT_HIP(hipGetLastError());
+  return RPT_OK;
+}
+
+int32_t make_plan(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, QueryPlan& pl) {
+  RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
+          "query dtype must have the forest's projection type (f64 vs f32/bf16)");
+  if (f->pdtype == RPT_F64) return make_plan_t<double>(ctx, f, q, pl);
+  return make_plan_t<float>(ctx, f, q, pl);
+}
+
+size_t topk_smem(int d, size_t acc_size) { return (sizeof(Entry) + 4) * kBuf + (size_t)d * acc_size; }
+
+}  // namespace
+
+int32_t candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, int64_t* off_host,
+                   int32_t* ids_host, int64_t cap, int64_t* total) {
+  QueryPlan pl;
+  RPT_TRY(make_plan(ctx, f, q, pl));
+  *total = pl.total_cand;
+  const int64_t m = q->n * f->T;
+  if (off_host) {
+    if (m > 0) RPT_HIP(hipMemcpy(off_host, pl.cand_off.p, (size_t)(m + 1) * 8, hipMemcpyDeviceToHost));
+    else off_host[0] = 0;
+  }
+  if (ids_host && pl.total_cand > 0) {
+    RPT_ARG(cap >= pl.total_cand, "ids capacity too small");
+    DevBuf<int32_t> ids;
+    RPT_TRY(ids.alloc((size_t)pl.total_cand));
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)q->n), dim3(128), 0, ctx->stream,
+                       f->perm.p, pl.ranges.p, pl.rng_off.p, pl.cand_off.p, f->T, ids.p);
+    RPT_HIP(hipGetLastError());
+    RPT_HIP(hipStreamSynchronize(ctx->stream));
+    RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)pl.total_cand * 4, hipMemcpyDeviceToHost));
+  }
+  return RPT_OK;
+}
+
+template <class TD>
+static int32_t launch_topk_dense(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* q,
+                                 const int32_t* perm, const Range* ranges, const int64_t* rng_off,
+                                 int T, int identity, int k, int dedup, int32_t* ids,
+                                 double* dist, int32_t* cnt) {
+  typedef typename AccOf<TD>::type TA;
+  const size_t smem = topk_smem(data->d, sizeof(TA));
+  if (smem > 64 * 1024)
+    RPT_HIP(hipFuncSetAttribute((const void*)topk_dense_kernel<TD>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(topk_dense_kernel<TD>, dim3((unsigned)q->n), dim3(256), smem, ctx->stream,
+                     (const TD*)data->X, data->d, (const TD*)q->X, perm, ranges, rng_off, T,
+                     data->n, identity, k, dedup, ids, dist, cnt);
+  RPT_HIP(hipGetLastError());
+  return RPT_OK;
+}
+
+int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
+                int32_t k, int32_t flags, int32_t* ids_dev, double* dist_dev, int32_t* count_dev) {
+  RPT_ARG(data->dtype == q->dtype, "data and query dtype must match");
+  RPT_ARG(k <= kBuf / 2, "k too large for the LDS merge buffer");
+  RPT_ARG((size_t)data->d * 8 + (sizeof(Entry) + 4) * kBuf <= 150 * 1024, "d too large");
+  QueryPlan pl;
+  RPT_TRY(make_plan(ctx, f, q, pl));
+  ctx->last_candidates = pl.total_cand;
+  if (q->n == 0) return RPT_OK;
+  const int dedup = (flags & RPT_KNN_DEDUP) ? 1 : 0;
+  if (data->csr) {
+    const size_t smem = topk_smem(data->d, 8);
+    if (data->dtype == RPT_F64) {
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)topk_csr_kernel<double>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(topk_csr_kernel<double>, dim3((unsigned)q->n), dim3(256), smem,
+                         ctx->stream, data->rowptr, data->col, (const double*)data->val, data->d,
+                         q->rowptr, q->col, (const double*)q->val, f->perm.p, pl.ranges.p,
+                         pl.rng_off.p, f->T, k, dedup, ids_dev, dist_dev, count_dev);
+    } else {
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)topk_csr_kernel<float>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(topk_csr_kernel<float>, dim3((unsigned)q->n), dim3(256), smem,
+                         ctx->stream, data->rowptr, data->col, (const float*)data->val, data->d,
+                         q->rowptr, q->col, (const float*)q->val, f->perm.p, pl.ranges.p,
+                         pl.rng_off.p, f->T, k, dedup, ids_dev, dist_dev, count_dev);
+    }
+    RPT_HIP(hipGetLastError());
+  } else if (data->dtype == RPT_F64) {
+    RPT_TRY(launch_topk_dense<double>(ctx, data, q, f->perm.p, pl.ranges.p, pl.rng_off.p, f->T, 0,
+                                      k, dedup, ids_dev, dist_dev, count_dev));
+  } else if (data->dtype == RPT_F32) {
+    RPT_TRY(launch_topk_dense<float>(ctx, data, q, f->perm.p, pl.ranges.p, pl.rng_off.p, f->T, 0,
+                                     k, dedup, ids_dev, dist_dev, count_dev));
+  } else {
+    RPT_TRY(launch_topk_dense<__hip_bfloat16>(ctx, data, q, f->perm.p, pl.ranges.p, pl.rng_off.p,
+                                              f->T, 0, k, dedup, ids_dev, dist_dev, count_dev));
+  }
+  RPT_HIP(hipStreamSynchronize(ctx->stream));  // the plan's buffers are released on return
+  return RPT_OK;
+}
+
+int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
+                      const int32_t* count_dev, int32_t G, int64_t nq, int32_t k, int32_t flags,
+                      int32_t* out_ids, double* out_dist, int32_t* out_count) {
+  if (nq == 0) return RPT_OK;
+  int np = 1;
+  while (np < G * k) np <<= 1;
+  const size_t smem = (sizeof(Entry) + 4) * (size_t)np;
+  if (smem > 64 * 1024)
+    RPT_HIP(hipFuncSetAttribute((const void*)merge_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, ctx->stream, ids_dev,
+                     dist_dev, count_dev, G, nq, k, (flags & RPT_KNN_DEDUP) ? 1 : 0, out_ids,
+                     out_dist, out_count);
+  RPT_HIP(hipGetLastError());
+  return RPT_OK;
+}
+
+int32_t brute_knn(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* q, int32_t k,
+                  int32_t* ids_host, double* dist_host) {
+  RPT_ARG(k <= kBuf / 2, "k too large");
+  const int64_t nq = q->n;
+  if (nq == 0) return RPT_OK;
+  DevBuf<int32_t> ids, cnt;
+  DevBuf<double> dist;
+  RPT_TRY(ids.alloc((size_t)nq * k));
+  RPT_TRY(dist.alloc((size_t)nq * k));
+  RPT_TRY(cnt.alloc((size_t)nq));
+  if (data->dtype == RPT_F64)
+    RPT_TRY(launch_topk_dense<double>(ctx, data, q, nullptr, nullptr, nullptr, 1, 1, k, 0, ids.p,
+                                      dist.p, cnt.p));
+  else if (data->dtype == RPT_F32)
+    RPT_TRY(launch_topk_dense<float>(ctx, data, q, nullptr, nullptr, nullptr, 1, 1, k, 0, ids.p,
+                                     dist.p, cnt.p));
+  else
+    RPT_TRY(launch_topk_dense<__hip_bfloat16>(ctx, data, q, nullptr, nullptr, nullptr, 1, 1, k, 0,
+                                              ids.p, dist.p, cnt.p));
+  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  RPT_HIP(hipMemcpy(dist_host, dist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+  return RPT_OK;
+}
+
+}  // namespace rpt

@@ -1,0 +1,541 @@
+"""rptree_amd — host-side mirror of the Data.RPTree API surface over the MI355X C ABI.
+
+The reference host language is Haskell (no GHC in this image), so this Python layer plays the
+role the Haskell `Data.RPTree` wrapper would play: same function names, argument order and
+meaning as the reference, calling the C ABI of include/rptree_hip.h.  Reference citations are
+file:line in ocramz/rp-tree v0.7.1.
+
+    forestBatch / treeBatch   Batch.hs:29-63
+    knn                       RPTree.hs:168-176
+    candidates                RPTree.hs:289-314
+    recallWith                RPTree.hs:259-282
+    rpTreeCfg / RPTreeConfig  Conduit.hs:123-141
+    SVector / DVector / Embed Internal.hs:56-59,92-133
+    leaves / levels / points / treeSize / leafSizes   Internal.hs:199-208, RPTree.hs:362-367
+"""
+import ctypes as C
+import math
+from collections import namedtuple
+
+import numpy as np
+
+from . import gen
+from ._lib import (RPT_BF16, RPT_F32, RPT_F64, RPT_KNN_DEDUP, RPT_KNN_KEEP_DUPLICATES,
+                   RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA, RPTError, check, lib)
+
+__all__ = [
+    "Context", "Dataset", "RPForest", "RPTree", "SVector", "DVector", "Embed", "fromListSv",
+    "fromVectorSv", "fromListDv", "fromVectorDv", "forestBatch", "treeBatch", "knn", "knnBatch",
+    "candidates", "recallWith", "rpTreeCfg", "RPTreeConfig", "leaves", "levels", "points",
+    "treeSize", "leafSizes", "metricL2", "inner", "project", "splitSegments", "topology",
+    "bruteKnn", "RPTError",
+]
+
+_DT = {np.dtype(np.float64): RPT_F64, np.dtype(np.float32): RPT_F32}
+
+
+def _vp(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+# ---------------------------------------------------------------------------------------
+# vector types (Internal.hs:92-133)
+# ---------------------------------------------------------------------------------------
+class SVector(namedtuple("SVector", "svDim svIdx svVal")):
+    """Sparse vector: dimension + (index, value) components, indices ascending (unchecked in
+    the reference, Internal.hs:99-105)."""
+    __slots__ = ()
+
+
+class DVector(namedtuple("DVector", "dvVec")):
+    __slots__ = ()
+
+
+Embed = namedtuple("Embed", "eEmbed eData")           # Internal.hs:56-59
+
+
+def fromListSv(n, ll):                                # Internal.hs:106-107
+    idx = np.array([i for i, _ in ll], dtype=np.int32)
+    val = np.array([x for _, x in ll], dtype=np.float64)
+    return SVector(int(n), idx, val)
+
+
+def fromVectorSv(n, idx, val):                        # Internal.hs:116-119
+    return SVector(int(n), np.asarray(idx, dtype=np.int32), np.asarray(val, dtype=np.float64))
+
+
+def fromListDv(ll):                                   # Internal.hs:128-129
+    return DVector(np.array(ll, dtype=np.float64))
+
+
+fromVectorDv = fromListDv                             # Internal.hs:130-131
+
+
+# ---------------------------------------------------------------------------------------
+# parameters (Conduit.hs:123-141)
+# ---------------------------------------------------------------------------------------
+RPTreeConfig = namedtuple("RPTreeConfig", "fpMaxTreeDepth fpDataChunkSize fpProjNzDensity")
+
+
+def rpTreeCfg(minl, n, d):
+    """Conduit.hs:132-141: maxd = ceiling(logBase 2 (n/minl)); chunk = ceiling(n/100);
+    pnz = min 1 (1/logBase 10 d)."""
+    maxd = math.ceil(math.log(n / minl) / math.log(2.0))
+    nchunk = math.ceil(n / 100)
+    with np.errstate(divide="ignore"):
+        pnz_min = 1.0 / (math.log(d) / math.log(10.0)) if d != 1 else math.inf
+    return RPTreeConfig(int(maxd), int(nchunk), min(pnz_min, 1.0))
+
+
+# ---------------------------------------------------------------------------------------
+# handles
+# ---------------------------------------------------------------------------------------
+class Context:
+    """One MI355X device + stream (rpt_ctx).  Raises if there is no usable HIP device."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        check(lib().rpt_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def sync(self):
+        check(lib().rpt_ctx_sync(self._h))
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        check(lib().rpt_ctx_stream(self._h, C.byref(s)))
+        return s.value
+
+    def close(self):
+        if self._h is not None:
+            lib().rpt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Dataset:
+    """Point set / query batch resident in HBM (rpt_dataset)."""
+
+    def __init__(self, ctx, handle, n, d, dtype, is_csr, keep=None):
+        self.ctx, self._h, self.n, self.d, self.dtype, self.is_csr = ctx, handle, n, d, dtype, is_csr
+        self._keep = keep
+
+    @staticmethod
+    def dense(ctx, X):
+        X = np.ascontiguousarray(X)
+        if X.ndim != 2:
+            raise ValueError("dense data must be a 2-D array [n][d]")
+        if X.dtype not in _DT:
+            X = X.astype(np.float64)
+        h = C.c_void_p()
+        check(lib().rpt_dataset_dense_host(ctx._h, _vp(X), X.shape[0], X.shape[1], _DT[X.dtype],
+                                           C.byref(h)))
+        return Dataset(ctx, h, X.shape[0], X.shape[1], _DT[X.dtype], False)
+
+    @staticmethod
+    def dense_device(ctx, ptr, n, d, dtype, keep=None):
+        """Borrow device memory (e.g. a torch tensor's data_ptr()); `keep` pins the owner."""
+        h = C.c_void_p()
+        check(lib().rpt_dataset_dense_dev(ctx._h, C.c_void_p(ptr), n, d, dtype, C.byref(h)))
+        return Dataset(ctx, h, n, d, dtype, False, keep)
+
+    @staticmethod
+    def csr(ctx, rowptr, col, val, d):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val)
+        if val.dtype not in _DT:
+            val = val.astype(np.float64)
+        h = C.c_void_p()
+        check(lib().rpt_dataset_csr_host(ctx._h, _vp(rowptr), _vp(col), _vp(val), len(rowptr) - 1,
+                                         int(d), _DT[val.dtype], C.byref(h)))
+        return Dataset(ctx, h, len(rowptr) - 1, int(d), _DT[val.dtype], True)
+
+    @staticmethod
+    def of(ctx, data):
+        """Pack `V.Vector (Embed v Double x)`-like input once at the boundary.  Accepts a
+        Dataset, a 2-D array, (rowptr, col, val, d), a scipy CSR matrix, or a sequence of
+        Embed / DVector / SVector values."""
+        if isinstance(data, Dataset):
+            return data
+        if isinstance(data, np.ndarray):
+            return Dataset.dense(ctx, data)
+        if isinstance(data, tuple) and len(data) == 4 and not isinstance(data, (SVector,)):
+            return Dataset.csr(ctx, *data)
+        if hasattr(data, "indptr") and hasattr(data, "indices"):
+            return Dataset.csr(ctx, data.indptr, data.indices, data.data, data.shape[1])
+        vs = [x.eEmbed if isinstance(x, Embed) else x for x in data]
+        if not vs:
+            raise ValueError("empty dataset")
+        if isinstance(vs[0], DVector):
+            return Dataset.dense(ctx, np.stack([np.asarray(v.dvVec, dtype=np.float64) for v in vs]))
+        if isinstance(vs[0], SVector):
+            rowptr = np.zeros(len(vs) + 1, dtype=np.int64)
+            rowptr[1:] = np.cumsum([len(v.svIdx) for v in vs])
+            col = np.concatenate([v.svIdx for v in vs]).astype(np.int32)
+            val = np.concatenate([v.svVal for v in vs]).astype(np.float64)
+            return Dataset.csr(ctx, rowptr, col, val, vs[0].svDim)
+        return Dataset.dense(ctx, np.asarray(vs, dtype=np.float64))
+
+    def close(self):
+        if self._h is not None:
+            lib().rpt_dataset_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _query_dataset(ctx, like, q):
+    """One query or a batch -> Dataset with the layout (dense/CSR) and dtype of `like`."""
+    if isinstance(q, Dataset):
+        return q, q.n
+    npdt = np.float64 if like.dtype == RPT_F64 else np.float32
+    if like.is_csr:
+        if isinstance(q, SVector):
+            q = [q]
+        if isinstance(q, tuple) and len(q) == 4:
+            return Dataset.csr(ctx, q[0], q[1], np.asarray(q[2], dtype=npdt), q[3]), len(q[0]) - 1
+        rowptr = np.zeros(len(q) + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum([len(v.svIdx) for v in q])
+        col = (np.concatenate([v.svIdx for v in q]) if len(q) else np.zeros(0)).astype(np.int32)
+        val = (np.concatenate([v.svVal for v in q]) if len(q) else np.zeros(0)).astype(npdt)
+        return Dataset.csr(ctx, rowptr, col, val, like.d), len(q)
+    if isinstance(q, DVector):
+        q = q.dvVec
+    a = np.asarray(q, dtype=npdt)
+    if a.ndim == 1:
+        a = a[None, :]
+    return Dataset.dense(ctx, a), a.shape[0]
+
+
+# ---------------------------------------------------------------------------------------
+# forest (Internal.hs:139-182)
+# ---------------------------------------------------------------------------------------
+class RPTree:
+    """View of one tree of a flat forest: `RPTree d l a` (Internal.hs:172-175)."""
+
+    def __init__(self, forest, t):
+        self.forest, self.t = forest, t
+
+    @property
+    def _rpVectors(self):
+        R = self.forest.R[self.t]
+        out = []
+        for l in range(R.shape[0]):
+            idx = np.nonzero(R[l])[0].astype(np.int32)
+            out.append(SVector(R.shape[1], idx, R[l, idx]))
+        return out
+
+
+class RPForest:
+    """`RPForest d a` = IntMap of trees keyed 0..T-1 (Internal.hs:182), held in HBM in the flat
+    layout of include/rptree_hip.h; `perm`, `thr`, `mglo`, `mghi` copy it out."""
+
+    def __init__(self, ctx, handle, data, R, max_depth, min_leaf):
+        self.ctx, self._h, self.data = ctx, handle, data
+        self.R = R
+        self.T, self.L, self.d = R.shape
+        assert self.L == max_depth
+        self.min_leaf = int(min_leaf)
+        self.N = data.n
+        self._perm = self._nodes = None
+
+    # IntMap-like access
+    def __len__(self):
+        return self.T
+
+    def __getitem__(self, t):
+        if not 0 <= t < self.T:
+            raise KeyError(t)
+        return RPTree(self, t)
+
+    def __iter__(self):
+        return (RPTree(self, t) for t in range(self.T))
+
+    def keys(self):
+        return range(self.T)
+
+    @property
+    def perm(self):
+        if self._perm is None:
+            p = np.empty((self.T, self.N), dtype=np.int32)
+            check(lib().rpt_forest_get_perm(self._h, _vp(p)))
+            self._perm = p
+        return self._perm
+
+    def _get_nodes(self):
+        if self._nodes is None:
+            nodes = (1 << self.L) - 1
+            a = [np.empty((self.T, nodes), dtype=np.float64) for _ in range(3)]
+            check(lib().rpt_forest_get_nodes(self._h, _vp(a[0]), _vp(a[1]), _vp(a[2])))
+            self._nodes = a
+        return self._nodes
+
+    thr = property(lambda self: self._get_nodes()[0])
+    mglo = property(lambda self: self._get_nodes()[1])
+    mghi = property(lambda self: self._get_nodes()[2])
+
+    def proj(self):
+        dt = np.float64 if self.data.dtype == RPT_F64 else np.float32
+        p = np.empty((self.T, self.L, self.N), dtype=dt)
+        check(lib().rpt_forest_get_proj(self._h, _vp(p)))
+        return p
+
+    def stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().rpt_forest_stats(self._h, C.byref(a), C.byref(b)))
+        return {"tie_nodes": a.value, "big_mid_nodes": b.value}
+
+    def topology(self):
+        return topology(self.N, self.L, self.min_leaf)
+
+    def close(self):
+        if self._h is not None:
+            lib().rpt_forest_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def topology(n, max_depth, min_leaf):
+    """DFS list of (level, heap, offset, size, is_leaf) — Internal.hs:289,495,503."""
+    cnt = C.c_int64()
+    check(lib().rpt_topology(n, max_depth, min_leaf, None, 0, C.byref(cnt)))
+    out = np.empty((cnt.value, 5), dtype=np.int64)
+    check(lib().rpt_topology(n, max_depth, min_leaf, _vp(out), cnt.value, C.byref(cnt)))
+    return out
+
+
+def _build(ctx, ds, R, maxd, minl, mode):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    T, L, d = R.shape
+    if L != maxd:
+        raise ValueError("hyperplane block has %d levels, maxDepth is %d" % (L, maxd))
+    h = C.c_void_p()
+    check(lib().rpt_forest_build(ctx._h, ds._h, _vp(R), T, L, int(minl), int(mode), C.byref(h)))
+    return RPForest(ctx, h, ds, R, maxd, minl)
+
+
+def forestBatch(seed, maxd, minl, ntrees, pnz, dim, src, *, ctx=None, mode=RPT_PROJ_AUTO,
+                hyperplanes=None):
+    """Batch.hs:48-63.  seed, max tree depth, min leaf size, number of trees, nonzero density of
+    the projection vectors, their dimension, dataset.  The hyperplanes are sampled on the host
+    exactly where the reference samples them (Batch.hs:59-61) unless `hyperplanes` (a dense
+    [T][L][dim] block, e.g. produced by the real Haskell generator) is supplied."""
+    ctx = ctx or default_context()
+    ds = Dataset.of(ctx, src)
+    if hyperplanes is None:
+        _, R = gen.forest_hyperplanes(seed, ntrees, maxd, pnz, dim)
+    else:
+        R = np.asarray(hyperplanes, dtype=np.float64)
+    if R.shape[2] != ds.d:
+        # the reference never checks `dim` against the data; HBM indexing must
+        raise ValueError("projection vector dimension %d != data dimension %d" % (R.shape[2], ds.d))
+    return _build(ctx, ds, R, maxd, minl, mode)
+
+
+def treeBatch(seed, maxDepth, minLeaf, pnz, dim, src, **kw):
+    """Batch.hs:29-41 (= forestBatch with one tree: same draw order for a single tree)."""
+    return forestBatch(seed, maxDepth, minLeaf, 1, pnz, dim, src, **kw)
+
+
+def importForest(ctx, data, R, min_leaf, perm, thr, mglo, mghi):
+    """Rebuild a device forest from flat arrays (e.g. after deserialiseRPForest)."""
+    ds = Dataset.of(ctx, data)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    T, L, _ = R.shape
+    h = C.c_void_p()
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (thr, mglo, mghi)]
+    check(lib().rpt_forest_import(ctx._h, ds._h, _vp(R), T, L, int(min_leaf), _vp(perm),
+                                  _vp(a[0]), _vp(a[1]), _vp(a[2]), C.byref(h)))
+    return RPForest(ctx, h, ds, R, L, min_leaf)
+
+
+# ---- accessors (Internal.hs:199-208, RPTree.hs:362-367) ----
+def leaves(tree):
+    """All leaf buckets of a tree, left to right (ids)."""
+    f, t = tree.forest, tree.t
+    topo = f.topology()
+    return [f.perm[t, o:o + n] for (_, _, o, n, leaf) in topo if leaf]
+
+
+def levels(tree):
+    return tree.forest.L
+
+
+def points(tree):
+    return tree.forest.perm[tree.t]
+
+
+def leafSizes(tree):
+    return [int(n) for (_, _, _, n, leaf) in tree.forest.topology() if leaf]
+
+
+def treeSize(tree):
+    return sum(leafSizes(tree))
+
+
+# ---- algebra helpers on the host (single pairs; the batch lives on the device) ----
+def inner(u, v):
+    """Inner SVector DVector / SVector SVector / DVector DVector (Internal.hs:322-341) with the
+    reference's summation order."""
+    if isinstance(u, SVector) and isinstance(v, DVector):
+        acc = 0.0
+        m = min(len(u.svIdx), len(v.dvVec))
+        for j in range(m - 1, -1, -1):
+            acc = float(u.svVal[j]) * float(v.dvVec[u.svIdx[j]]) + acc
+        return acc
+    if isinstance(u, SVector) and isinstance(v, SVector):
+        prods, a, b = [], 0, 0
+        while a < len(u.svIdx) and b < len(v.svIdx):
+            if u.svIdx[a] == v.svIdx[b]:
+                prods.append(float(u.svVal[a]) * float(v.svVal[b]))
+                a += 1
+                b += 1
+            elif u.svIdx[a] < v.svIdx[b]:
+                a += 1
+            else:
+                b += 1
+        acc = 0.0
+        for p in reversed(prods):
+            acc = p + acc
+        return acc
+    acc = 0.0
+    for x, y in zip(u.dvVec, v.dvVec):
+        acc = acc + float(x) * float(y)
+    return acc
+
+
+def metricL2(u, v):
+    """metricDDL2 (Internal.hs:403-406) for dense pairs; the device kernels use the same
+    definition (true Euclidean distance)."""
+    a = np.asarray(u.dvVec if isinstance(u, DVector) else u, dtype=np.float64)
+    b = np.asarray(v.dvVec if isinstance(v, DVector) else v, dtype=np.float64)
+    return float(np.sqrt(np.sum((a - b) ** 2)))
+
+
+# ---------------------------------------------------------------------------------------
+# queries
+# ---------------------------------------------------------------------------------------
+def candidates(tree, q):
+    """RPTree.hs:289-314: ids of the leaf buckets reached by q in this tree, left to right."""
+    f = tree.forest
+    off, ids = candidatesBatch(f, q)
+    t = tree.t
+    return ids[off[t]:off[t + 1]]
+
+
+def candidatesBatch(forest, qs):
+    """-> (off[nq*T+1], ids): candidates of (query i, tree t) = ids[off[i*T+t]:off[i*T+t+1]]"""
+    ctx = forest.ctx
+    qd, nq = _query_dataset(ctx, forest.data, qs)
+    total = C.c_int64()
+    off = np.empty(nq * forest.T + 1, dtype=np.int64)
+    check(lib().rpt_candidates(ctx._h, forest._h, qd._h, _vp(off), None, 0, C.byref(total)))
+    ids = np.empty(max(total.value, 1), dtype=np.int32)
+    check(lib().rpt_candidates(ctx._h, forest._h, qd._h, _vp(off), _vp(ids), total.value,
+                               C.byref(total)))
+    return off, ids[:total.value]
+
+
+def knnBatch(k, forest, qs, dedup=False):
+    """knn for a batch of queries -> (ids[nq][k], dist[nq][k], count[nq])."""
+    ctx = forest.ctx
+    qd, nq = _query_dataset(ctx, forest.data, qs)
+    ids = np.empty((nq, k), dtype=np.int32)
+    dist = np.empty((nq, k), dtype=np.float64)
+    cnt = np.empty(nq, dtype=np.int32)
+    flags = RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES
+    check(lib().rpt_knn_host(ctx._h, forest._h, forest.data._h, qd._h, int(k), flags, _vp(ids),
+                             _vp(dist), _vp(cnt)))
+    return ids, dist, cnt
+
+
+def knn(distf, k, tts, q, dedup=False):
+    """RPTree.hs:168-176: `knn distf k forest q` -> [(distance, point id)] in increasing
+    distance order, duplicates across trees kept (the reference never de-duplicates).
+    Only distf = metricL2 is accelerated (the metric is evaluated on the device)."""
+    if distf is not metricL2:
+        raise NotImplementedError("the device path evaluates metricL2 only")
+    ids, dist, cnt = knnBatch(k, tts, q, dedup=dedup)
+    return [(float(dist[0, i]), int(ids[0, i])) for i in range(int(cnt[0]))]
+
+
+def bruteKnn(forest_or_data, qs, k, ctx=None):
+    data = forest_or_data.data if isinstance(forest_or_data, RPForest) else forest_or_data
+    ctx = ctx or data.ctx
+    qd, nq = _query_dataset(ctx, data, qs)
+    ids = np.empty((nq, k), dtype=np.int32)
+    dist = np.empty((nq, k), dtype=np.float64)
+    check(lib().rpt_brute_knn_host(ctx._h, data._h, qd._h, int(k), _vp(ids), _vp(dist)))
+    return ids, dist
+
+
+def recallWith(distf, tt, k, q):
+    """RPTree.hs:259-282: mean over trees of |candidates(tree, q) ∩ true kNN| / k, the truth by
+    brute force over all points."""
+    if distf is not metricL2:
+        raise NotImplementedError("the device path evaluates metricL2 only")
+    true_ids, _ = bruteKnn(tt, q, k)
+    kk = set(int(i) for i in true_ids[0] if i >= 0)
+    off, ids = candidatesBatch(tt, q)
+    rs = []
+    for t in range(tt.T):
+        aa = set(ids[off[t]:off[t + 1]].tolist())
+        rs.append(len(aa & kk) / k)
+    return sum(rs) / len(rs)
+
+
+# ---------------------------------------------------------------------------------------
+# stand-alone kernels (parity tests)
+# ---------------------------------------------------------------------------------------
+def project(data, R, mode=RPT_PROJ_AUTO, ctx=None):
+    """P[c][i] = R[c] `inner` x_i (the N inner products of Internal.hs:504 as one batch)."""
+    ctx = ctx or (data.ctx if isinstance(data, Dataset) else default_context())
+    ds = Dataset.of(ctx, data)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    Cn = R.shape[0]
+    dt = np.float64 if ds.dtype == RPT_F64 else np.float32
+    P = np.empty((Cn, ds.n), dtype=dt)
+    check(lib().rpt_project_host(ctx._h, ds._h, _vp(R), Cn, int(mode), _vp(P)))
+    return P
+
+
+def splitSegments(keys, perm, seg_off, seg_len, ctx=None):
+    """partitionAtMedian (Internal.hs:486-505) of every segment on caller-supplied projections.
+    Returns (perm sorted per segment, thr_mg[S][3])."""
+    ctx = ctx or default_context()
+    keys = np.ascontiguousarray(keys, dtype=np.float64)
+    perm = np.array(perm, dtype=np.int32)
+    so = np.ascontiguousarray(seg_off, dtype=np.int64)
+    sl = np.ascontiguousarray(seg_len, dtype=np.int64)
+    out = np.empty((len(so), 3), dtype=np.float64)
+    check(lib().rpt_split_segments(ctx._h, _vp(keys), len(keys), _vp(perm), _vp(so), _vp(sl),
+                                   len(so), _vp(out)))
+    return perm, out

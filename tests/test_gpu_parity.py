@@ -1,0 +1,358 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer / index results must be IDENTICAL; exact-order projections must be
+bit-identical; MFMA projections within 1e-5 * |x||r| (north_star tolerance, norm-relative
+because a projection can cancel to ~0)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rp():
+    import rptree_amd
+    return rptree_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(rp):
+    return rp.default_context()
+
+
+def ref_inner_exact(X, r):
+    """innerSD order (Internal.hs:382): acc = x_k*r_k + acc from the last index to the first,
+    separate multiply and add (numpy element-wise ops are IEEE exact)."""
+    acc = np.zeros(X.shape[0], dtype=X.dtype)
+    for k in range(X.shape[1] - 1, -1, -1):
+        if r[k] != 0:
+            acc = X[:, k] * X.dtype.type(r[k]) + acc
+    return acc
+
+
+def sparse_R(rng, C, d, pnz):
+    R = rng.standard_normal((C, d))
+    R[rng.random((C, d)) >= pnz] = 0.0
+    return R
+
+
+# ------------------------------------------------------------------ projection batch
+@pytest.mark.parametrize("n,d,C", [(1000, 16, 3), (5000, 128, 32), (777, 37, 33), (64, 5, 1),
+                                   (1, 128, 40), (4099, 130, 13)])
+def test_project_exact_f64_bit_identical(rp, ctx, n, d, C):
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d))
+    R = sparse_R(rng, C, d, 0.47)
+    P = rp.project(X, R, mode=rp.RPT_PROJ_EXACT, ctx=ctx)
+    for c in range(C):
+        assert np.array_equal(P[c], ref_inner_exact(X, R[c])), "column %d" % c
+
+
+def test_project_exact_matches_oracle_inner_sd(rp, ctx, oracle):
+    X = oracle.data_normal_dense2(1234, 300, 16)
+    R, _ = oracle.forest_hyperplanes(7, 2, 4, 0.83, 16)
+    P = rp.project(X, R.reshape(-1, 16), mode=rp.RPT_PROJ_EXACT, ctx=ctx)
+    for c in range(8):
+        idx = np.nonzero(R.reshape(-1, 16)[c])[0]
+        for i in (0, 1, 150, 299):
+            assert P[c, i] == oracle.inner_sd(idx, R.reshape(-1, 16)[c, idx], X[i])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 1e-5)])
+@pytest.mark.parametrize("n,d,C", [(1000, 16, 3), (5000, 128, 32), (777, 37, 33), (4099, 200, 17)])
+def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
+    rng = np.random.default_rng(n * 3 + d)
+    X = rng.standard_normal((n, d)).astype(dtype)
+    R = sparse_R(rng, C, d, 0.47)
+    P = rp.project(X, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    Rq = R.astype(dtype).astype(np.float64)          # the kernel rounds R to the compute type
+    want = X.astype(np.float64) @ Rq.T
+    scale = np.linalg.norm(X.astype(np.float64), axis=1)[:, None] * np.linalg.norm(Rq, axis=1)[None, :]
+    err = np.abs(P.T.astype(np.float64) - want)
+    assert (err <= tol * scale + 1e-300).all(), float((err / (scale + 1e-300)).max())
+
+
+def test_project_mfma_bf16_input(rp, ctx):
+    import torch
+    rng = np.random.default_rng(5)
+    n, d, C = 3000, 256, 32
+    Xf = rng.standard_normal((n, d)).astype(np.float32)
+    xb = torch.from_numpy(Xf).to(torch.bfloat16)
+    Xr = xb.to(torch.float32).numpy().astype(np.float64)     # exactly representable inputs
+    xd = xb.cuda()
+    torch.cuda.synchronize()
+    ds = rp.Dataset.dense_device(ctx, xd.data_ptr(), n, d, rp.RPT_BF16, keep=xd)
+    R = sparse_R(rng, C, d, 0.35)
+    P = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    Rq = R.astype(np.float32).astype(np.float64)
+    want = Xr @ Rq.T
+    scale = np.linalg.norm(Xr, axis=1)[:, None] * np.linalg.norm(Rq, axis=1)[None, :]
+    assert (np.abs(P.T - want) <= 1e-5 * scale).all()
+
+
+def test_project_csr_exact(rp, ctx, oracle):
+    rowptr, col, val = oracle.data_normal_sparse2(1234, 500, 40, 0.2)
+    rng = np.random.default_rng(0)
+    R = sparse_R(rng, 19, 40, 0.35)
+    ds = rp.Dataset.csr(ctx, rowptr, col, val, 40)
+    P = rp.project(ds, R, ctx=ctx)
+    for c in (0, 7, 18):
+        idx = np.nonzero(R[c])[0]
+        for i in (0, 3, 250, 499):
+            a, b = rowptr[i], rowptr[i + 1]
+            assert P[c, i] == oracle.inner_ss(idx, R[c, idx], col[a:b], val[a:b])
+
+
+# ------------------------------------------------------------------ split on identical inputs
+def test_split_segments_matches_partition_at_median(rp, ctx, oracle):
+    rng = np.random.default_rng(11)
+    n = 30000
+    keys = np.round(rng.standard_normal(n), 1)       # heavy ties
+    keys[rng.random(n) < 0.05] = 0.0
+    keys[rng.random(n) < 0.02] = -0.0
+    perm0 = rng.permutation(n).astype(np.int32)
+    seg_len = [1, 2, 3, 4, 7, 8, 100, 4096, 4097, 9000, 12000]
+    seg_off = np.concatenate([[0], np.cumsum(seg_len)[:-1]])
+    perm, tm = rp.splitSegments(keys, perm0, seg_off, seg_len, ctx=ctx)
+    for s, (o, l) in enumerate(zip(seg_off, seg_len)):
+        ids = perm0[o:o + l]
+        nh, order, thr, lo, hi = oracle.partition_at_median(keys[ids])
+        assert np.array_equal(perm[o:o + l], ids[order]), "segment %d" % s
+        assert (tm[s, 0], tm[s, 1], tm[s, 2]) == (thr, lo, hi)
+    # untouched tail
+    assert np.array_equal(perm[sum(seg_len):], perm0[sum(seg_len):])
+
+
+# ------------------------------------------------------------------ forest build
+def assert_forest_equal(f, fo):
+    assert np.array_equal(f.perm, fo.perm)
+    for a, b in ((f.thr, fo.thr), (f.mglo, fo.mglo), (f.mghi, fo.mghi)):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,d,T,min_leaf,L", [
+    (1000, 16, 3, 20, None),       # SURVEY §8c golden (iii)
+    (257, 5, 2, 128, 3),           # mixed leaf depths
+    (20000, 32, 4, 50, None),      # big path (n > 4096) at the top levels
+    (10000, 16, 2, 3000, 4),       # big nodes whose children are leaves
+    (9000, 8, 2, 5000, 3),         # leaves larger than the LDS sort
+    (3, 4, 2, 0, 4), (2, 4, 1, 0, 3), (1, 4, 1, 0, 2), (1, 4, 1, 5, 2), (50, 4, 2, 100, 5),
+    (64, 3, 1, 1, 0),              # maxDepth 0: the root is a Tip
+])
+def test_forest_build_exact_identical(rp, ctx, oracle, n, d, T, min_leaf, L):
+    X = oracle.data_normal_dense2(1234, n, d)
+    if L is None:
+        L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    else:
+        pnz = 0.6
+    R, _ = oracle.forest_hyperplanes(1235137, T, L, pnz, d)
+    fo = oracle.forest_build_dense(X, R, min_leaf, want_proj=True)
+    f = rp.forestBatch(1235137, L, min_leaf, T, pnz, d, X, ctx=ctx)
+    assert np.array_equal(f.R, R)                     # host generator == oracle generator
+    assert_forest_equal(f, fo)
+    if L > 0 and n > min_leaf:
+        P = f.proj()
+        mask = ~np.isnan(fo.proj)
+        assert np.array_equal(P[mask], fo.proj[mask])
+
+
+def test_forest_build_sparse_with_ties_identical(rp, ctx, oracle):
+    # SURVEY §8c golden (iv): sparse data x sparse hyperplanes -> many exact-zero projections
+    rowptr, col, val = oracle.data_normal_sparse2(1234, 6000, 12, 0.25)
+    R, _ = oracle.forest_hyperplanes(7, 3, 6, 0.3, 12)
+    fo = oracle.forest_build_csr(rowptr, col, val, 12, R, 10, want_proj=True)
+    assert (fo.proj[0, 0] == 0).sum() > 500
+    f = rp.forestBatch(7, 6, 10, 3, 0.3, 12, (rowptr, col, val, 12), ctx=ctx)
+    assert_forest_equal(f, fo)
+    assert f.stats()["tie_nodes"] > 0
+
+
+def test_forest_build_all_identical_points(rp, ctx, oracle):
+    # every projection ties at every level: order falls back to the input order
+    X = np.ones((5000, 6))
+    R, _ = oracle.forest_hyperplanes(3, 2, 5, 0.9, 6)
+    fo = oracle.forest_build_dense(X, R, 100)
+    f = rp.forestBatch(3, 5, 100, 2, 0.9, 6, X, ctx=ctx)
+    assert_forest_equal(f, fo)
+
+
+def test_forest_build_mfma_mode_is_valid_tree(rp, ctx, oracle):
+    """MFMA projections are not bit-identical, so compare structure: every point once per
+    tree, thresholds consistent with the tree's own projections, leaf flips vs oracle rare."""
+    n, d, T, min_leaf = 20000, 64, 4, 64
+    X = oracle.data_normal_dense2(99, n, d)
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    R, _ = oracle.forest_hyperplanes(5, T, L, pnz, d)
+    fo = oracle.forest_build_dense(X, R, min_leaf)
+    f = rp.forestBatch(5, L, min_leaf, T, pnz, d, X, ctx=ctx, mode=rp.RPT_PROJ_MFMA)
+    P = f.proj()
+    topo = f.topology()
+    for t in range(T):
+        assert np.array_equal(np.sort(f.perm[t]), np.arange(n))
+        for level, heap, off, m, leaf in topo:
+            if leaf:
+                continue
+            nh = m // 2
+            left = P[t, level][f.perm[t, off:off + nh]]
+            right = P[t, level][f.perm[t, off + nh:off + m]]
+            assert left.max() <= f.thr[t, heap] == right.min()
+    # leaf assignment agreement with the exact-order oracle
+    leaf_of = np.empty((T, n), dtype=np.int64)
+    leaf_of_o = np.empty((T, n), dtype=np.int64)
+    li = 0
+    for level, heap, off, m, leaf in topo:
+        if leaf:
+            for t in range(T):
+                leaf_of[t, f.perm[t, off:off + m]] = li
+                leaf_of_o[t, fo.perm[t, off:off + m]] = li
+            li += 1
+    flips = (leaf_of != leaf_of_o).mean()
+    assert flips < 1e-3, flips
+
+
+def test_forest_build_f32(rp, ctx, oracle):
+    n, d, T, min_leaf = 30000, 32, 3, 100
+    X = oracle.data_normal_dense2(3, n, d).astype(np.float32)
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    f = rp.forestBatch(11, L, min_leaf, T, pnz, d, X, ctx=ctx)
+    P = f.proj()
+    assert P.dtype == np.float32
+    for t in range(T):
+        assert np.array_equal(np.sort(f.perm[t]), np.arange(n))
+    for level, heap, off, m, leaf in f.topology():
+        if not leaf:
+            nh = m // 2
+            left = P[0, level][f.perm[0, off:off + nh]]
+            right = P[0, level][f.perm[0, off + nh:off + m]]
+            assert left.max() <= f.thr[0, heap] == right.min()
+
+
+# ------------------------------------------------------------------ queries
+@pytest.fixture(scope="module")
+def small_forest(rp, ctx, oracle):
+    n, d, T, min_leaf = 4000, 16, 5, 20
+    X = oracle.data_normal_dense2(1234, n, d)
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    R, _ = oracle.forest_hyperplanes(1235137, T, L, pnz, d)
+    fo = oracle.forest_build_dense(X, R, min_leaf)
+    f = rp.forestBatch(1235137, L, min_leaf, T, pnz, d, X, ctx=ctx)
+    Q = oracle.data_normal_dense2(4321, 32, d)
+    return X, f, fo, Q
+
+
+def test_candidates_identical(rp, small_forest, oracle):
+    X, f, fo, Q = small_forest
+    off, ids = rp.candidatesBatch(f, Q)
+    for i in range(len(Q)):
+        for t in range(f.T):
+            want = oracle.candidates_dense(fo, Q[i], t)
+            got = ids[off[i * f.T + t]:off[i * f.T + t + 1]]
+            assert np.array_equal(got, want), (i, t)
+    # data points as queries: proj == thr happens exactly -> the `otherwise` branch
+    off, ids = rp.candidatesBatch(f, X[:16])
+    for i in range(16):
+        for t in range(f.T):
+            want = oracle.candidates_dense(fo, X[i], t)
+            assert np.array_equal(ids[off[i * f.T + t]:off[i * f.T + t + 1]], want)
+
+
+@pytest.mark.parametrize("k", [1, 10, 50])
+def test_knn_matches_oracle(rp, small_forest, oracle, k):
+    X, f, fo, Q = small_forest
+    ids, dist, cnt = rp.knnBatch(k, f, Q)
+    for i in range(len(Q)):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+        assert cnt[i] == len(wi)
+        assert np.array_equal(ids[i, :cnt[i]], wi), i       # duplicates kept, same order
+        assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=0)
+    # single-query reference-shaped call
+    hits = rp.knn(rp.metricL2, k, f, rp.fromListDv(Q[0]))
+    assert [h[1] for h in hits] == oracle.knn_dense(fo, X, Q[0], k)[0].tolist()
+
+
+def test_knn_dedup(rp, small_forest, oracle):
+    X, f, fo, Q = small_forest
+    ids, dist, cnt = rp.knnBatch(10, f, Q, dedup=True)
+    for i in range(len(Q)):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], 10, dedup=True)
+        assert np.array_equal(ids[i, :cnt[i]], wi)
+        assert len(set(ids[i, :cnt[i]].tolist())) == cnt[i]
+
+
+def test_knn_more_than_candidates(rp, ctx, oracle):
+    X = oracle.data_normal_dense2(1, 40, 4)
+    f = rp.forestBatch(2, 2, 5, 1, 1.0, 4, X, ctx=ctx)
+    ids, dist, cnt = rp.knnBatch(30, f, X[:3])
+    assert (cnt < 30).all() and (ids[np.arange(3), cnt] == -1).all()
+    assert np.isinf(dist[0, cnt[0]])
+
+
+def test_two_discs_reference_test(rp, ctx, oracle):
+    # test/Data/RPTreeSpec.hs:50-85 on the device path
+    n, T, min_leaf, k = 10000, 10, 20, 5
+    X = oracle.data_circle2d2(42, n)
+    cfg = rp.rpTreeCfg(min_leaf, n, 2)
+    tts = rp.forestBatch(42, cfg.fpMaxTreeDepth, min_leaf, T, 1.0, 2, X, ctx=ctx)
+    assert all(rp.treeSize(t) == n for t in tts)
+    hits = rp.knn(rp.metricL2, k, tts, rp.fromListDv([0, 0]))
+    assert max(h[0] for h in hits) < 1
+
+
+def test_recall_with_matches_oracle(rp, small_forest, oracle):
+    X, f, fo, Q = small_forest
+    for i in range(4):
+        assert rp.recallWith(rp.metricL2, f, 10, Q[i]) == pytest.approx(
+            oracle.recall_with_dense(fo, X, Q[i], 10), abs=1e-12)
+
+
+def test_brute_knn(rp, small_forest, oracle):
+    X, f, fo, Q = small_forest
+    ids, dist = rp.bruteKnn(f, Q[:8], 10)
+    for i in range(8):
+        wi, wd = oracle.brute_knn_dense(X, Q[i], 10)
+        assert np.array_equal(ids[i], wi)
+        assert np.allclose(dist[i], wd, rtol=1e-12)
+
+
+def test_knn_csr(rp, ctx, oracle):
+    n, d = 3000, 30
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.3)
+    R, _ = oracle.forest_hyperplanes(9, 4, 6, 0.5, d)
+    fo = oracle.forest_build_csr(rowptr, col, val, d, R, 25)
+    f = rp.forestBatch(9, 6, 25, 4, 0.5, d, (rowptr, col, val, d), ctx=ctx)
+    assert np.array_equal(f.perm, fo.perm)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 10, d, 0.3)
+    ids, dist, cnt = rp.knnBatch(7, f, (qr, qc, qv, d))
+    for i in range(10):
+        a, b = qr[i], qr[i + 1]
+        wi, wd = oracle.knn_csr(fo, rowptr, col, val, qc[a:b], qv[a:b], 7, true_l2=True)
+        assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-9, atol=1e-12)
+        # ids agree wherever distances are separated (sparse rows can tie exactly)
+        if len(set(np.round(wd, 9))) == len(wd):
+            assert np.array_equal(ids[i, :cnt[i]], wi)
+
+
+def test_knn_merge_shards(rp, ctx, small_forest, oracle):
+    """Multi-GPU merge on one device: two shard forests (trees 0-1 | 2-4) merged == full knn."""
+    import ctypes as C
+    import torch
+    from rptree_amd import _lib
+    X, f, fo, Q = small_forest
+    k, nq = 10, len(Q)
+    R = f.R
+    fa = rp.forestBatch(0, f.L, f.min_leaf, 2, 0, f.d, X, ctx=ctx, hyperplanes=R[:2])
+    fb = rp.forestBatch(0, f.L, f.min_leaf, 3, 0, f.d, X, ctx=ctx, hyperplanes=R[2:])
+    parts = [rp.knnBatch(k, fa, Q), rp.knnBatch(k, fb, Q)]
+    ids = torch.tensor(np.stack([p[0] for p in parts])).cuda()
+    dist = torch.tensor(np.stack([p[1] for p in parts])).cuda()
+    cnt = torch.tensor(np.stack([p[2] for p in parts])).cuda()
+    oi = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+    oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().rpt_knn_merge_dev(ctx._h, ids.data_ptr(), dist.data_ptr(),
+                                            cnt.data_ptr(), 2, nq, k, 0, oi.data_ptr(),
+                                            od.data_ptr(), oc.data_ptr()))
+    ctx.sync()
+    full = rp.knnBatch(k, f, Q)
+    assert np.array_equal(oi.cpu().numpy(), full[0])
+    assert np.array_equal(od.cpu().numpy(), full[1])
