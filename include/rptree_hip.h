@@ -80,6 +80,15 @@ int32_t rpt_ctx_sync(rpt_ctx* ctx);
 /* the hipStream_t all work of this ctx is enqueued on (for HIP-event timing by the caller) */
 int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
 
+/* ---- kernel timing (bench.py roofline): HIP events recorded on the ctx stream around every
+ * launch of a kernel class while enabled.  which: 0 = projection batch kernel (one launch =
+ * up to 32 hyperplanes over the whole point set), 1 = split work of one tree level,
+ * 2 = query plan (query projections + traversal), 3 = distance/top-k kernel.
+ * rpt_prof_get synchronises the stream and returns the accumulated ms and launch count. */
+int32_t rpt_prof_enable(rpt_ctx* ctx, int32_t on);
+int32_t rpt_prof_reset(rpt_ctx* ctx);
+int32_t rpt_prof_get(rpt_ctx* ctx, int32_t which, double* total_ms, int64_t* launches);
+
 /* ---- datasets: Embed / DVector / SVector carriers (Internal.hs:56-59,92-93,122) ----
  * dense: row-major X[n][d] (`V.Vector (Embed DVector Double x)` packed once at the boundary).
  * csr:   SVector rows: rowptr[n+1] (int64), col[nnz] (int32, ascending per row, < d), val.

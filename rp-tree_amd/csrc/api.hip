@@ -38,6 +38,8 @@ void enumerate_topology(int64_t N, int32_t L, int32_t min_leaf, std::vector<Node
 
 using namespace rpt;
 
+static void prof_resolve(rpt_ctx* ctx);
+
 extern "C" {
 
 int32_t rpt_abi_version(void) { return RPT_ABI_VERSION; }
@@ -87,6 +89,7 @@ int32_t rpt_ctx_destroy(rpt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
+    prof_resolve(ctx);
     (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -103,6 +106,49 @@ int32_t rpt_ctx_sync(rpt_ctx* ctx) {
 int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream) {
   RPT_ARG(ctx && hip_stream, "NULL argument");
   *hip_stream = (void*)ctx->stream;
+  return RPT_OK;
+}
+
+// ---- kernel timing ----------------------------------------------------------------------
+static void prof_resolve(rpt_ctx* ctx) {
+  for (rpt_prof_span& sp : ctx->spans) {
+    float ms = 0.f;
+    if (hipEventSynchronize(sp.b) == hipSuccess &&
+        hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      ctx->prof_ms[sp.which] += (double)ms;
+      ctx->prof_n[sp.which] += 1;
+    }
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  ctx->spans.clear();
+}
+
+int32_t rpt_prof_enable(rpt_ctx* ctx, int32_t on) {
+  RPT_ARG(ctx, "ctx is NULL");
+  ctx->prof = on != 0;
+  return RPT_OK;
+}
+
+int32_t rpt_prof_reset(rpt_ctx* ctx) {
+  RPT_ARG(ctx, "ctx is NULL");
+  RPT_HIP(hipSetDevice(ctx->device));
+  prof_resolve(ctx);
+  for (int i = 0; i < RPT_PROF_CLASSES; ++i) {
+    ctx->prof_ms[i] = 0;
+    ctx->prof_n[i] = 0;
+  }
+  return RPT_OK;
+}
+
+int32_t rpt_prof_get(rpt_ctx* ctx, int32_t which, double* total_ms, int64_t* launches) {
+  RPT_ARG(ctx && total_ms && launches, "NULL argument");
+  RPT_ARG(which >= 0 && which < RPT_PROF_CLASSES, "unknown kernel class");
+  RPT_HIP(hipSetDevice(ctx->device));
+  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  prof_resolve(ctx);
+  *total_ms = ctx->prof_ms[which];
+  *launches = ctx->prof_n[which];
   return RPT_OK;
 }
 

@@ -86,12 +86,49 @@ struct DevBuf {
 
 }  // namespace rpt
 
+// kernel classes timed by rpt_prof_* (HIP events on the ctx stream)
+enum { RPT_PROF_PROJECT = 0, RPT_PROF_SPLIT = 1, RPT_PROF_KNN_PLAN = 2, RPT_PROF_KNN_TOPK = 3,
+       RPT_PROF_CLASSES = 4 };
+
+struct rpt_prof_span {
+  hipEvent_t a, b;
+  int which;
+};
+
 struct rpt_ctx {
   int32_t device = 0;
   hipStream_t stream = nullptr;
   int64_t last_candidates = 0;
   int32_t n_cu = 256;
+  bool prof = false;
+  std::vector<rpt_prof_span> spans;
+  double prof_ms[RPT_PROF_CLASSES] = {0, 0, 0, 0};
+  int64_t prof_n[RPT_PROF_CLASSES] = {0, 0, 0, 0};
 };
+
+namespace rpt {
+// RAII span: records an event pair around the launches issued in its scope when profiling
+// is enabled (rpt_prof_enable); resolved lazily by rpt_prof_get.
+struct ProfScope {
+  rpt_ctx* ctx;
+  rpt_prof_span sp;
+  bool on;
+  ProfScope(rpt_ctx* c, int which) : ctx(c), on(c->prof) {
+    if (!on) return;
+    sp.which = which;
+    if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(sp.a, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(sp.b, ctx->stream);
+    ctx->spans.push_back(sp);
+  }
+};
+}  // namespace rpt
 
 struct rpt_dataset {
   rpt_ctx* ctx = nullptr;

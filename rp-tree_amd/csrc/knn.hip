@@ -454,6 +454,7 @@ int32_t make_plan_t(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, QueryPlan
   const int64_t nq = q->n;
   const int T = f->T, L = f->L;
   hipStream_t st = ctx->stream;
+  ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
   RPT_TRY(pl.Pq.alloc((size_t)T * L * nq * sizeof(TK) + 16));
   if (L > 0 && nq > 0) RPT_TRY(project_columns(ctx, q, f->R.p, T * L, f->mode, pl.Pq.p));
   const int64_t m = nq * T;
@@ -528,6 +529,7 @@ static int32_t launch_topk_dense(rpt_ctx* ctx, const rpt_dataset* data, const rp
   if (smem > 64 * 1024)
     RPT_HIP(hipFuncSetAttribute((const void*)topk_dense_kernel<TD>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   hipLaunchKernelGGL(topk_dense_kernel<TD>, dim3((unsigned)q->n), dim3(256), smem, ctx->stream,
                      (const TD*)data->X, data->d, (const TD*)q->X, perm, ranges, rng_off, T,
                      data->n, identity, k, dedup, ids, dist, cnt);

@@ -109,6 +109,112 @@ __global__ __launch_bounds__(256) void proj_exact(const T* __restrict__ X, int64
 }
 
 // ---------------------------------------------------------------------------------------
+// Fast exact-order path for rows of exactly D elements.  Same arithmetic as proj_exact (one
+// `acc = r*x + acc` per (k, hyperplane), k descending, separate multiply and add) with
+//   * guard-free, fully unrolled staging: the next k-chunk's 16-B pieces are loaded into
+//     registers while the current chunk is accumulated (async-STAGE split); waves never
+//     synchronise with each other (wave-private LDS tile),
+//   * SKIP (off by default): the (k, c) pairs with r == 0 — the terms innerSD never visits
+//     (Internal.hs:375-382); a dense-ified zero adds an exact +-0 that never changes the
+//     accumulator — can be skipped with wave-uniform scalar branches on a per-k bit mask.
+//     Measured as a loss: hipcc sinks the scalar load of r into every taken branch, so each
+//     executed term waits on the scalar cache; the dense form hoists 4 s_load_dwordx16 per k.
+// Work item = (64-row tile, k-chunk); chunks of a tile are visited last to first.
+// ---------------------------------------------------------------------------------------
+template <class T>
+__global__ void mask_R_kernel(const T* __restrict__ Rt, int d, int CB, int nblk,
+                              uint32_t* __restrict__ masks /*[nblk][d]*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk * d) return;
+  const T* r = Rt + (int64_t)i * CB;
+  uint32_t m = 0;
+  for (int c = 0; c < CB; ++c) m |= (r[c] != (T)0 ? 1u : 0u) << c;
+  masks[i] = m;
+}
+
+template <class T, int D, int CB, int KC, bool SKIP>
+__global__ __launch_bounds__(256, 2) void proj_exact_fast(const T* __restrict__ X, int64_t n,
+                                                          const T* __restrict__ Rt /*[D][CB]*/,
+                                                          const uint32_t* __restrict__ masks,
+                                                          T* __restrict__ P, int64_t ldp,
+                                                          int ncol, int64_t ntiles) {
+  static_assert(CB == 32, "one mask bit per hyperplane");
+  constexpr int PIECE = 16 / (int)sizeof(T);
+  constexpr int PPR = KC / PIECE;              // pieces per row per chunk
+  constexpr int NP = kWave * PPR / 64;         // pieces per lane per chunk
+  constexpr int NCH = D / KC;
+  constexpr int LDW = KC + PIECE;              // row stride keeps 16-B alignment
+  __shared__ __attribute__((aligned(16))) T tile[4][kWave * LDW];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  T* my = tile[wave];
+  struct alignas(16) Raw { T v[PIECE]; };
+  const int64_t last_row = n - 1;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+
+  Raw stage[NP];
+  auto issue = [&](int64_t t, int ch) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = i * 64 + lane;
+      int64_t row = t * kWave + p / PPR;
+      row = row < last_row ? row : last_row;
+      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + ch * KC + (p % PPR) * PIECE);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = i * 64 + lane;
+      *reinterpret_cast<Raw*>(my + (p / PPR) * LDW + (p % PPR) * PIECE) = stage[i];
+    }
+  };
+
+  T acc[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) acc[c] = (T)0;
+
+  int64_t t = wave_global;
+  int ch = NCH - 1;
+  if (t < ntiles) issue(t, ch);
+  while (t < ntiles) {
+    commit();
+    // next work item
+    int64_t tn = t;
+    int chn = ch - 1;
+    if (chn < 0) {
+      chn = NCH - 1;
+      tn = t + wave_stride;
+    }
+    if (tn < ntiles) issue(tn, chn);
+    // accumulate this chunk, k descending
+    const T* rrow = Rt + (int64_t)ch * KC * CB;
+    const uint32_t* mrow = masks + ch * KC;
+    for (int k = KC - 1; k >= 0; --k) {
+      const T x = my[lane * LDW + k];
+      const T* rk = rrow + k * CB;      // wave-uniform -> scalar loads
+      const uint32_t mk = SKIP ? mrow[k] : 0u;  // wave-uniform
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+        if (!SKIP || (mk & (1u << c))) acc[c] = add_rn(mul_rn(rk[c], x), acc[c]);
+    }
+    if (ch == 0) {
+      const int64_t row = t * kWave + lane;
+      if (row < n) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+          if (c < ncol) P[(int64_t)c * ldp + row] = acc[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CB; ++c) acc[c] = (T)0;
+    }
+    t = tn;
+    ch = chn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // MFMA kernel.  D[m = hyperplane][n = point] = sum_k A[m][k] * B[k][n],
 //   A[m][k] = R[c0+m][k]   (lane l: m = l&15, k = 4s + (l>>4)) — registers, loaded once per
 //             k-chunk (hoisted out of the tile loop when d <= KCH),
@@ -248,6 +354,117 @@ __global__ __launch_bounds__(WAVES * 64) void proj_mfma(const TIn* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// Fast MFMA path for rows of exactly D elements (D = 128: BASELINE configs C2/C4).
+// No per-element guards anywhere in the loop:
+//   * hyperplane fragments come from a pre-padded buffer Apad[CBT][D/4][64] (one coalesced
+//     load per fragment, zero where col >= ncol),
+//   * a 16-row tile is ONE contiguous 16*D*sizeof(TIn) byte run of row-major X: every lane
+//     loads 16 B pieces, piece p of the tile -> row p / (D*sizeof/16); rows past n are
+//     clamped to the last row (their results are never stored),
+//   * software pipeline (async-STAGE split): the next tile's pieces are loaded into
+//     registers while the current tile is multiplied out of LDS; waves never synchronise
+//     with each other (wave-private LDS tile).
+// ---------------------------------------------------------------------------------------
+template <class TC>
+__global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, int nblk,
+                             TC* __restrict__ Apad /*[nblk][2][D/4][64]*/) {
+  const int steps = D / 4;
+  const int64_t total = (int64_t)nblk * 2 * steps * 64;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const int s = (int)((i >> 6) % steps);
+    const int h = (int)((i / (64 * (int64_t)steps)) & 1);
+    const int blk = (int)(i / (128 * (int64_t)steps));
+    const int col = blk * 32 + h * 16 + (lane & 15);
+    const int k = 4 * s + (lane >> 4);
+    Apad[i] = (col < C && k < d) ? (TC)R[(int64_t)col * d + k] : (TC)0;
+  }
+}
+
+template <class TIn, class TC, int D, int CBT>
+__global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
+                                                         const TC* __restrict__ Apad, int c0,
+                                                         int ncol, TC* __restrict__ P,
+                                                         int64_t ldp, int64_t ntiles) {
+  constexpr int STEPS = D / 4;
+  constexpr int PIECE = 16 / (int)sizeof(TIn);            // elements per 16-B piece
+  constexpr int PIECES_PER_ROW = D / PIECE;
+  constexpr int NP = 16 * PIECES_PER_ROW / 64;            // pieces per lane per tile
+  constexpr int LDW = D + 16 / (int)sizeof(TC);           // LDS row stride (elements of TC)
+  static_assert((16 * PIECES_PER_ROW) % 64 == 0, "tile must be a multiple of 64 pieces");
+  __shared__ __attribute__((aligned(16))) TC tile[4][16 * LDW];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  TC* my = tile[wave];
+  typedef typename Mfma<TC>::acc_t acc_t;
+  struct alignas(16) Raw { TIn v[PIECE]; };
+
+  TC a[CBT][STEPS];
+#pragma unroll
+  for (int h = 0; h < CBT; ++h)
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) a[h][s] = Apad[(h * STEPS + s) * 64 + lane];
+
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+  const int64_t last_row = n - 1;
+
+  Raw stage[NP];
+  auto issue = [&](int64_t t) {
+    const int64_t row0 = t * 16;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = i * 64 + lane;
+      int64_t row = row0 + p / PIECES_PER_ROW;
+      row = row < last_row ? row : last_row;
+      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + (p % PIECES_PER_ROW) * PIECE);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = i * 64 + lane;
+      TC* dst = my + (p / PIECES_PER_ROW) * LDW + (p % PIECES_PER_ROW) * PIECE;
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        if constexpr (sizeof(TIn) == sizeof(TC)) dst[j] = (TC)stage[i].v[j];
+        else dst[j] = (TC)to_f32<TIn>(stage[i].v[j]);
+      }
+    }
+  };
+
+  int64_t t = wave_global;
+  if (t < ntiles) issue(t);
+  while (t < ntiles) {
+    commit();                                   // waits for the staged pieces, writes LDS
+    const int64_t tn = t + wave_stride;
+    if (tn < ntiles) issue(tn);                 // in flight during the MFMA phase
+    acc_t acc[CBT];
+#pragma unroll
+    for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const TC b = my[m * LDW + 4 * s + q];
+#pragma unroll
+      for (int h = 0; h < CBT; ++h) acc[h] = Mfma<TC>::run(a[h][s], b, acc[h]);
+    }
+    const int64_t row = t * 16 + m;             // D col = lane&15 = point
+    if (row < n) {
+#pragma unroll
+      for (int h = 0; h < CBT; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
+          if (col < ncol) P[(int64_t)(c0 + col) * ldp + row] = acc[h][r];
+        }
+    }
+    t = tn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // CSR rows x dense-ified hyperplanes.  16 lanes per row (one lane per hyperplane of the
 // block, CB = 16), 4 rows per wave; every lane walks its row's nonzeros from the last to
 // the first: acc = val*r[col] + acc  (innerSS, Internal.hs:353-366: only matching indices
@@ -281,6 +498,32 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                     TC* P) {
   const int64_t n = ds->n;
   const int64_t ntiles = (n + 15) / 16;
+  if (ds->d == 128) {  // guard-free pipelined path
+    constexpr int D = 128;
+    const int nblk = (C + 31) / 32;
+    DevBuf<TC> Apad;
+    RPT_TRY(Apad.alloc((size_t)nblk * 2 * (D / 4) * 64));
+    hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D,
+                       nblk, Apad.p);
+    int64_t blocks = (ntiles + 3) / 4;
+    const int64_t cap = (int64_t)ctx->n_cu * 2;
+    if (blocks > cap) blocks = cap;
+    for (int b = 0; b < nblk; ++b) {
+      const int c0 = b * 32;
+      const int ncol = C - c0 < 32 ? C - c0 : 32;
+      const TC* Ab = Apad.p + (size_t)b * 2 * (D / 4) * 64;
+      ProfScope ps(ctx, RPT_PROF_PROJECT);
+      if (ncol > 16)
+        hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
+                           ctx->stream, (const TIn*)ds->X, n, Ab, c0, ncol, P, n, ntiles);
+      else
+        hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
+                           ctx->stream, (const TIn*)ds->X, n, Ab, c0, ncol, P, n, ntiles);
+    }
+    RPT_HIP(hipGetLastError());
+    RPT_HIP(hipStreamSynchronize(ctx->stream));  // Apad is released on return
+    return RPT_OK;
+  }
   constexpr int WAVES = 4;
   int64_t blocks = (ntiles + WAVES - 1) / WAVES;
   const int64_t cap = (int64_t)ctx->n_cu * 8;
@@ -288,6 +531,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
   if (blocks < 1) blocks = 1;
   for (int c0 = 0; c0 < C; c0 += 32) {
     const int ncol = C - c0 < 32 ? C - c0 : 32;
+    ProfScope ps(ctx, RPT_PROF_PROJECT);
     if (ncol > 16)
       hipLaunchKernelGGL((proj_mfma<TIn, TC, 2, 128, WAVES>), dim3((unsigned)blocks),
                          dim3(WAVES * 64), 0, ctx->stream, (const TIn*)ds->X, n, ds->d, R_dev,
@@ -309,15 +553,31 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
   constexpr int CB = 32;
   const int nblk = (C + CB - 1) / CB;
   DevBuf<T> Rt;
+  DevBuf<uint32_t> masks;
   RPT_TRY(Rt.alloc((size_t)nblk * d * CB));
   hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
+  const bool fast = d == 128;
+  if (fast) {
+    RPT_TRY(masks.alloc((size_t)nblk * d));
+    hipLaunchKernelGGL(mask_R_kernel<T>, dim3((unsigned)((nblk * d + 255) / 256)), dim3(256), 0,
+                       ctx->stream, Rt.p, d, CB, nblk, masks.p);
+  }
+  const int64_t ntiles = (n + 63) / 64;
+  int64_t fblocks = (ntiles + 3) / 4;
+  if (fblocks > (int64_t)ctx->n_cu * 2) fblocks = (int64_t)ctx->n_cu * 2;
   const int64_t blocks = (n + 255) / 256;
   for (int b = 0; b < nblk; ++b) {
     const int c0 = b * CB;
     const int ncol = C - c0 < CB ? C - c0 : CB;
-    hipLaunchKernelGGL((proj_exact<T, CB, 32>), dim3((unsigned)blocks), dim3(256), 0,
-                       ctx->stream, (const T*)ds->X, n, d, Rt.p + (size_t)b * d * CB,
-                       P + (int64_t)c0 * n, n, ncol);
+    ProfScope ps(ctx, RPT_PROF_PROJECT);
+    if (fast)
+      hipLaunchKernelGGL((proj_exact_fast<T, 128, CB, 32, false>), dim3((unsigned)fblocks), dim3(256), 0,
+                         ctx->stream, (const T*)ds->X, n, Rt.p + (size_t)b * d * CB,
+                         masks.p + (size_t)b * d, P + (int64_t)c0 * n, n, ncol, ntiles);
+    else
+      hipLaunchKernelGGL((proj_exact<T, CB, 32>), dim3((unsigned)blocks), dim3(256), 0,
+                         ctx->stream, (const T*)ds->X, n, d, Rt.p + (size_t)b * d * CB,
+                         P + (int64_t)c0 * n, n, ncol);
   }
   RPT_HIP(hipGetLastError());
   RPT_HIP(hipStreamSynchronize(ctx->stream));  // Rt is freed on return
@@ -337,6 +597,7 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
   for (int b = 0; b < nblk; ++b) {
     const int c0 = b * CB;
     const int ncol = C - c0 < CB ? C - c0 : CB;
+    ProfScope ps(ctx, RPT_PROF_PROJECT);
     hipLaunchKernelGGL((proj_csr<T, CB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
                        ds->rowptr, ds->col, (const T*)ds->val, n, Rt.p + (size_t)b * d * CB,
                        P + (int64_t)c0 * n, n, ncol);

@@ -37,7 +37,7 @@ namespace {
 constexpr int kSmallCap = 4096;   // largest segment sorted by one workgroup in LDS
 constexpr int kNB = 1024;         // value bins of the big path (0 and kNB-1 are the tails)
 constexpr int kSample = 1024;     // samples per big node
-constexpr int kDelta = 48;        // splitter half-width in sample ranks (~4.2 sigma)
+constexpr int kDelta = 80;        // splitter half-width in sample ranks (5 sigma: sd = 16)
 constexpr int kChunk = 4096;      // elements per block in hist / scatter
 constexpr int kPad = 0x7fffffff;  // id of bitonic padding entries
 
@@ -721,6 +721,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   };
 
   for (int level = 0; level < Lused; ++level) {
+    ProfScope ps(ctx, RPT_PROF_SPLIT);
     std::vector<Seg> small, big;
     for (const Seg& s : splits[(size_t)level]) (s.n > kSmallCap ? big : small).push_back(s);
     // children of this level's split nodes that are leaves

@@ -27,6 +27,9 @@ SYMBOLS = {
     "rpt_ctx_destroy": (i32, [vp]),
     "rpt_ctx_sync": (i32, [vp]),
     "rpt_ctx_stream": (i32, [vp, C.POINTER(vp)]),
+    "rpt_prof_enable": (i32, [vp, i32]),
+    "rpt_prof_reset": (i32, [vp]),
+    "rpt_prof_get": (i32, [vp, i32, p_f64, p_i64]),
     "rpt_dataset_dense_host": (i32, [vp, vp, i64, i32, i32, C.POINTER(vp)]),
     "rpt_dataset_dense_dev": (i32, [vp, vp, i64, i32, i32, C.POINTER(vp)]),
     "rpt_dataset_csr_host": (i32, [vp, vp, vp, vp, i64, i32, i32, C.POINTER(vp)]),
