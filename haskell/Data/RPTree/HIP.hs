@@ -1,0 +1,99 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+{-# LANGUAGE FlexibleContexts #-}
+-- | Binding of the MI355X hot path (include/rptree_hip.h) under the unchanged Data.RPTree API.
+--
+-- WRITTEN BLIND: there is no GHC in the build image, so this module has not been compiled.
+-- It shows the binding a maintainer would add next to src/Data/RPTree/Batch.hs; the tested
+-- mirrors of exactly this call sequence are rp-tree_amd/python/rptree_amd/__init__.py and
+-- rp-tree_amd/host/rptree.hpp.
+module Data.RPTree.HIP (forestBatchHIP, knnHIP, FlatForest(..)) where
+
+import Control.Exception (Exception, throwIO)
+import Control.Monad (when)
+import Data.Int (Int32, Int64)
+import Data.Word (Word64)
+import Foreign.C.String (CString, peekCString)
+import Foreign.ForeignPtr (ForeignPtr, newForeignPtr, withForeignPtr)
+import Foreign.Marshal.Alloc (alloca)
+import Foreign.Ptr (FunPtr, Ptr, castPtr, nullPtr)
+import Foreign.Storable (peek)
+import System.IO.Unsafe (unsafePerformIO)
+import qualified Data.IntMap.Strict as IM
+import qualified Data.Vector as V
+import qualified Data.Vector.Storable as VS
+import qualified Data.Vector.Storable.Mutable as VSM
+import qualified Data.Vector.Unboxed as VU
+
+import System.Random.SplitMix.Distributions (sample, stdNormal)
+import Data.RPTree.Gen (sparse)
+import Data.RPTree.Internal (Embed(..), DVector(..), SVector(..), RPForest, RPTree(..), RPT(..), Margin(..))
+import Data.Semigroup (Max(..), Min(..))
+
+data Ctx; data Dataset; data Forest
+
+-- `safe`: every call may launch kernels and synchronise; do not block the RTS.
+foreign import ccall safe "rpt_ctx_create"          c_ctx_create     :: Int32 -> Ptr (Ptr Ctx) -> IO Int32
+foreign import ccall safe "rpt_dataset_dense_host"  c_dataset_dense  :: Ptr Ctx -> Ptr Double -> Int64 -> Int32 -> Int32 -> Ptr (Ptr Dataset) -> IO Int32
+foreign import ccall safe "rpt_forest_build"        c_forest_build   :: Ptr Ctx -> Ptr Dataset -> Ptr Double -> Int32 -> Int32 -> Int32 -> Int32 -> Ptr (Ptr Forest) -> IO Int32
+foreign import ccall safe "rpt_forest_get_perm"     c_forest_perm    :: Ptr Forest -> Ptr Int32 -> IO Int32
+foreign import ccall safe "rpt_forest_get_nodes"    c_forest_nodes   :: Ptr Forest -> Ptr Double -> Ptr Double -> Ptr Double -> IO Int32
+foreign import ccall safe "rpt_knn_host"            c_knn_host       :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Int32 -> Ptr Int32 -> Ptr Double -> Ptr Int32 -> IO Int32
+foreign import ccall unsafe "rpt_last_error"        c_last_error     :: IO CString
+foreign import ccall "&rpt_forest_free"             p_forest_free    :: FunPtr (Ptr Forest -> IO ())
+foreign import ccall "&rpt_dataset_free"            p_dataset_free   :: FunPtr (Ptr Dataset -> IO ())
+
+newtype RPTHipError = RPTHipError String deriving Show
+instance Exception RPTHipError          -- next to RPTError (Internal.hs:66-72)
+
+check :: Int32 -> IO ()
+check 0 = pure ()
+check _ = c_last_error >>= peekCString >>= throwIO . RPTHipError
+
+-- | The flat forest of include/rptree_hip.h, copied out so ordinary 'RPTree' values can be rebuilt.
+data FlatForest = FlatForest
+  { ffPerm :: VS.Vector Int32, ffThr, ffLo, ffHi :: VS.Vector Double
+  , ffN, ffTrees, ffDepth, ffMinLeaf :: Int }
+
+-- | Drop-in for 'Data.RPTree.Batch.forestBatch' (Batch.hs:48-63) on dense data.
+forestBatchHIP :: Word64 -> Int -> Int -> Int -> Double -> Int
+               -> V.Vector (Embed DVector Double x)
+               -> RPForest Double (V.Vector (Embed DVector Double x))
+forestBatchHIP seed maxd minl ntrees pnz dim src = unsafePerformIO $ do
+  -- hyperplanes: sampled by the HOST exactly as Batch.hs:59-61 does
+  let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))
+      dense (SV _ vv) = VS.fromList [ maybe 0 id (lookup i (VU.toList vv)) | i <- [0 .. dim - 1] ]
+      rflat = VS.concat [ dense r | rvs <- V.toList rvss, r <- V.toList rvs ]          -- R[T][L][d]
+      xflat = VS.concat [ VS.convert v | Embed (DV v) _ <- V.toList src ]                -- X[N][d]
+      n = V.length src
+      nodes = 2 ^ maxd - 1
+  ctx <- alloca $ \pp -> c_ctx_create 0 pp >>= check >> peek pp
+  ds  <- alloca $ \pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral n) (fromIntegral dim) 0 pp) >>= check >> peek pp
+  f   <- alloca $ \pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) 0 pp) >>= check >> peek pp
+  perm <- VSM.new (ntrees * n); thr <- VSM.new (ntrees * nodes); lo <- VSM.new (ntrees * nodes); hi <- VSM.new (ntrees * nodes)
+  VSM.unsafeWith perm (c_forest_perm f) >>= check
+  VSM.unsafeWith thr (\a -> VSM.unsafeWith lo (\b -> VSM.unsafeWith hi (c_forest_nodes f a b))) >>= check
+  ff <- FlatForest <$> VS.freeze perm <*> VS.freeze thr <*> VS.freeze lo <*> VS.freeze hi
+                   <*> pure n <*> pure ntrees <*> pure maxd <*> pure minl
+  _ <- newForeignPtr p_forest_free f; _ <- newForeignPtr p_dataset_free ds
+  pure $ IM.fromList [ (t, RPTree (rvss V.! t) (rebuild ff src t)) | t <- [0 .. ntrees - 1] ]
+
+-- | Rebuild the lazy 'RPT' (Internal.hs:139-149) of tree t from the flat arrays: topology is a
+-- pure function of (N, minLeaf, maxDepth) (Internal.hs:289,495,503).
+rebuild :: FlatForest -> V.Vector a -> Int -> RPT Double () (V.Vector a)
+rebuild ff src t = go 0 0 0 (ffN ff)
+  where
+    nodes = 2 ^ ffDepth ff - 1
+    go lev h off m
+      | lev >= ffDepth ff || m <= ffMinLeaf ff =
+          Tip () (V.generate m (\i -> src V.! fromIntegral (ffPerm ff VS.! (t * ffN ff + off + i))))
+      | otherwise =
+          let nh = m `div` 2; ix = t * nodes + h
+          in Bin () (ffThr ff VS.! ix) (Margin (Max (ffLo ff VS.! ix)) (Min (ffHi ff VS.! ix)))
+                 (go (lev + 1) (2 * h + 1) off nh) (go (lev + 1) (2 * h + 2) (off + nh) (m - nh))
+
+-- | 'knn metricL2 k' (RPTree.hs:168-176) for a batch of dense queries: ids and distances.
+knnHIP :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int -> Int -> IO (VS.Vector Int32, VS.Vector Double, VS.Vector Int32)
+knnHIP ctx f ds qs nq k = do
+  ids <- VSM.new (nq * k); dist <- VSM.new (nq * k); cnt <- VSM.new nq
+  VSM.unsafeWith ids (\a -> VSM.unsafeWith dist (\b -> VSM.unsafeWith cnt (c_knn_host ctx f ds qs (fromIntegral k) 0 a b))) >>= check
+  (,,) <$> VS.freeze ids <*> VS.freeze dist <*> VS.freeze cnt

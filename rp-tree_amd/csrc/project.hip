@@ -32,6 +32,14 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 
+// 16-byte register pieces (SSA-friendly ext vectors; struct pieces were demoted to scratch)
+template <class T>
+struct Vec16;
+template <>
+struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <>
+struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); };
+
 // ---------------------------------------------------------------------------------------
 // transpose a block of hyperplanes R[C][d] -> Rt[blk][d][CB] (k-major, zero padded)
 // ---------------------------------------------------------------------------------------
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void proj_exact_fast(const T* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   T* my = tile[wave];
-  struct alignas(16) Raw { T v[PIECE]; };
+  typedef typename Vec16<T>::type Raw;
   const int64_t last_row = n - 1;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * 4;
