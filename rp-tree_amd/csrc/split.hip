@@ -27,6 +27,9 @@
 // Algorithmic HBM bytes per point per tree per level (SURVEY.md §8d lower bound: 16):
 //   big path: perm 4 + key gather 8 + key stash 8+8 + perm 4+4 = 36; small path: 4 + 8 + 4.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <limits>
 
 #include "common.h"
@@ -169,6 +172,486 @@ __global__ __launch_bounds__(256) void small_sort_kernel(
     mghi[h] = (double)skey[nh + 1 < n ? nh + 1 : n - 1];
     if (nh > 0 && !(skey[nh - 1] < skey[nh])) atomicAdd(tie_count, 1ULL);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// fused small-subtree kernel: one workgroup per (tree, top node with n <= kSmallCap) runs up
+// to kRmax tree levels without moving a single element:
+//   per level: gather the level's key of every element, per-node min/max, per-node value
+//   histogram in LDS (kSmallCap/M bins per node, M = nodes at this depth), pivot bin by a
+//   wave scan, exact resolution of the pivot bin only (rank counting with the lexicographic
+//   tie-break), thr / margins, child = 2*node + side.  O(n) per level, no sort.
+//   An element whose child is a leaf (Internal.hs:289) retires with (left-aligned path, the
+//   key of its last split).  One bitonic sort by (path, key, tie-break) at the end puts every
+//   leaf bucket in the reference's order (children inherit the sorted order,
+//   Internal.hs:495,504-505) and groups the still-active nodes in left-to-right order.
+//   Retired elements go to the final perm F, active ones to `nxt` for the next launch.
+// grid = (S, T), 256 threads.
+// ---------------------------------------------------------------------------------------
+constexpr int kRmax = 6;                 // levels per launch (<= 64 nodes per block)
+constexpr int kSubThreads = 1024;        // 16 waves: latency hiding + small per-thread state
+constexpr int kE = kSmallCap / kSubThreads;  // element slots per thread
+constexpr int kMaxM = 1 << (kRmax - 1);  // nodes at the deepest processed depth
+
+struct SubNode {  // per relative node of the current depth (LDS)
+  int n, nh, pb, cL, cMid, lowb, highb, midoff;
+};
+
+__device__ inline int sub_node_size(int n_top, int r, int j) {
+  int n = n_top;
+  for (int b = r - 1; b >= 0; --b) {
+    const int nh = n >> 1;
+    n = ((j >> b) & 1) ? n - nh : nh;
+  }
+  return n;
+}
+
+template <class TK>
+__global__ __launch_bounds__(kSubThreads) void subtree_kernel(
+    const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
+    int64_t N, const TK* __restrict__ P, int L, int level0, int min_leaf,
+    const Seg* __restrict__ segs, double* thr, double* mglo, double* mghi, int64_t nodes,
+    unsigned long long* tie_count, unsigned long long* dbg) {
+  __shared__ __attribute__((aligned(16))) TK skey[kSmallCap];
+  __shared__ int sid[kSmallCap];
+  __shared__ unsigned int sx[kSmallCap];          // histogram during the levels, path at the end
+  __shared__ unsigned long long nmin[kMaxM], nmax[kMaxM], nmaxL[kMaxM], nminR[kMaxM];
+  __shared__ TK nlo[kMaxM], nscale[kMaxM];
+  __shared__ SubNode sn[kMaxM];
+  __shared__ int midcur[kMaxM];
+  __shared__ int s_active;
+
+  const Seg sg = segs[blockIdx.x];
+  const int t = blockIdx.y;
+  const int n_top = sg.n;
+  if (n_top <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int dbgi = 0;
+#define STAMP() do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) dbg[dbgi++] = clock64(); } while (0)
+  STAMP();
+  const TK* Pt = P + (int64_t)t * L * N;
+  const int32_t* s = src + (int64_t)t * N + sg.off;
+
+  int id[kE], node[kE];
+  unsigned int dpath[kE];   // (left-aligned path << 8) | level of the retained key; 0 = active
+  TK fkey[kE];
+#pragma unroll
+  for (int e = 0; e < kE; ++e) {
+    const int pos = e * kSubThreads + tid;
+    id[e] = pos < n_top ? s[pos] : -1;
+    node[e] = 0;
+    dpath[e] = 0;
+    fkey[e] = (TK)0;
+  }
+
+  int depth = 0;
+  for (; depth < kRmax; ++depth) {
+    const int level = level0 + depth;
+    if (level >= L) break;
+    // any element still active?
+    if (tid == 0) s_active = 0;
+    __syncthreads();
+    {
+      int a = 0;
+#pragma unroll
+      for (int e = 0; e < kE; ++e) a |= (id[e] >= 0 && dpath[e] == 0);
+      if (a) s_active = 1;
+    }
+    __syncthreads();
+    if (!s_active) break;
+
+    const int M = 1 << depth;
+    const int B = (kSmallCap / M) < 1024 ? (kSmallCap / M) : 1024;
+    const TK* Pl = Pt + (int64_t)level * N;
+    Keys<TK> K{Pt, N, level, nullptr};
+
+    // ---- a. keys ----
+    TK key[kE];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) key[e] = (id[e] >= 0 && dpath[e] == 0) ? Pl[id[e]] : (TK)0;
+
+    STAMP();  // keys issued
+    // ---- b. per-node min / max ----
+    if (tid < M) {
+      nmin[tid] = ~0ULL;
+      nmax[tid] = 0ULL;
+      nmaxL[tid] = 0ULL;
+      nminR[tid] = ~0ULL;
+      midcur[tid] = 0;
+    }
+    for (int i = tid; i < kSmallCap; i += kSubThreads) sx[i] = 0;
+    __syncthreads();
+    if (M <= 4) {  // few nodes: everybody would hit the same LDS word -> reduce per wave first
+      for (int j = 0; j < M; ++j) {
+        unsigned long long mn = ~0ULL, mx = 0ULL;
+#pragma unroll
+        for (int e = 0; e < kE; ++e)
+          if (id[e] >= 0 && dpath[e] == 0 && node[e] == j) {
+            const unsigned long long o = ord_of(key[e]);
+            mn = o < mn ? o : mn;
+            mx = o > mx ? o : mx;
+          }
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+          mn = a < mn ? a : mn;
+          mx = b > mx ? b : mx;
+        }
+        if (lane == 0) {
+          if (mn != ~0ULL) atomicMin(&nmin[j], mn);
+          if (mx != 0ULL) atomicMax(&nmax[j], mx);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < kE; ++e)
+        if (id[e] >= 0 && dpath[e] == 0) {
+          const unsigned long long o = ord_of(key[e]);
+          atomicMin(&nmin[node[e]], o);
+          atomicMax(&nmax[node[e]], o);
+        }
+    }
+    __syncthreads();
+    STAMP();  // minmax
+    // ---- c. bin geometry ----
+    if (tid < M) {
+      SubNode a;
+      a.n = sub_node_size(n_top, depth, tid);
+      a.nh = a.n >> 1;
+      a.pb = a.cL = a.cMid = 0;
+      a.lowb = -1;
+      a.highb = B;
+      a.midoff = 0;
+      sn[tid] = a;
+      if (nmin[tid] != ~0ULL) {
+        const TK lo = ord_to(nmin[tid], TK()), hi = ord_to(nmax[tid], TK());
+        nlo[tid] = lo;
+        nscale[tid] = lo < hi ? (TK)B / (hi - lo) : (TK)0;
+      } else {
+        nlo[tid] = (TK)0;
+        nscale[tid] = (TK)0;
+      }
+    }
+    __syncthreads();
+    // ---- d. histogram ----
+    int bin[kE];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      bin[e] = -1;
+      if (id[e] >= 0 && dpath[e] == 0) {
+        const int j = node[e];
+        int b = (int)((key[e] - nlo[j]) * nscale[j]);
+        b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
+        bin[e] = b;
+        atomicAdd(&sx[j * B + b], 1u);
+      }
+    }
+    __syncthreads();
+    STAMP();  // hist
+    // ---- e. pivot bin per node: one wave per node, wave scan over B bins ----
+    for (int j = wave; j < M; j += kSubThreads / 64) {
+      const int n = sn[j].n;
+      if (n <= 0) continue;
+      const unsigned int nh = (unsigned int)sn[j].nh;
+      const int per = (B + 63) / 64;
+      unsigned int loc = 0;
+      for (int i = 0; i < per; ++i) {
+        const int b = lane * per + i;
+        if (b < B) loc += sx[j * B + b];
+      }
+      unsigned int inc = loc;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      unsigned int run = inc - loc;  // elements in bins before this lane's range
+      int pb = -1, cL = 0, cMid = 0;
+      for (int i = 0; i < per; ++i) {
+        const int b = lane * per + i;
+        if (b < B) {
+          const unsigned int c = sx[j * B + b];
+          if (run <= nh && nh < run + c) {
+            pb = b;
+            cL = (int)run;
+            cMid = (int)c;
+          }
+          run += c;
+        }
+      }
+      // broadcast the owning lane's result
+      const unsigned long long own = __ballot(pb >= 0);
+      const int src_lane = __ffsll((long long)own) - 1;
+      pb = __shfl(pb, src_lane);
+      cL = __shfl(cL, src_lane);
+      cMid = __shfl(cMid, src_lane);
+      // nearest non-empty bins around the pivot bin (for margins outside the pivot bin)
+      int lowb = -1, highb = B;
+      for (int i = 0; i < per; ++i) {
+        const int b = lane * per + i;
+        if (b < B && sx[j * B + b]) {
+          if (b < pb) lowb = b > lowb ? b : lowb;
+          if (b > pb) highb = b < highb ? b : highb;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(lowb, o), b2 = __shfl_xor(highb, o);
+        lowb = a > lowb ? a : lowb;
+        highb = b2 < highb ? b2 : highb;
+      }
+      if (lane == 0) {
+        sn[j].pb = pb;
+        sn[j].cL = cL;
+        sn[j].cMid = cMid;
+        sn[j].lowb = lowb;
+        sn[j].highb = highb;
+      }
+    }
+    __syncthreads();
+    STAMP();  // pick
+    // ---- f. collect the pivot bins (mid pool in skey/sid), max(left bin) / min(right bin) ----
+    if (tid == 0) {
+      int run = 0;
+      for (int j = 0; j < M; ++j) {
+        sn[j].midoff = run;
+        run += sn[j].cMid;
+      }
+    }
+    __syncthreads();
+    int mpos[kE];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      mpos[e] = -1;
+      if (bin[e] >= 0) {
+        const int j = node[e];
+        if (bin[e] == sn[j].pb) {
+          const int p = sn[j].midoff + atomicAdd(&midcur[j], 1);
+          skey[p] = key[e];
+          sid[p] = id[e];
+          mpos[e] = p;
+        } else if (bin[e] == sn[j].lowb) {
+          atomicMax(&nmaxL[j], ord_of(key[e]));
+        } else if (bin[e] == sn[j].highb) {
+          atomicMin(&nminR[j], ord_of(key[e]));
+        }
+      }
+    }
+    __syncthreads();
+    STAMP();  // collect
+    // ---- g. exact rank inside the pivot bin; node outputs ----
+    int side[kE];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      side[e] = 0;
+      if (bin[e] < 0) continue;
+      const int j = node[e];
+      const SubNode a = sn[j];
+      if (mpos[e] < 0) {
+        side[e] = bin[e] > a.pb;
+        continue;
+      }
+      int rank = 0;
+      for (int q = a.midoff; q < a.midoff + a.cMid; ++q)
+        if (q != mpos[e] && K.less(skey[q], sid[q], key[e], id[e])) ++rank;
+      const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
+      if (rank == a.nh - a.cL) thr[h] = (double)key[e];
+      if (rank == il - a.cL) mglo[h] = (double)key[e];
+      if (rank == ih - a.cL) mghi[h] = (double)key[e];
+      side[e] = rank >= a.nh - a.cL;
+    }
+    __syncthreads();
+    if (tid < M && sn[tid].cMid > 0) {  // cMid == 0: phantom slot below a Tip
+      const SubNode a = sn[tid];
+      const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + tid);
+      if (il < a.cL) mglo[h] = (double)ord_to(nmaxL[tid], TK());
+      if (ih >= a.cL + a.cMid) mghi[h] = (double)ord_to(nminR[tid], TK());
+    }
+    STAMP();  // rank
+    // ---- h. descend ----
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      if (bin[e] < 0) continue;
+      const SubNode a = sn[node[e]];
+      const int child = 2 * node[e] + side[e];
+      const int nc = side[e] ? a.n - a.nh : a.nh;
+      if (level + 1 >= L || nc <= min_leaf) {  // the child is a Tip (Internal.hs:289)
+        dpath[e] = ((unsigned int)(child << (kRmax - (depth + 1))) << 8) | (unsigned int)(level + 1);
+        fkey[e] = key[e];
+      } else {
+        node[e] = child;
+      }
+    }
+    __syncthreads();
+    // ties straddling the cut (statistics): thr element equals its left neighbour
+    if (tid < M && sn[tid].n > 1 && sn[tid].cMid > 0) {
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + tid);
+      __threadfence_block();
+      if (!(mglo[h] < thr[h])) atomicAdd(tie_count, 1ULL);
+    }
+  }
+
+  // ---- final order ----
+  // 1. compact: every terminal node (leaf, or node still active after kRmax levels) becomes a
+  //    contiguous slot range at its topological offset; 2. every leaf bucket is sorted by
+  //    (retained key, earlier levels, id) inside ONE wave (<= 128 points: two per lane,
+  //    bitonic network over shuffles, no block barrier); buckets larger than that fall back
+  //    to a block-wide bitonic sort by (path, key, ...).
+  __syncthreads();
+  STAMP();  // levels done
+  __shared__ int tcur[1 << kRmax];
+  __shared__ int trec_off[1 << kRmax], trec_n[1 << kRmax];
+  __shared__ unsigned int trec_path[1 << kRmax];
+  __shared__ int nterm, need_block_sort;
+  if (tid < (1 << kRmax)) tcur[tid] = 0;
+  if (tid == 0) {
+    nterm = 0;
+    need_block_sort = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < kE; ++e) {
+    if (id[e] < 0) continue;
+    const bool done = dpath[e] != 0;
+    const int d = done ? (int)(dpath[e] & 255u) - level0 : depth;  // depth of the terminal
+    const unsigned int pth = done ? (dpath[e] >> 8) : (unsigned int)(node[e] << (kRmax - depth));
+    int toff = 0, tn = n_top;
+    for (int b = 0; b < d; ++b) {
+      const int nh = tn >> 1;
+      if ((pth >> (kRmax - 1 - b)) & 1u) {
+        toff += nh;
+        tn -= nh;
+      } else {
+        tn = nh;
+      }
+    }
+    const int c = atomicAdd(&tcur[pth], 1);
+    const int slot = toff + c;
+    skey[slot] = done ? fkey[e] : (TK)0;
+    sid[slot] = id[e];
+    sx[slot] = done ? dpath[e] : (pth << 8);
+    if (c == 0) {
+      const int r = atomicAdd(&nterm, 1);
+      trec_off[r] = toff;
+      trec_n[r] = tn;
+      trec_path[r] = done ? dpath[e] : 0u;
+      if (done && tn > 128) need_block_sort = 1;
+    }
+  }
+  __syncthreads();
+  if (!need_block_sort) {
+    for (int r = wave; r < nterm; r += kSubThreads / 64) {
+      const unsigned int pl = trec_path[r];
+      if (!(pl & 255u)) continue;  // still active: order is irrelevant
+      const int toff = trec_off[r], tn = trec_n[r];
+      const int lv = (int)(pl & 255u) - 1;
+      Keys<TK> K{Pt, N, lv, nullptr};
+      TK k0, k1;
+      int i0, i1;
+      {
+        const bool v0 = lane < tn, v1 = lane + 64 < tn;
+        k0 = v0 ? skey[toff + lane] : pos_inf<TK>();
+        i0 = v0 ? sid[toff + lane] : kPad;
+        k1 = v1 ? skey[toff + lane + 64] : pos_inf<TK>();
+        i1 = v1 ? sid[toff + lane + 64] : kPad;
+      }
+      const int npad = tn > 64 ? 128 : 64;
+      for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          if (j == 64) {  // partner = the other register of the same lane (index ^ 64)
+            const bool up = true;  // k == 128: (idx & 128) == 0 for every index
+            const bool one_lt_zero = K.less(k1, i1, k0, i0);
+            if (up ? one_lt_zero : !one_lt_zero) {
+              const TK tk = k0;
+              k0 = k1;
+              k1 = tk;
+              const int ti = i0;
+              i0 = i1;
+              i1 = ti;
+            }
+          } else {
+            {  // register 0: index = lane
+              const TK ok = __shfl_xor(k0, j);
+              const int oi = __shfl_xor(i0, j);
+              const bool up = (lane & k) == 0;
+              const bool lower = (lane & j) == 0;
+              const bool o_lt_me = K.less(ok, oi, k0, i0);
+              // lower keeps the min when ascending; upper keeps the max
+              const bool take = (lower == up) ? o_lt_me : !o_lt_me;
+              if (take) {
+                k0 = ok;
+                i0 = oi;
+              }
+            }
+            if (npad == 128) {  // register 1: index = 64 + lane
+              const TK ok = __shfl_xor(k1, j);
+              const int oi = __shfl_xor(i1, j);
+              const bool up = ((64 + lane) & k) == 0;
+              const bool lower = (lane & j) == 0;
+              const bool o_lt_me = K.less(ok, oi, k1, i1);
+              const bool take = (lower == up) ? o_lt_me : !o_lt_me;
+              if (take) {
+                k1 = ok;
+                i1 = oi;
+              }
+            }
+          }
+        }
+      }
+      if (lane < tn) sid[toff + lane] = i0;
+      if (lane + 64 < tn) sid[toff + lane + 64] = i1;
+    }
+    __syncthreads();
+  } else {
+  const int np = next_pow2(n_top);
+  for (int i = n_top + tid; i < np; i += kSubThreads) {
+    sx[i] = 0xffffffffu;
+    skey[i] = pos_inf<TK>();
+    sid[i] = kPad;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < (np >> 1); i += kSubThreads) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned int pl = sx[lo], ph = sx[hi];
+        const TK kl = skey[lo], kh = skey[hi];
+        const int il = sid[lo], ih = sid[hi];
+        bool h_lt_l;  // "hi entry precedes lo entry"
+        if (pl != ph) h_lt_l = ph < pl;
+        else if (kh < kl) h_lt_l = true;
+        else if (kl < kh) h_lt_l = false;
+        else {
+          // same bucket, equal retained key (the projection of level (pl & 255) - 1): the
+          // earlier levels decide, then the id
+          const int lv = (int)(pl & 255u) - 1;
+          Keys<TK> K{Pt, N, lv < 0 ? 0 : lv, nullptr};
+          h_lt_l = K.tie_less(ih, il);
+        }
+        // entries are distinct under the full order, so "lo precedes hi" == !h_lt_l
+        if (up ? h_lt_l : !h_lt_l) {
+          sx[lo] = ph;
+          sx[hi] = pl;
+          skey[lo] = kh;
+          skey[hi] = kl;
+          sid[lo] = ih;
+          sid[hi] = il;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  }
+  STAMP();  // sorted
+  int32_t* of = F + (int64_t)t * N + sg.off;
+  int32_t* on = nxt + (int64_t)t * N + sg.off;
+  for (int i = tid; i < n_top; i += kSubThreads) {
+    if (sx[i] & 255u) of[i] = sid[i];   // retired: final position
+    else on[i] = sid[i];                // still active: input of the next launch
+  }
+  STAMP();
+#undef STAMP
 }
 
 // copy segments src -> dst unchanged (leaves that are already in final order). grid=(S,T)
@@ -707,9 +1190,14 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   }
   hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, st, bufA.p, N, T);
 
-  int32_t* cur = bufA.p;
-  int32_t* nxt = bufB.p;
   int32_t* F = f->perm.p;
+  unsigned long long* dbgbuf = nullptr;
+  DevBuf<unsigned long long> dbgdev;
+  if (getenv("RPT_DEBUG_STAMPS")) {
+    RPT_TRY(dbgdev.alloc(256));
+    RPT_HIP(hipMemsetAsync(dbgdev.p, 0, 256 * 8, st));
+    dbgbuf = dbgdev.p;
+  }
   unsigned long long* tie_count = counters.p;
   unsigned int* big_count = reinterpret_cast<unsigned int*>(counters.p + 1);
 
@@ -720,146 +1208,153 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     return RPT_OK;
   };
 
+  // pending split nodes per level, each remembering which ping-pong buffer holds its points
+  struct PNode {
+    Seg seg;
+    int buf;
+  };
+  std::vector<std::vector<PNode>> pending((size_t)Lused + kRmax + 1);
+  int32_t* bufs[2] = {bufA.p, bufB.p};
+  if (!splits[0].empty()) pending[0].push_back(PNode{splits[0][0], 0});
+  // descendants of a node `depth` levels below it that are still split nodes
+  std::function<void(const Seg&, int, int, int, std::vector<Seg>&)> descend =
+      [&](const Seg& sgm, int level, int depth, int want, std::vector<Seg>& out) {
+        if (is_leaf(level, sgm.n, L, f->min_leaf)) return;
+        if (depth == want) {
+          out.push_back(sgm);
+          return;
+        }
+        const int nh = sgm.n / 2;
+        descend(Seg{sgm.off, nh, 2 * sgm.heap + 1}, level + 1, depth + 1, want, out);
+        descend(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, level + 1, depth + 1, want, out);
+      };
+
   for (int level = 0; level < Lused; ++level) {
-    ProfScope ps(ctx, RPT_PROF_SPLIT);
-    std::vector<Seg> small, big;
-    for (const Seg& s : splits[(size_t)level]) (s.n > kSmallCap ? big : small).push_back(s);
-    // children of this level's split nodes that are leaves
-    const std::vector<Seg>& lv = leaves[(size_t)level + 1];
-    bool all_leaf = true;
-    if (level + 1 < Lused) all_leaf = splits[(size_t)level + 1].empty();
-    int32_t* dst = all_leaf ? F : nxt;
+    for (int b = 0; b < 2; ++b) {
+      std::vector<Seg> small, big;
+      for (const PNode& pn : pending[(size_t)level])
+        if (pn.buf == b) (pn.seg.n > kSmallCap ? big : small).push_back(pn.seg);
+      if (small.empty() && big.empty()) continue;
+      ProfScope ps(ctx, RPT_PROF_SPLIT);
+      int32_t* cur = bufs[b];
+      int32_t* nxt = bufs[1 - b];
 
-    if (!small.empty()) {
-      RPT_TRY(upload(small, dsegs));
-      int nmax = 0;
-      for (const Seg& s : small) nmax = s.n > nmax ? s.n : nmax;
-      const size_t smem = (size_t)next_pow2(nmax) * (sizeof(TK) + 4);
-      hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)small.size(), T), dim3(256), smem,
-                         st, cur, dst, N, P, L, level, dsegs.p, (const int32_t*)nullptr, f->thr.p,
-                         f->mglo.p, f->mghi.p, f->nodes, tie_count);
-    }
-    std::vector<Seg> big_leaf_children;  // leaves produced by the unstable big path
-    if (!big.empty()) {
-      RPT_TRY(upload(big, dsegs2));
-      const unsigned S = (unsigned)big.size();
-      int nmax = 0;
-      for (const Seg& s : big) nmax = s.n > nmax ? s.n : nmax;
-      const unsigned chunks = (unsigned)((nmax + kChunk - 1) / kChunk);
-      hipLaunchKernelGGL(sample_kernel<TK>, dim3(S, T), dim3(256), 0, st, cur, N, P, L, level,
-                         dsegs2.p, (int)S, bins.p);
-      hipLaunchKernelGGL(hist_kernel<TK>, dim3(chunks, S, T), dim3(256), 0, st, cur, N, P, L,
-                         level, dsegs2.p, (int)S, bins.p, Kst.p, hist.p);
-      hipLaunchKernelGGL(pick_kernel, dim3(S, T), dim3(256), 0, st, dsegs2.p, (int)S, hist.p,
-                         aux.p);
-      // the big path always scatters into nxt-like storage; if all children are leaves the
-      // leaf sort below moves them into F
-      int32_t* bdst = nxt;
-      hipLaunchKernelGGL(scatter_kernel<TK>, dim3(chunks, S, T), dim3(256), 0, st, cur, bdst, N,
-                         dsegs2.p, (int)S, bins.p, Kst.p, aux.p);
-      RPT_HIP(hipMemsetAsync(bigflags.p, 0, (size_t)T * S * 4, st));
-      RPT_HIP(hipMemsetAsync(big_count, 0, 4, st));
-      const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
-      hipLaunchKernelGGL(mid_kernel<TK>, dim3(S, T), dim3(256), smem, st, bdst, N, P, L, level,
-                         dsegs2.p, (int)S, aux.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
-                         tie_count, bigflags.p, big_count);
-      RPT_HIP(hipGetLastError());
-      unsigned int nbig = 0;
-      RPT_HIP(hipMemcpyAsync(&nbig, big_count, 4, hipMemcpyDeviceToHost, st));
-      RPT_HIP(hipStreamSynchronize(st));
-      if (nbig) {  // rare: pivot bins larger than LDS -> HBM merge sort of those bins
-        std::vector<unsigned int> flags((size_t)T * S);
-        std::vector<NodeAux> haux((size_t)T * S);
-        RPT_HIP(hipMemcpy(flags.data(), bigflags.p, flags.size() * 4, hipMemcpyDeviceToHost));
-        RPT_HIP(hipMemcpy(haux.data(), aux.p, haux.size() * sizeof(NodeAux),
-                          hipMemcpyDeviceToHost));
-        std::vector<GSeg> gl;
-        std::vector<int> gidx;
-        for (int t = 0; t < T; ++t)
-          for (unsigned s = 0; s < S; ++s)
-            if (flags[(size_t)t * S + s]) {
-              const NodeAux& a = haux[(size_t)t * S + s];
-              const Seg& sg = big[s];
-              const int n = sg.n, nh = n / 2;
-              const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
-              GSeg g;
-              g.off = (int64_t)t * N + sg.off + a.cL;
-              g.n = a.cMid;
-              g.t = t;
-              g.heap = sg.heap;
-              g.nh_rel = nh - a.cL;
-              g.il_rel = il >= a.cL ? il - a.cL : -1;
-              g.ih_rel = ih < a.cL + a.cMid ? ih - a.cL : -1;
-              gl.push_back(g);
-              gidx.push_back(t * (int)S + (int)s);
-            }
-        f->big_mid_nodes += (int64_t)gl.size();
-        RPT_TRY(gsort<TK>(ctx, bdst, cur /*scratch: cur is dead for these nodes*/, N, P, L,
-                          level, gl, dglist, nullptr));
-        DevBuf<int> didx;
-        RPT_TRY(didx.alloc(gidx.size()));
-        RPT_HIP(hipMemcpy(didx.p, gidx.data(), gidx.size() * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(gsort_emit_kernel<TK>, dim3((unsigned)((gl.size() + 63) / 64)),
-                           dim3(64), 0, st, bdst, N, P, L, level, dglist.p, (int)gl.size(), aux.p,
-                           didx.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
-        RPT_HIP(hipStreamSynchronize(st));
+      if (!small.empty()) {  // whole subtrees in LDS, kRmax levels per launch
+        RPT_TRY(upload(small, dsegs));
+        hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)small.size(), T), dim3(kSubThreads), 0, st,
+                           cur, nxt, F, N, P, L, level, f->min_leaf, dsegs.p, f->thr.p, f->mglo.p,
+                           f->mghi.p, f->nodes, tie_count, dbgbuf);
+        if (level + kRmax < Lused) {
+          std::vector<Seg> rest;
+          for (const Seg& sgm : small) descend(sgm, level, 0, kRmax, rest);
+          for (const Seg& sgm : rest) pending[(size_t)level + kRmax].push_back(PNode{sgm, 1 - b});
+        }
       }
-      // leaf children of big nodes need their final (sorted) order
-      for (const Seg& s : big) {
-        const int nh = s.n / 2;
-        if (is_leaf(level + 1, nh, L, f->min_leaf))
-          big_leaf_children.push_back(Seg{s.off, nh, -1});
-        if (is_leaf(level + 1, s.n - nh, L, f->min_leaf))
-          big_leaf_children.push_back(Seg{s.off + nh, s.n - nh, -1});
-      }
-    }
-
-    // ---- finalize the leaves created at this level ----
-    if (!big_leaf_children.empty()) {
-      int32_t* bsrc = nxt;
-      std::vector<Seg> lsmall;
-      std::vector<GSeg> lbig;
-      for (const Seg& s : big_leaf_children) {
-        if (s.n <= kSmallCap) lsmall.push_back(s);
-        else
-          for (int t = 0; t < T; ++t)
-            lbig.push_back(GSeg{(int64_t)t * N + s.off, s.n, t, -1, -1, -1, -1});
-      }
-      if (!lsmall.empty()) {
-        RPT_TRY(upload(lsmall, dsegs));
+      if (!big.empty()) {
+        RPT_TRY(upload(big, dsegs2));
+        const unsigned S = (unsigned)big.size();
         int nmax = 0;
-        for (const Seg& s : lsmall) nmax = s.n > nmax ? s.n : nmax;
-        const size_t smem = (size_t)next_pow2(nmax) * (sizeof(TK) + 4);
-        hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)lsmall.size(), T), dim3(256),
-                           smem, st, bsrc, F, N, P, L, level, dsegs.p, (const int32_t*)nullptr,
-                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
+        for (const Seg& sgm : big) nmax = sgm.n > nmax ? sgm.n : nmax;
+        const unsigned chunks = (unsigned)((nmax + kChunk - 1) / kChunk);
+        hipLaunchKernelGGL(sample_kernel<TK>, dim3(S, T), dim3(256), 0, st, cur, N, P, L, level,
+                           dsegs2.p, (int)S, bins.p);
+        hipLaunchKernelGGL(hist_kernel<TK>, dim3(chunks, S, T), dim3(256), 0, st, cur, N, P, L,
+                           level, dsegs2.p, (int)S, bins.p, Kst.p, hist.p);
+        hipLaunchKernelGGL(pick_kernel, dim3(S, T), dim3(256), 0, st, dsegs2.p, (int)S, hist.p,
+                           aux.p);
+        hipLaunchKernelGGL(scatter_kernel<TK>, dim3(chunks, S, T), dim3(256), 0, st, cur, nxt, N,
+                           dsegs2.p, (int)S, bins.p, Kst.p, aux.p);
+        RPT_HIP(hipMemsetAsync(bigflags.p, 0, (size_t)T * S * 4, st));
+        RPT_HIP(hipMemsetAsync(big_count, 0, 4, st));
+        const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
+        hipLaunchKernelGGL(mid_kernel<TK>, dim3(S, T), dim3(256), smem, st, nxt, N, P, L, level,
+                           dsegs2.p, (int)S, aux.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
+                           tie_count, bigflags.p, big_count);
+        RPT_HIP(hipGetLastError());
+        unsigned int nbig = 0;
+        RPT_HIP(hipMemcpyAsync(&nbig, big_count, 4, hipMemcpyDeviceToHost, st));
+        RPT_HIP(hipStreamSynchronize(st));
+        if (nbig) {  // rare: pivot bins larger than LDS -> HBM merge sort of those bins
+          std::vector<unsigned int> flags((size_t)T * S);
+          std::vector<NodeAux> haux((size_t)T * S);
+          RPT_HIP(hipMemcpy(flags.data(), bigflags.p, flags.size() * 4, hipMemcpyDeviceToHost));
+          RPT_HIP(hipMemcpy(haux.data(), aux.p, haux.size() * sizeof(NodeAux),
+                            hipMemcpyDeviceToHost));
+          std::vector<GSeg> gl;
+          std::vector<int> gidx;
+          for (int t = 0; t < T; ++t)
+            for (unsigned sI = 0; sI < S; ++sI)
+              if (flags[(size_t)t * S + sI]) {
+                const NodeAux& a = haux[(size_t)t * S + sI];
+                const Seg& sgm = big[sI];
+                const int n = sgm.n, nh = n / 2;
+                const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
+                GSeg g;
+                g.off = (int64_t)t * N + sgm.off + a.cL;
+                g.n = a.cMid;
+                g.t = t;
+                g.heap = sgm.heap;
+                g.nh_rel = nh - a.cL;
+                g.il_rel = il >= a.cL ? il - a.cL : -1;
+                g.ih_rel = ih < a.cL + a.cMid ? ih - a.cL : -1;
+                gl.push_back(g);
+                gidx.push_back(t * (int)S + (int)sI);
+              }
+          f->big_mid_nodes += (int64_t)gl.size();
+          RPT_TRY(gsort<TK>(ctx, nxt, cur /*scratch: cur is dead for these nodes*/, N, P, L,
+                            level, gl, dglist, nullptr));
+          DevBuf<int> didx;
+          RPT_TRY(didx.alloc(gidx.size()));
+          RPT_HIP(hipMemcpy(didx.p, gidx.data(), gidx.size() * 4, hipMemcpyHostToDevice));
+          hipLaunchKernelGGL(gsort_emit_kernel<TK>, dim3((unsigned)((gl.size() + 63) / 64)),
+                             dim3(64), 0, st, nxt, N, P, L, level, dglist.p, (int)gl.size(),
+                             aux.p, didx.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
+          RPT_HIP(hipStreamSynchronize(st));
+        }
+        // children: leaves get their final (sorted) order now, the rest stays pending
+        std::vector<Seg> lsmall;
+        std::vector<GSeg> lbig;
+        std::vector<Seg> lbig_copy;
+        for (const Seg& sgm : big) {
+          const int nh = sgm.n / 2;
+          const Seg ch[2] = {Seg{sgm.off, nh, 2 * sgm.heap + 1},
+                             Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}};
+          for (const Seg& c : ch) {
+            if (!is_leaf(level + 1, c.n, L, f->min_leaf)) {
+              pending[(size_t)level + 1].push_back(PNode{c, 1 - b});
+            } else if (c.n <= kSmallCap) {
+              lsmall.push_back(Seg{c.off, c.n, -1});
+            } else {
+              lbig_copy.push_back(Seg{c.off, c.n, -1});
+              for (int t = 0; t < T; ++t)
+                lbig.push_back(GSeg{(int64_t)t * N + c.off, c.n, t, -1, -1, -1, -1});
+            }
+          }
+        }
+        if (!lsmall.empty()) {
+          RPT_TRY(upload(lsmall, dsegs));
+          int nm = 0;
+          for (const Seg& sgm : lsmall) nm = sgm.n > nm ? sgm.n : nm;
+          const size_t sm2 = (size_t)next_pow2(nm) * (sizeof(TK) + 4);
+          hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)lsmall.size(), T), dim3(256),
+                             sm2, st, nxt, F, N, P, L, level, dsegs.p, (const int32_t*)nullptr,
+                             f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
+        }
+        if (!lbig.empty()) {
+          RPT_TRY(gsort<TK>(ctx, nxt, cur, N, P, L, level, lbig, dglist, nullptr));
+          RPT_TRY(upload(lbig_copy, dsegs));
+          hipLaunchKernelGGL(copy_segs_kernel, dim3((unsigned)lbig_copy.size(), T), dim3(256), 0,
+                             st, nxt, F, N, dsegs.p);
+        }
       }
-      if (!lbig.empty()) {
-        RPT_TRY(gsort<TK>(ctx, bsrc, cur, N, P, L, level, lbig, dglist, nullptr));
-        std::vector<Seg> cp;
-        for (const Seg& s : big_leaf_children)
-          if (s.n > kSmallCap) cp.push_back(s);
-        RPT_TRY(upload(cp, dsegs));
-        hipLaunchKernelGGL(copy_segs_kernel, dim3((unsigned)cp.size(), T), dim3(256), 0, st, bsrc,
-                           F, N, dsegs.p);
-      }
+      RPT_HIP(hipGetLastError());
     }
-    if (!all_leaf && !lv.empty()) {
-      // leaf children of SMALL nodes are already in final order inside nxt: copy them to F
-      std::vector<Seg> cp;
-      for (const Seg& s : lv) {
-        bool from_big = false;
-        for (const Seg& b : big_leaf_children) from_big = from_big || b.off == s.off;
-        if (!from_big) cp.push_back(s);
-      }
-      if (!cp.empty()) {
-        RPT_TRY(upload(cp, dsegs));
-        hipLaunchKernelGGL(copy_segs_kernel, dim3((unsigned)cp.size(), T), dim3(256), 0, st, nxt,
-                           F, N, dsegs.p);
-      }
-    }
-    RPT_HIP(hipGetLastError());
-    std::swap(cur, nxt);
+  }
+  if (dbgbuf) {
+    unsigned long long hs[256];
+    RPT_HIP(hipStreamSynchronize(st));
+    RPT_HIP(hipMemcpy(hs, dbgbuf, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int i = 1; i < 256 && hs[i]; ++i) fprintf(stderr, "stamp %d: +%llu\n", i, hs[i] - hs[i - 1]);
   }
   unsigned long long ties = 0;
   RPT_HIP(hipMemcpyAsync(&ties, tie_count, 8, hipMemcpyDeviceToHost, st));
