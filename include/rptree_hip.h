@@ -77,6 +77,9 @@ int32_t rpt_device_count(int32_t* count);
 int32_t rpt_ctx_create(int32_t device, rpt_ctx** out);
 int32_t rpt_ctx_destroy(rpt_ctx* ctx);
 int32_t rpt_ctx_sync(rpt_ctx* ctx);
+/* device buffers released by the library are cached for reuse (multi-GB hipMalloc/hipFree per
+ * build is slow); rpt_ctx_trim returns the cache to the driver (rpt_ctx_destroy does too). */
+int32_t rpt_ctx_trim(rpt_ctx* ctx);
 /* the hipStream_t all work of this ctx is enqueued on (for HIP-event timing by the caller) */
 int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
 

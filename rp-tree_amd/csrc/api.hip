@@ -1,8 +1,11 @@
 // api.hip — C-ABI entry points (include/rptree_hip.h): contexts, datasets, topology,
 // forest accessors and the thin wrappers around the kernels in project/split/knn.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "common.h"
@@ -14,6 +17,113 @@ void set_error(const std::string& msg) { g_err = msg; }
 int32_t fail(int32_t code, const std::string& msg) {
   g_err = msg;
   return code;
+}
+
+// ---- caching device allocator ------------------------------------------------------------
+namespace {
+struct Block {
+  void* p;
+  size_t bytes;
+};
+std::mutex g_pool_mu;
+std::map<int, std::vector<Block>> g_pool_free;            // device -> cached blocks
+std::map<void*, std::pair<int, size_t>> g_pool_live;      // ptr -> (device, bytes)
+struct Pending {
+  void* p;
+  size_t bytes;
+  int dev;
+  hipStream_t stream;
+};
+std::vector<Pending> g_pool_pending;                      // freed, stream not yet synchronised
+thread_local hipStream_t tl_stream = nullptr;
+size_t round_bytes(size_t b) {
+  const size_t g = b >= ((size_t)1 << 20) ? ((size_t)2 << 20) : 256;
+  return (b + g - 1) / g * g;
+}
+}  // namespace
+
+static hipError_t dev_alloc_impl(void** p, size_t bytes);
+hipError_t dev_alloc(void** p, size_t bytes) {
+  if (getenv("RPT_NO_POOL")) return hipMalloc(p, bytes ? bytes : 1);
+  const hipError_t e = dev_alloc_impl(p, bytes);
+  if (e == hipSuccess) {
+    if (const char* ps = getenv("RPT_POOL_POISON")) {  // debugging aid: find uninitialised reads
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(*p, atoi(ps), bytes ? bytes : 1);
+      (void)hipDeviceSynchronize();
+    }
+  }
+  return e;
+}
+static hipError_t dev_alloc_impl(void** p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t want = round_bytes(bytes ? bytes : 1);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    std::vector<Block>& fl = g_pool_free[dev];
+    int best = -1;
+    for (int i = 0; i < (int)fl.size(); ++i)
+      if (fl[i].bytes >= want && fl[i].bytes <= want + want / 4 &&
+          (best < 0 || fl[i].bytes < fl[best].bytes))
+        best = i;
+    if (best >= 0) {
+      *p = fl[best].p;
+      g_pool_live[*p] = {dev, fl[best].bytes};
+      fl.erase(fl.begin() + best);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) {  // give the cache back to the driver and retry once
+    dev_trim();
+    e = hipMalloc(p, want);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[*p] = {dev, want};
+  }
+  return e;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool_live.find(p);
+  if (it == g_pool_live.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  g_pool_pending.push_back(Pending{p, it->second.second, it->second.first, tl_stream});
+  g_pool_live.erase(it);
+}
+
+void dev_set_stream(hipStream_t s) { tl_stream = s; }
+
+hipError_t stream_sync(hipStream_t s) {
+  const hipError_t e = hipStreamSynchronize(s);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_pool_pending.size();) {
+    if (g_pool_pending[i].stream == s) {
+      g_pool_free[g_pool_pending[i].dev].push_back(Block{g_pool_pending[i].p, g_pool_pending[i].bytes});
+      g_pool_pending[i] = g_pool_pending.back();
+      g_pool_pending.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  return e;
+}
+
+void dev_trim() {
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (Pending& q : g_pool_pending) (void)hipFree(q.p);
+  g_pool_pending.clear();
+  for (auto& kv : g_pool_free) {
+    for (Block& b : kv.second) (void)hipFree(b.p);
+    kv.second.clear();
+  }
 }
 
 void enumerate_topology(int64_t N, int32_t L, int32_t min_leaf, std::vector<Node>& out) {
@@ -85,25 +195,38 @@ int32_t rpt_ctx_create(int32_t device, rpt_ctx** out) {
 }
 
 int32_t rpt_ctx_destroy(rpt_ctx* ctx) {
+  if (ctx) dev_set_stream(ctx->stream);
   if (!ctx) return RPT_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) {
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_sync(ctx->stream);
     prof_resolve(ctx);
     (void)hipStreamDestroy(ctx->stream);
   }
+  dev_trim();
   delete ctx;
   return RPT_OK;
 }
 
 int32_t rpt_ctx_sync(rpt_ctx* ctx) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx, "ctx is NULL");
   RPT_HIP(hipSetDevice(ctx->device));
-  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
+  return RPT_OK;
+}
+
+int32_t rpt_ctx_trim(rpt_ctx* ctx) {
+  if (ctx) dev_set_stream(ctx->stream);
+  RPT_ARG(ctx, "ctx is NULL");
+  RPT_HIP(hipSetDevice(ctx->device));
+  RPT_HIP(stream_sync(ctx->stream));
+  dev_trim();
   return RPT_OK;
 }
 
 int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && hip_stream, "NULL argument");
   *hip_stream = (void*)ctx->stream;
   return RPT_OK;
@@ -125,12 +248,14 @@ static void prof_resolve(rpt_ctx* ctx) {
 }
 
 int32_t rpt_prof_enable(rpt_ctx* ctx, int32_t on) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx, "ctx is NULL");
   ctx->prof = on != 0;
   return RPT_OK;
 }
 
 int32_t rpt_prof_reset(rpt_ctx* ctx) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx, "ctx is NULL");
   RPT_HIP(hipSetDevice(ctx->device));
   prof_resolve(ctx);
@@ -142,10 +267,11 @@ int32_t rpt_prof_reset(rpt_ctx* ctx) {
 }
 
 int32_t rpt_prof_get(rpt_ctx* ctx, int32_t which, double* total_ms, int64_t* launches) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && total_ms && launches, "NULL argument");
   RPT_ARG(which >= 0 && which < RPT_PROF_CLASSES, "unknown kernel class");
   RPT_HIP(hipSetDevice(ctx->device));
-  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
   prof_resolve(ctx);
   *total_ms = ctx->prof_ms[which];
   *launches = ctx->prof_n[which];
@@ -160,6 +286,7 @@ static int32_t check_dtype(int32_t dt) {
 
 int32_t rpt_dataset_dense_host(rpt_ctx* ctx, const void* X_host, int64_t n, int32_t d,
                                int32_t dtype, rpt_dataset** out) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && out, "NULL argument");
   *out = nullptr;
   RPT_TRY(check_dtype(dtype));
@@ -175,16 +302,16 @@ int32_t rpt_dataset_dense_host(rpt_ctx* ctx, const void* X_host, int64_t n, int3
   ds->dtype = dtype;
   ds->owns = true;
   size_t bytes = (size_t)n * d * dtype_size(dtype);
-  hipError_t e = hipMalloc(&ds->X, bytes ? bytes : 16);
+  hipError_t e = dev_alloc(&ds->X, bytes ? bytes : 16);
   if (e != hipSuccess) {
     delete ds;
     return fail(RPT_E_NOMEM, std::string("hipMalloc dataset: ") + hipGetErrorString(e));
   }
   if (bytes) {
     e = hipMemcpyAsync(ds->X, X_host, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_sync(ctx->stream);
     if (e != hipSuccess) {
-      (void)hipFree(ds->X);
+      dev_free(ds->X);
       delete ds;
       return fail(RPT_E_HIP, std::string("H2D copy: ") + hipGetErrorString(e));
     }
@@ -195,6 +322,7 @@ int32_t rpt_dataset_dense_host(rpt_ctx* ctx, const void* X_host, int64_t n, int3
 
 int32_t rpt_dataset_dense_dev(rpt_ctx* ctx, const void* X_dev, int64_t n, int32_t d,
                               int32_t dtype, rpt_dataset** out) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && out, "NULL argument");
   *out = nullptr;
   RPT_TRY(check_dtype(dtype));
@@ -217,6 +345,7 @@ int32_t rpt_dataset_dense_dev(rpt_ctx* ctx, const void* X_dev, int64_t n, int32_
 int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int32_t* col_host,
                              const void* val_host, int64_t n, int32_t d, int32_t dtype,
                              rpt_dataset** out) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && out, "NULL argument");
   *out = nullptr;
   RPT_TRY(check_dtype(dtype));
@@ -245,9 +374,9 @@ int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int
   ds->owns = true;
   ds->nnz = nnz;
   size_t vb = (size_t)nnz * dtype_size(dtype);
-  hipError_t e = hipMalloc((void**)&ds->rowptr, (size_t)(n + 1) * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&ds->col, nnz ? (size_t)nnz * 4 : 16);
-  if (e == hipSuccess) e = hipMalloc(&ds->val, vb ? vb : 16);
+  hipError_t e = dev_alloc((void**)&ds->rowptr, (size_t)(n + 1) * 8);
+  if (e == hipSuccess) e = dev_alloc((void**)&ds->col, nnz ? (size_t)nnz * 4 : 16);
+  if (e == hipSuccess) e = dev_alloc(&ds->val, vb ? vb : 16);
   if (e == hipSuccess)
     e = hipMemcpyAsync(ds->rowptr, rowptr_host, (size_t)(n + 1) * 8, hipMemcpyHostToDevice,
                        ctx->stream);
@@ -255,7 +384,7 @@ int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int
     e = hipMemcpyAsync(ds->col, col_host, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz)
     e = hipMemcpyAsync(ds->val, val_host, vb, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = stream_sync(ctx->stream);
   if (e != hipSuccess) {
     rpt_dataset_free(ds);
     return fail(RPT_E_HIP, std::string("CSR upload: ") + hipGetErrorString(e));
@@ -265,13 +394,15 @@ int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int
 }
 
 int32_t rpt_dataset_free(rpt_dataset* ds) {
+  if (ds) dev_set_stream(ds->ctx->stream);
   if (!ds) return RPT_OK;
   if (ds->owns) {
     (void)hipSetDevice(ds->ctx->device);
-    if (ds->X) (void)hipFree(ds->X);
-    if (ds->rowptr) (void)hipFree(ds->rowptr);
-    if (ds->col) (void)hipFree(ds->col);
-    if (ds->val) (void)hipFree(ds->val);
+    (void)stream_sync(ds->ctx->stream);
+    if (ds->X) dev_free(ds->X);
+    if (ds->rowptr) dev_free(ds->rowptr);
+    if (ds->col) dev_free(ds->col);
+    if (ds->val) dev_free(ds->val);
   }
   delete ds;
   return RPT_OK;
@@ -313,25 +444,27 @@ static int32_t upload_R(rpt_ctx* ctx, const double* R_host, size_t count, DevBuf
   RPT_TRY(buf.alloc(count));
   if (count) {
     RPT_HIP(hipMemcpyAsync(buf.p, R_host, count * 8, hipMemcpyHostToDevice, ctx->stream));
-    RPT_HIP(hipStreamSynchronize(ctx->stream));
+    RPT_HIP(stream_sync(ctx->stream));
   }
   return RPT_OK;
 }
 
 int32_t rpt_project_dev(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,
                         int32_t mode, void* P_dev) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && ds && R_host && P_dev, "NULL argument");
   RPT_ARG(C >= 1, "C must be >= 1");
   RPT_HIP(hipSetDevice(ctx->device));
   DevBuf<double> Rd;
   RPT_TRY(upload_R(ctx, R_host, (size_t)C * ds->d, Rd));
   RPT_TRY(project_columns(ctx, ds, Rd.p, C, mode, P_dev));
-  RPT_HIP(hipStreamSynchronize(ctx->stream));  // Rd is released on return
+  RPT_HIP(stream_sync(ctx->stream));  // Rd is released on return
   return RPT_OK;
 }
 
 int32_t rpt_project_host(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,
                          int32_t mode, void* P_host) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && ds && R_host && P_host, "NULL argument");
   RPT_ARG(C >= 1, "C must be >= 1");
   RPT_HIP(hipSetDevice(ctx->device));
@@ -379,6 +512,7 @@ static int32_t forest_alloc(rpt_ctx* ctx, const rpt_dataset* ds, const double* R
 
 int32_t rpt_forest_build(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
                          int32_t L, int32_t min_leaf, int32_t flags, rpt_forest** out) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(out, "out is NULL");
   *out = nullptr;
   rpt_forest* f = nullptr;
@@ -396,6 +530,7 @@ int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_h
                           int32_t L, int32_t min_leaf, const int32_t* perm_host,
                           const double* thr_host, const double* mglo_host,
                           const double* mghi_host, rpt_forest** out) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(out, "out is NULL");
   *out = nullptr;
   RPT_ARG(perm_host && thr_host && mglo_host && mghi_host, "NULL argument");
@@ -421,9 +556,10 @@ int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_h
 }
 
 int32_t rpt_forest_free(rpt_forest* f) {
+  if (f) dev_set_stream(f->ctx->stream);
   if (!f) return RPT_OK;
   (void)hipSetDevice(f->ctx->device);
-  (void)hipStreamSynchronize(f->ctx->stream);
+  (void)stream_sync(f->ctx->stream);
   delete f;
   return RPT_OK;
 }
@@ -440,9 +576,10 @@ int32_t rpt_forest_info(const rpt_forest* f, int64_t* n, int32_t* d, int32_t* T,
 }
 
 int32_t rpt_forest_get_perm(rpt_forest* f, int32_t* perm_host) {
+  if (f) dev_set_stream(f->ctx->stream);
   RPT_ARG(f && perm_host, "NULL argument");
   RPT_HIP(hipSetDevice(f->ctx->device));
-  RPT_HIP(hipStreamSynchronize(f->ctx->stream));
+  RPT_HIP(stream_sync(f->ctx->stream));
   if (f->n)
     RPT_HIP(hipMemcpy(perm_host, f->perm.p, (size_t)f->T * f->n * 4, hipMemcpyDeviceToHost));
   return RPT_OK;
@@ -450,9 +587,10 @@ int32_t rpt_forest_get_perm(rpt_forest* f, int32_t* perm_host) {
 
 int32_t rpt_forest_get_nodes(rpt_forest* f, double* thr_host, double* mglo_host,
                              double* mghi_host) {
+  if (f) dev_set_stream(f->ctx->stream);
   RPT_ARG(f && thr_host && mglo_host && mghi_host, "NULL argument");
   RPT_HIP(hipSetDevice(f->ctx->device));
-  RPT_HIP(hipStreamSynchronize(f->ctx->stream));
+  RPT_HIP(stream_sync(f->ctx->stream));
   size_t nb = (size_t)f->T * f->nodes * 8;
   if (nb) {
     RPT_HIP(hipMemcpy(thr_host, f->thr.p, nb, hipMemcpyDeviceToHost));
@@ -463,10 +601,11 @@ int32_t rpt_forest_get_nodes(rpt_forest* f, double* thr_host, double* mglo_host,
 }
 
 int32_t rpt_forest_get_proj(rpt_forest* f, void* proj_host) {
+  if (f) dev_set_stream(f->ctx->stream);
   RPT_ARG(f && proj_host, "NULL argument");
   RPT_ARG(f->proj.p, "this forest holds no projections (imported forest)");
   RPT_HIP(hipSetDevice(f->ctx->device));
-  RPT_HIP(hipStreamSynchronize(f->ctx->stream));
+  RPT_HIP(stream_sync(f->ctx->stream));
   size_t nb = (size_t)f->T * f->L * f->n * dtype_size(f->pdtype);
   if (nb) RPT_HIP(hipMemcpy(proj_host, f->proj.p, nb, hipMemcpyDeviceToHost));
   return RPT_OK;
@@ -482,6 +621,7 @@ int32_t rpt_forest_stats(rpt_forest* f, int64_t* tie_nodes, int64_t* big_mid_nod
 int32_t rpt_split_segments(rpt_ctx* ctx, const double* key_host, int64_t n,
                            int32_t* perm_io_host, const int64_t* seg_off_host,
                            const int64_t* seg_len_host, int32_t S, double* thr_mg_host) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && key_host && perm_io_host && seg_off_host && seg_len_host && thr_mg_host,
           "NULL argument");
   RPT_ARG(n >= 1 && S >= 1, "n and S must be >= 1");
@@ -501,6 +641,7 @@ static int32_t check_query(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q) {
 
 int32_t rpt_candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* queries,
                        int64_t* off_host, int32_t* ids_host, int64_t cap, int64_t* total) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_TRY(check_query(ctx, f, queries));
   RPT_ARG(total, "total is NULL");
   return candidates(ctx, f, queries, off_host, ids_host, cap, total);
@@ -509,6 +650,7 @@ int32_t rpt_candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* queries,
 int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                     const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_dev,
                     double* dist_dev, int32_t* count_dev) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_TRY(check_query(ctx, f, queries));
   RPT_ARG(data && data->ctx == ctx, "bad data handle");
   RPT_ARG(data->n == f->n && data->d == f->d, "data shape differs from the forest's");
@@ -521,6 +663,7 @@ int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
 int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                      const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_host,
                      double* dist_host, int32_t* count_host) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_TRY(check_query(ctx, f, queries));
   RPT_ARG(ids_host && dist_host && count_host, "NULL output");
   RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
@@ -531,7 +674,7 @@ int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
   RPT_TRY(dist.alloc((size_t)nq * k));
   RPT_TRY(cnt.alloc((size_t)nq));
   RPT_TRY(rpt_knn_dev(ctx, f, data, queries, k, flags, ids.p, dist.p, cnt.p));
-  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
   if (nq) {
     RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
     RPT_HIP(hipMemcpy(dist_host, dist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
@@ -541,6 +684,7 @@ int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
 }
 
 int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && total, "NULL argument");
   *total = ctx->last_candidates;
   return RPT_OK;
@@ -550,6 +694,7 @@ int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* di
                           const int32_t* count_dev, int32_t G, int64_t nq, int32_t k,
                           int32_t flags, int32_t* out_ids_dev, double* out_dist_dev,
                           int32_t* out_count_dev) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && ids_dev && dist_dev && count_dev && out_ids_dev && out_dist_dev &&
               out_count_dev,
           "NULL argument");
@@ -562,6 +707,7 @@ int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* di
 
 int32_t rpt_brute_knn_host(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* queries,
                            int32_t k, int32_t* ids_host, double* dist_host) {
+  if (ctx) dev_set_stream(ctx->stream);
   RPT_ARG(ctx && data && queries && ids_host && dist_host, "NULL argument");
   RPT_ARG(data->ctx == ctx && queries->ctx == ctx, "handles belong to another context");
   RPT_ARG(!data->csr && !queries->csr, "brute-force kNN supports dense data only");

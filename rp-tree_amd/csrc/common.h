@@ -58,6 +58,19 @@ inline size_t dtype_size(int32_t dt) { return dt == RPT_F64 ? 8 : dt == RPT_F32 
 // compute/projection type: double for f64 data, float otherwise
 inline int32_t proj_dtype(int32_t dt) { return dt == RPT_F64 ? RPT_F64 : RPT_F32; }
 
+// Caching device allocator (api.hip).  Multi-GB hipMalloc/hipFree per forest build cost
+// milliseconds and occasionally ~100 ms (driver map/unmap); freed blocks are therefore kept
+// per device and handed out again (best fit within 25 %).  All work of a context is ordered
+// on its stream and every entry point that releases buffers synchronises that stream first,
+// so reuse is safe.  rpt_ctx_trim / rpt_ctx_destroy return the cache to the driver.
+// A freed block becomes reusable only after the stream that was current when it was freed has
+// been synchronised (stream_sync): kernels still in flight may be reading it.
+hipError_t dev_alloc(void** p, size_t bytes);
+void dev_free(void* p);
+void dev_trim();
+void dev_set_stream(hipStream_t s);          // stream of the calling thread's current entry point
+hipError_t stream_sync(hipStream_t s);       // hipStreamSynchronize + release blocks freed on s
+
 // simple owned device buffer
 template <class T>
 struct DevBuf {
@@ -68,14 +81,14 @@ struct DevBuf {
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_free(p);
     p = nullptr;
     count = 0;
   }
   int32_t alloc(size_t n) {
     release();
     if (n == 0) n = 1;
-    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    hipError_t e = dev_alloc((void**)&p, n * sizeof(T));
     if (e != hipSuccess)
       return fail(RPT_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
     count = n;

@@ -474,7 +474,7 @@ int32_t make_plan_t(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, QueryPlan
   int64_t tot[2];
   RPT_HIP(hipMemcpyAsync(&tot[0], pl.cand_off.p + m, 8, hipMemcpyDeviceToHost, st));
   RPT_HIP(hipMemcpyAsync(&tot[1], pl.rng_off.p + m, 8, hipMemcpyDeviceToHost, st));
-  RPT_HIP(hipStreamSynchronize(st));
+  RPT_HIP(stream_sync(st));
   pl.total_cand = tot[0];
   pl.total_rng = tot[1];
   RPT_TRY(pl.ranges.alloc((size_t)pl.total_rng));
@@ -513,7 +513,7 @@ int32_t candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, int64_t* o
     hipLaunchKernelGGL(expand_kernel, dim3((unsigned)q->n), dim3(128), 0, ctx->stream,
                        f->perm.p, pl.ranges.p, pl.rng_off.p, pl.cand_off.p, f->T, ids.p);
     RPT_HIP(hipGetLastError());
-    RPT_HIP(hipStreamSynchronize(ctx->stream));
+    RPT_HIP(stream_sync(ctx->stream));
     RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)pl.total_cand * 4, hipMemcpyDeviceToHost));
   }
   return RPT_OK;
@@ -577,7 +577,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     RPT_TRY(launch_topk_dense<__hip_bfloat16>(ctx, data, q, f->perm.p, pl.ranges.p, pl.rng_off.p,
                                               f->T, 0, k, dedup, ids_dev, dist_dev, count_dev));
   }
-  RPT_HIP(hipStreamSynchronize(ctx->stream));  // the plan's buffers are released on return
+  RPT_HIP(stream_sync(ctx->stream));  // the plan's buffers are released on return
   return RPT_OK;
 }
 
@@ -617,7 +617,7 @@ int32_t brute_knn(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* q, i
   else
     RPT_TRY(launch_topk_dense<__hip_bfloat16>(ctx, data, q, nullptr, nullptr, nullptr, 1, 1, k, 0,
                                               ids.p, dist.p, cnt.p));
-  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
   RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
   RPT_HIP(hipMemcpy(dist_host, dist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
   return RPT_OK;

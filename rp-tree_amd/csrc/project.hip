@@ -529,7 +529,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                            ctx->stream, (const TIn*)ds->X, n, Ab, c0, ncol, P, n, ntiles);
     }
     RPT_HIP(hipGetLastError());
-    RPT_HIP(hipStreamSynchronize(ctx->stream));  // Apad is released on return
+    RPT_HIP(stream_sync(ctx->stream));  // Apad is released on return
     return RPT_OK;
   }
   constexpr int WAVES = 4;
@@ -588,7 +588,7 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
                          P + (int64_t)c0 * n, n, ncol);
   }
   RPT_HIP(hipGetLastError());
-  RPT_HIP(hipStreamSynchronize(ctx->stream));  // Rt is freed on return
+  RPT_HIP(stream_sync(ctx->stream));  // Rt is freed on return
   return RPT_OK;
 }
 
@@ -611,7 +611,7 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
                        P + (int64_t)c0 * n, n, ncol);
   }
   RPT_HIP(hipGetLastError());
-  RPT_HIP(hipStreamSynchronize(ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
   return RPT_OK;
 }
 

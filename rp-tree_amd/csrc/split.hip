@@ -26,6 +26,7 @@
 //
 // Algorithmic HBM bytes per point per tree per level (SURVEY.md §8d lower bound: 16):
 //   big path: perm 4 + key gather 8 + key stash 8+8 + perm 4+4 = 36; small path: 4 + 8 + 4.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -117,6 +118,10 @@ __device__ void lds_bitonic(TK* skey, int* sid, int np, const Keys<TK>& K) {
   }
 }
 
+__device__ inline bool is_leaf_dev(int level, int n, int L, int min_leaf) {
+  return level >= L || n <= min_leaf;
+}
+
 __host__ __device__ inline int next_pow2(int n) {
   int p = 1;
   while (p < n) p <<= 1;
@@ -129,6 +134,61 @@ template <>
 __device__ inline double pos_inf<double>() { return __longlong_as_double(0x7ff0000000000000LL); }
 template <>
 __device__ inline float pos_inf<float>() { return __uint_as_float(0x7f800000u); }
+
+// Bitonic sort of NR*64 (key, id) pairs held NR per lane (index = r*64 + lane) by one wave:
+// partners at distance >= 64 are other registers of the same lane, closer partners come
+// through lane shuffles.  No LDS, no barrier.
+template <class TK, int NR, int KK, int J>
+__device__ inline void wave_bitonic_stage(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K, int lane) {
+  if constexpr (J >= 64) {
+    constexpr int JR = J >> 6;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      if ((r & JR) == 0) {
+        const int r2 = r + JR;
+        const bool up = ((r * 64) & KK) == 0;  // KK >= 128: the direction bit lives in r
+        const bool hi_lt_lo = K.less(k[r2], id[r2], k[r], id[r]);
+        if (up ? hi_lt_lo : !hi_lt_lo) {
+          const TK tk = k[r];
+          k[r] = k[r2];
+          k[r2] = tk;
+          const int ti = id[r];
+          id[r] = id[r2];
+          id[r2] = ti;
+        }
+      }
+    }
+  } else {
+    const bool lower = (lane & J) == 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      TK ok = __shfl_xor(k[r], J);
+      int oi = __shfl_xor(id[r], J);
+      // pin the exchanged values here: the id is only consumed on key ties, and a cross-lane
+      // read must never be sunk into that divergent branch (lanes outside it would not
+      // take part in the exchange)
+      asm volatile("" : "+v"(ok), "+v"(oi));
+      const bool up = ((r * 64 + lane) & KK) == 0;
+      const bool o_lt_me = K.less(ok, oi, k[r], id[r]);
+      if ((lower == up) ? o_lt_me : !o_lt_me) {
+        k[r] = ok;
+        id[r] = oi;
+      }
+    }
+  }
+  if constexpr (J > 1) wave_bitonic_stage<TK, NR, KK, (J >> 1)>(k, id, K, lane);
+}
+
+template <class TK, int NR, int KK>
+__device__ inline void wave_bitonic_phase(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K, int lane) {
+  wave_bitonic_stage<TK, NR, KK, (KK >> 1)>(k, id, K, lane);
+  if constexpr (KK < 64 * NR) wave_bitonic_phase<TK, NR, (KK << 1)>(k, id, K, lane);
+}
+
+template <class TK, int NR>
+__device__ inline void wave_bitonic(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K) {
+  wave_bitonic_phase<TK, NR, 2>(k, id, K, threadIdx.x & 63);
+}
 
 // ---------------------------------------------------------------------------------------
 // small path: sort one segment per block.  grid = (S, T).
@@ -654,6 +714,376 @@ __global__ __launch_bounds__(kSubThreads) void subtree_kernel(
 #undef STAMP
 }
 
+// ---------------------------------------------------------------------------------------
+// wave-centric subtree kernel: ONE WAVE per (tree, top node with n <= kWCap).  Same select as
+// subtree_kernel (per level: min/max, value histogram, pivot bin, exact resolution of the
+// pivot bin; no element ever moves) but without a single workgroup barrier: all state lives
+// in the wave's registers (16 points per lane) and a wave-private LDS slab, so a CU runs many
+// independent subtrees at once and their latencies overlap.
+// Output: every point is scattered to the slot range of its terminal node — a leaf (final
+// perm F, UNORDERED, with the key of the leaf's parent level in Kleaf) or a node still active
+// after kWRmax levels (nxt).  leaf_sort_kernel then orders every leaf bucket.
+// A wave that meets a pivot bin larger than its LDS slab flags the node and writes nothing;
+// the host re-runs those nodes with subtree_kernel.
+// grid = ceil(S*T/4) blocks of 256 threads.
+// ---------------------------------------------------------------------------------------
+constexpr int kWCap = 1024;
+constexpr int kWE = kWCap / 64;   // points per lane
+constexpr int kWRmax = 5;         // levels per launch (<= 16 nodes at the deepest depth)
+constexpr int kWHist = 1024;      // histogram entries per wave
+constexpr int kWMid = 192;        // pivot-bin pool per wave
+
+struct WSlab {
+  unsigned int hist[kWHist];
+  unsigned long long nmin[16], nmax[16], nmaxL[16], nminR[16];
+  double nlo[16], nscale[16];
+  SubNode sn[16];
+  int midcur[16];
+  double midkey[kWMid];
+  int midid[kWMid];
+  int toff[32], tcur[32];
+  double vthr[16], vlo[16];
+};
+
+__device__ inline void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class TK>
+__global__ __launch_bounds__(256) void wsub_kernel(
+    const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
+    TK* __restrict__ Kleaf, int64_t N, const TK* __restrict__ P, int L, int T, int level0,
+    int min_leaf, const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
+    int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
+    unsigned int* ovf_count) {
+  __shared__ WSlab slabs[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
+  if (wg >= (int64_t)S * T) return;
+  const int si = (int)(wg % S), t = (int)(wg / S);
+  WSlab& W = slabs[wave];
+  const Seg sg = segs[si];
+  const int n_top = sg.n;
+  if (n_top <= 0) return;
+  const TK* Pt = P + (int64_t)t * L * N;
+  const int32_t* s = src + (int64_t)t * N + sg.off;
+
+  int id[kWE];
+  TK key[kWE];   // key of the current level; frozen at the level a point retires
+  int st[kWE];   // active: node index (>= 0); retired: -(((left-aligned path) << 8) | leaf level)
+#pragma unroll
+  for (int e = 0; e < kWE; ++e) {
+    const int pos = e * 64 + lane;
+    id[e] = pos < n_top ? s[pos] : -1;
+    st[e] = 0;
+    key[e] = (TK)0;
+  }
+
+  int depth = 0;
+  bool overflow = false;
+  for (; depth < kWRmax; ++depth) {
+    const int level = level0 + depth;
+    if (level >= L) break;
+    int act = 0;
+#pragma unroll
+    for (int e = 0; e < kWE; ++e) act |= (id[e] >= 0 && st[e] >= 0);
+    if (!__any(act)) break;
+
+    const int M = 1 << depth;
+    const int B = kWHist / M;
+    Keys<TK> K{Pt, N, level, nullptr};
+    // ---- a. keys ----
+    {
+      const TK* Pl = Pt + (int64_t)level * N;
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0) key[e] = Pl[id[e]];
+    }
+    // ---- b. per-node min / max ----
+    if (lane < M) {
+      W.nmin[lane] = ~0ULL;
+      W.nmax[lane] = 0ULL;
+      W.nmaxL[lane] = 0ULL;
+      W.nminR[lane] = ~0ULL;
+      W.midcur[lane] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < kWHist / 64; ++i) W.hist[i * 64 + lane] = 0;
+    wsync();
+    if (M == 1) {
+      unsigned long long mn = ~0ULL, mx = 0ULL;
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0) {
+          const unsigned long long o = ord_of(key[e]);
+          mn = o < mn ? o : mn;
+          mx = o > mx ? o : mx;
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+      }
+      if (lane == 0) {
+        W.nmin[0] = mn;
+        W.nmax[0] = mx;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0) {
+          const unsigned long long o = ord_of(key[e]);
+          atomicMin(&W.nmin[st[e]], o);
+          atomicMax(&W.nmax[st[e]], o);
+        }
+    }
+    wsync();
+    // ---- c. bin geometry ----
+    if (lane < M) {
+      SubNode a;
+      a.n = sub_node_size(n_top, depth, lane);
+      a.nh = a.n >> 1;
+      a.pb = -1;
+      a.cL = a.cMid = 0;
+      a.lowb = -1;
+      a.highb = B;
+      a.midoff = 0;
+      W.sn[lane] = a;
+      if (W.nmin[lane] != ~0ULL) {
+        const TK lo = ord_to(W.nmin[lane], TK()), hi = ord_to(W.nmax[lane], TK());
+        W.nlo[lane] = (double)lo;
+        W.nscale[lane] = lo < hi ? (double)((TK)B / (hi - lo)) : 0.0;
+      } else {
+        W.nlo[lane] = 0.0;
+        W.nscale[lane] = 0.0;
+      }
+    }
+    wsync();
+    auto bin_of_e = [&](TK k, int j) {
+      int b = (int)((k - (TK)W.nlo[j]) * (TK)W.nscale[j]);
+      return b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
+    };
+    // ---- d. histogram ----
+#pragma unroll
+    for (int e = 0; e < kWE; ++e)
+      if (id[e] >= 0 && st[e] >= 0) atomicAdd(&W.hist[st[e] * B + bin_of_e(key[e], st[e])], 1u);
+    wsync();
+    // ---- e. pivot bin per node (the whole wave scans one node at a time) ----
+    for (int j = 0; j < M; ++j) {
+      if (W.sn[j].n <= 0) continue;
+      const unsigned int nh = (unsigned int)W.sn[j].nh;
+      const int per = B / 64;  // B >= 64
+      unsigned int loc = 0;
+      for (int i = 0; i < per; ++i) loc += W.hist[j * B + lane * per + i];
+      unsigned int inc = loc;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      unsigned int run = inc - loc;
+      int pb = -1, cL = 0, cMid = 0, lowb = -1, highb = B;
+      for (int i = 0; i < per; ++i) {
+        const int b = lane * per + i;
+        const unsigned int c = W.hist[j * B + b];
+        if (run <= nh && nh < run + c) {
+          pb = b;
+          cL = (int)run;
+          cMid = (int)c;
+        }
+        run += c;
+      }
+      const unsigned long long own = __ballot(pb >= 0);
+      if (!own) continue;  // phantom slot below a Tip
+      const int src_lane = __ffsll((long long)own) - 1;
+      pb = __shfl(pb, src_lane);
+      cL = __shfl(cL, src_lane);
+      cMid = __shfl(cMid, src_lane);
+      for (int i = 0; i < per; ++i) {
+        const int b = lane * per + i;
+        if (W.hist[j * B + b]) {
+          if (b < pb) lowb = b > lowb ? b : lowb;
+          if (b > pb) highb = b < highb ? b : highb;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const int x = __shfl_xor(lowb, o), y = __shfl_xor(highb, o);
+        lowb = x > lowb ? x : lowb;
+        highb = y < highb ? y : highb;
+      }
+      if (lane == 0) {
+        W.sn[j].pb = pb;
+        W.sn[j].cL = cL;
+        W.sn[j].cMid = cMid;
+        W.sn[j].lowb = lowb;
+        W.sn[j].highb = highb;
+      }
+    }
+    wsync();
+    // ---- f. pool the pivot bins ----
+    int tot = 0;
+    if (lane == 0) {
+      for (int j = 0; j < M; ++j) {
+        W.sn[j].midoff = tot;
+        tot += W.sn[j].cMid;
+      }
+    }
+    tot = __shfl(tot, 0);
+    if (tot > kWMid) {
+      overflow = true;
+      break;
+    }
+    wsync();
+#pragma unroll
+    for (int e = 0; e < kWE; ++e) {
+      if (id[e] < 0 || st[e] < 0) continue;
+      const int j = st[e];
+      const int b = bin_of_e(key[e], j);
+      if (b == W.sn[j].pb) {
+        const int p = W.sn[j].midoff + atomicAdd(&W.midcur[j], 1);
+        W.midkey[p] = (double)key[e];
+        W.midid[p] = id[e];
+      } else if (b == W.sn[j].lowb) {
+        atomicMax(&W.nmaxL[j], ord_of(key[e]));
+      } else if (b == W.sn[j].highb) {
+        atomicMin(&W.nminR[j], ord_of(key[e]));
+      }
+    }
+    wsync();
+    // ---- g. exact rank inside the pivot bin, node outputs, h. descend ----
+#pragma unroll
+    for (int e = 0; e < kWE; ++e) {
+      if (id[e] < 0 || st[e] < 0) continue;
+      const int j = st[e];
+      const SubNode a = W.sn[j];
+      const int b = bin_of_e(key[e], j);
+      int side = b > a.pb;
+      if (b == a.pb) {
+        int rank = 0;
+        for (int q = a.midoff; q < a.midoff + a.cMid; ++q)
+          if (W.midid[q] != id[e] && K.less((TK)W.midkey[q], W.midid[q], key[e], id[e])) ++rank;
+        const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+        const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
+        if (rank == a.nh - a.cL) {
+          thr[h] = (double)key[e];
+          W.vthr[j] = (double)key[e];
+        }
+        if (rank == il - a.cL) {
+          mglo[h] = (double)key[e];
+          W.vlo[j] = (double)key[e];
+        }
+        if (rank == ih - a.cL) mghi[h] = (double)key[e];
+        side = rank >= a.nh - a.cL;
+      }
+      const int child = 2 * j + side;
+      const int nc = side ? a.n - a.nh : a.nh;
+      if (level + 1 >= L || nc <= min_leaf)
+        st[e] = -(((child << (kWRmax - (depth + 1))) << 8) | (level + 1));
+      else
+        st[e] = child;
+    }
+    wsync();
+    if (lane < M && W.sn[lane].cMid > 0) {
+      const SubNode a = W.sn[lane];
+      const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + lane);
+      double vlo = W.vlo[lane];
+      if (il < a.cL) {
+        vlo = (double)ord_to(W.nmaxL[lane], TK());
+        mglo[h] = vlo;
+      }
+      if (ih >= a.cL + a.cMid) mghi[h] = (double)ord_to(W.nminR[lane], TK());
+      if (a.nh > 0 && !(vlo < W.vthr[lane])) atomicAdd(tie_count, 1ULL);
+    }
+    wsync();
+  }
+  if (overflow) {
+    if (lane == 0) {
+      ovf_flags[si] = 1u;
+      atomicAdd(ovf_count, 1u);
+    }
+    return;
+  }
+
+  // ---- scatter every point to the slot range of its terminal node ----
+  // lane v < 32: offset of the terminal whose left-aligned path is v
+  if (lane < (1 << kWRmax)) {
+    int off = 0, n = n_top, d = 0;
+    while (d < depth && !is_leaf_dev(level0 + d, n, L, min_leaf)) {
+      const int nh = n >> 1;
+      if ((lane >> (kWRmax - 1 - d)) & 1) {
+        off += nh;
+        n -= nh;
+      } else {
+        n = nh;
+      }
+      ++d;
+    }
+    W.toff[lane] = off;
+    W.tcur[lane] = 0;
+  }
+  wsync();
+  int32_t* of = F + (int64_t)t * N + sg.off;
+  int32_t* on = nxt + (int64_t)t * N + sg.off;
+  TK* kl = Kleaf + (int64_t)t * N + sg.off;
+#pragma unroll
+  for (int e = 0; e < kWE; ++e) {
+    if (id[e] < 0) continue;
+    const bool done = st[e] < 0;
+    const int v = done ? ((-st[e]) >> 8) : (st[e] << (kWRmax - depth));
+    const int slot = W.toff[v] + atomicAdd(&W.tcur[v], 1);
+    if (done) {
+      of[slot] = id[e];
+      kl[slot] = key[e];
+    } else {
+      on[slot] = id[e];
+    }
+  }
+}
+
+// order one leaf bucket per wave: (key of the parent's level, earlier levels, id).  The bucket
+// (<= 128 points, two per lane) is sorted by a bitonic network over lane shuffles.
+// segs: leaf segments (identical for every tree); key level = leaf level - 1.
+// grid = ceil(S*T/4) blocks of 256 threads.
+template <class TK>
+__global__ __launch_bounds__(256) void leaf_sort_kernel(int32_t* __restrict__ F,
+                                                        const TK* __restrict__ Kleaf, int64_t N,
+                                                        const TK* __restrict__ P, int L, int T,
+                                                        const Seg* __restrict__ segs, int S,
+                                                        const int* __restrict__ seg_level) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= (int64_t)S * T) return;
+  const int si = (int)(wg % S), t = (int)(wg / S);
+  const Seg sg = segs[si];
+  const int tn = sg.n;
+  if (tn <= 1) return;
+  Keys<TK> K{P + (int64_t)t * L * N, N, seg_level[si] - 1, nullptr};
+  int32_t* f = F + (int64_t)t * N + sg.off;
+  const TK* kk = Kleaf + (int64_t)t * N + sg.off;
+  const bool v0 = lane < tn, v1 = lane + 64 < tn;
+  TK k0 = v0 ? kk[lane] : pos_inf<TK>();
+  int i0 = v0 ? f[lane] : kPad;
+  TK k1 = v1 ? kk[lane + 64] : pos_inf<TK>();
+  int i1 = v1 ? f[lane + 64] : kPad;
+  if (tn <= 64) {
+    TK ka[1] = {k0};
+    int ia[1] = {i0};
+    wave_bitonic<TK, 1>(ka, ia, K);
+    k0 = ka[0];
+    i0 = ia[0];
+  } else {
+    TK ka[2] = {k0, k1};
+    int ia[2] = {i0, i1};
+    wave_bitonic<TK, 2>(ka, ia, K);
+    i0 = ia[0];
+    i1 = ia[1];
+  }
+  if (v0) f[lane] = i0;
+  if (v1) f[lane + 64] = i1;
+}
+
 // copy segments src -> dst unchanged (leaves that are already in final order). grid=(S,T)
 __global__ void copy_segs_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
                                  int64_t N, const Seg* __restrict__ segs) {
@@ -964,6 +1394,536 @@ __global__ __launch_bounds__(256) void mid_kernel(int32_t* __restrict__ dst, int
 }
 
 // ---------------------------------------------------------------------------------------
+// streaming path for the top levels (every node of the level is a Bin, <= kStreamMaxNodes
+// nodes per tree): elements never move.  node_of[t][id] holds the in-level node index of
+// every point; one level =
+//   stream_hist   : coalesced pass over (key_l[id], node_of[id]) -> per-node value histogram
+//                   in LDS (kStreamBins bins split over the nodes), flushed by atomics
+//   stream_pick   : one wave per (tree, node): pivot bin, counts, nearest non-empty bins
+//   stream_assign : coalesced pass: bin < pivot -> left child, > pivot -> right child, pivot
+//                   bin -> appended to the node's mid list; min/max of the NEXT level's key per
+//                   child (bin geometry of the next level)
+//   stream_mid    : exact order of the pivot bin (LDS sort with the lexicographic tie-break),
+//                   thr / margins, children of the mid points
+// HBM bytes per point per tree per level: 10 (hist) + 20 (assign) — all coalesced — against
+// 36 + a random 64-B sector for the gather-based path.  stream_to_perm finally counting-sorts
+// the points by node into the permutation the deeper levels work on.
+// A pivot bin larger than LDS (heavy ties / extreme outliers) makes the host leave the
+// streaming path at that level (the gather path has the general fallbacks).
+// ---------------------------------------------------------------------------------------
+constexpr int kStreamMaxNodes = 512;
+constexpr int kStreamBins = 16384;      // LDS histogram entries per block (64 KB)
+constexpr int kStreamThreads = 1024;
+
+template <class TK>
+struct SNode {  // per (tree, node) of the current streaming level
+  TK lo, scale;
+  int n, nh, pb, cL, cMid, lowb, highb, midoff;
+  unsigned int midcur;
+  unsigned long long maxL, minR;
+};
+
+__host__ __device__ inline int stream_bins(int M) {
+  const int b = kStreamBins / M;
+  return b > 4096 ? 4096 : b;
+}
+
+// min / max of one level's keys over the whole tree (root geometry). grid = (nblk, T)
+template <class TK>
+__global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __restrict__ P,
+                                                                 int64_t N, int L, int64_t per,
+                                                                 unsigned long long* cmin,
+                                                                 unsigned long long* cmax) {
+  const int t = blockIdx.y;
+  const TK* Pl = P + (int64_t)t * L * N;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+  unsigned long long mn = ~0ULL, mx = 0ULL;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
+    const unsigned long long o = ord_of(Pl[i]);
+    mn = o < mn ? o : mn;
+    mx = o > mx ? o : mx;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && mn != ~0ULL) {
+    atomicMin(&cmin[t], mn);
+    atomicMax(&cmax[t], mx);
+  }
+}
+
+// per-level node table from the min/max gathered so far. grid = (ceil(M/64), T)
+template <class TK>
+__global__ void stream_setup(int64_t N, int level, int M, const unsigned long long* cmin,
+                             const unsigned long long* cmax, SNode<TK>* nodes_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (j >= M) return;
+  SNode<TK> a;
+  int64_t n = N;
+  for (int b = level - 1; b >= 0; --b) {
+    const int64_t nh = n >> 1;
+    n = ((j >> b) & 1) ? n - nh : nh;
+  }
+  a.n = (int)n;
+  a.nh = (int)(n >> 1);
+  const unsigned long long mn = cmin[(int64_t)t * M + j], mx = cmax[(int64_t)t * M + j];
+  const int B = stream_bins(M);
+  if (mn != ~0ULL) {
+    const TK lo = ord_to(mn, TK()), hi = ord_to(mx, TK());
+    a.lo = lo;
+    a.scale = lo < hi ? (TK)B / (hi - lo) : (TK)0;
+  } else {
+    a.lo = (TK)0;
+    a.scale = (TK)0;
+  }
+  a.pb = a.cL = a.cMid = 0;
+  a.lowb = -1;
+  a.highb = B;
+  a.midoff = 0;
+  a.midcur = 0;
+  a.maxL = 0ULL;
+  a.minR = ~0ULL;
+  nodes_out[(int64_t)t * M + j] = a;
+}
+
+template <class TK>
+__device__ inline int stream_bin(TK key, TK lo, TK scale, int B) {
+  int b = (int)((key - lo) * scale);
+  return b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
+}
+
+template <class TK>
+__global__ __launch_bounds__(kStreamThreads) void stream_hist(
+    const TK* __restrict__ P, const uint16_t* __restrict__ node_of, int64_t N, int L, int level,
+    int M, int64_t per, const SNode<TK>* __restrict__ nd, unsigned int* __restrict__ ghist) {
+  __shared__ unsigned int hist[kStreamBins];
+  __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
+  const int t = blockIdx.y;
+  const int B = stream_bins(M);
+  for (int i = threadIdx.x; i < M * B; i += kStreamThreads) hist[i] = 0;
+  for (int j = threadIdx.x; j < M; j += kStreamThreads) {
+    nlo[j] = nd[(int64_t)t * M + j].lo;
+    nsc[j] = nd[(int64_t)t * M + j].scale;
+  }
+  __syncthreads();
+  const TK* Pl = P + ((int64_t)t * L + level) * N;
+  const uint16_t* no = node_of + (int64_t)t * N;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
+    const int j = no[i];
+    const int b = stream_bin(Pl[i], nlo[j], nsc[j], B);
+    atomicAdd(&hist[j * B + b], 1u);
+  }
+  __syncthreads();
+  unsigned int* gh = ghist + (int64_t)t * kStreamBins;
+  for (int i = threadIdx.x; i < M * B; i += kStreamThreads)
+    if (hist[i]) atomicAdd(&gh[i], hist[i]);
+}
+
+// one wave per (tree, node), four nodes per block. grid = (ceil(M/4), T), 256 threads
+template <class TK>
+__global__ __launch_bounds__(256) void stream_pick(int M, SNode<TK>* nd, unsigned int* ghist,
+                                                   unsigned int* poolcur, unsigned int* bigmid) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), t = blockIdx.y, lane = threadIdx.x & 63;
+  if (j >= M) return;
+  SNode<TK>* a = &nd[(int64_t)t * M + j];
+  const int B = stream_bins(M);
+  unsigned int* h = ghist + (int64_t)t * kStreamBins + (int64_t)j * B;
+  const unsigned int nh = (unsigned int)a->nh;
+  const int per = (B + 63) / 64;
+  unsigned int loc = 0;
+  for (int i = 0; i < per; ++i) {
+    const int b = lane * per + i;
+    if (b < B) loc += h[b];
+  }
+  unsigned int inc = loc;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  unsigned int run = inc - loc;
+  int pb = -1, cL = 0, cMid = 0;
+  for (int i = 0; i < per; ++i) {
+    const int b = lane * per + i;
+    if (b < B) {
+      const unsigned int c = h[b];
+      if (run <= nh && nh < run + c) {
+        pb = b;
+        cL = (int)run;
+        cMid = (int)c;
+      }
+      run += c;
+    }
+  }
+  const unsigned long long own = __ballot(pb >= 0);
+  const int src_lane = own ? __ffsll((long long)own) - 1 : 0;
+  pb = __shfl(pb, src_lane);
+  cL = __shfl(cL, src_lane);
+  cMid = __shfl(cMid, src_lane);
+  // the margins p'[nh-1] / p'[nh+1] fall outside the pivot bin only at its edges: only then
+  // the assign pass has to track max(left) / min(right) (in the nearest non-empty bins)
+  const int n = a->n;
+  const int il = nh > 0 ? (int)nh - 1 : 0, ih = (int)nh + 1 < n ? (int)nh + 1 : n - 1;
+  const bool need_lo = il < cL, need_hi = ih >= cL + cMid;
+  int lowb = -1, highb = B;
+  if (need_lo || need_hi) {
+    for (int i = 0; i < per; ++i) {
+      const int b = lane * per + i;
+      if (b < B && h[b]) {
+        if (b < pb) lowb = b > lowb ? b : lowb;
+        if (b > pb) highb = b < highb ? b : highb;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const int x = __shfl_xor(lowb, o), y = __shfl_xor(highb, o);
+      lowb = x > lowb ? x : lowb;
+      highb = y < highb ? y : highb;
+    }
+  }
+  if (!need_lo) lowb = -2;
+  if (!need_hi) highb = B + 1;
+  for (int i = 0; i < per; ++i) {  // clean for the next level
+    const int b = lane * per + i;
+    if (b < B) h[b] = 0;
+  }
+  if (lane == 0) {
+    a->pb = pb;
+    a->cL = cL;
+    a->cMid = cMid;
+    a->lowb = lowb;
+    a->highb = highb;
+    a->midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
+    if (cMid > kSmallCap) atomicAdd(bigmid, 1u);
+  }
+}
+
+template <class TK>
+__global__ __launch_bounds__(kStreamThreads) void stream_assign(
+    const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
+    int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
+    unsigned long long* cmin_next, unsigned long long* cmax_next) {
+  __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
+  __shared__ int npb[kStreamMaxNodes], nlowb[kStreamMaxNodes], nhighb[kStreamMaxNodes],
+      nmidoff[kStreamMaxNodes];
+  __shared__ unsigned long long smin[2 * kStreamMaxNodes], smax[2 * kStreamMaxNodes];
+  const int t = blockIdx.y;
+  const int B = stream_bins(M);
+  SNode<TK>* ndt = nd + (int64_t)t * M;
+  for (int j = threadIdx.x; j < M; j += kStreamThreads) {
+    nlo[j] = ndt[j].lo;
+    nsc[j] = ndt[j].scale;
+    npb[j] = ndt[j].pb;
+    nlowb[j] = ndt[j].lowb;
+    nhighb[j] = ndt[j].highb;
+    nmidoff[j] = ndt[j].midoff;
+  }
+  for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
+    smin[c] = ~0ULL;
+    smax[c] = 0ULL;
+  }
+  __syncthreads();
+  const TK* Pl = P + ((int64_t)t * L + level) * N;
+  const TK* Pn = has_next ? Pl + N : Pl;
+  uint16_t* no = node_of + (int64_t)t * N;
+  int32_t* pl = pool + (int64_t)t * N;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+  // few nodes: a per-thread running min/max per child avoids hammering one LDS word
+  const bool few = M <= 4;
+  unsigned long long tmn[8], tmx[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    tmn[c] = ~0ULL;
+    tmx[c] = 0ULL;
+  }
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
+    const int j = no[i];
+    const TK key = Pl[i];
+    const int b = stream_bin(key, nlo[j], nsc[j], B);
+    const int pb = npb[j];
+    if (b == pb) {
+      const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
+      pl[nmidoff[j] + p] = (int32_t)i;
+      continue;
+    }
+    const int child = 2 * j + (b > pb);
+    no[i] = (uint16_t)child;
+    if (b == nlowb[j]) atomicMax(&ndt[j].maxL, ord_of(key));
+    if (b == nhighb[j]) atomicMin(&ndt[j].minR, ord_of(key));
+    if (has_next) {
+      const unsigned long long o = ord_of(Pn[i]);
+      if (few) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c == child) {
+            tmn[c] = o < tmn[c] ? o : tmn[c];
+            tmx[c] = o > tmx[c] ? o : tmx[c];
+          }
+      } else {
+        atomicMin(&smin[child], o);
+        atomicMax(&smax[child], o);
+      }
+    }
+  }
+  if (has_next && few) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c >= 2 * M) break;
+      unsigned long long mn = tmn[c], mx = tmx[c];
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(mn, o), b2 = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b2 > mx ? b2 : mx;
+      }
+      if ((threadIdx.x & 63) == 0) {
+        if (mn != ~0ULL) atomicMin(&smin[c], mn);
+        if (mx != 0ULL) atomicMax(&smax[c], mx);
+      }
+    }
+  }
+  __syncthreads();
+  if (has_next)
+    for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
+      if (smin[c] != ~0ULL) atomicMin(&cmin_next[(int64_t)t * 2 * M + c], smin[c]);
+      if (smax[c] != 0ULL) atomicMax(&cmax_next[(int64_t)t * 2 * M + c], smax[c]);
+    }
+}
+
+// exact order of the pivot bin, shared tail: children of the pivot-bin points, min/max of the
+// next level's key, thr / margins.  `sorted(i)` returns the i-th (key, id) of the sorted bin.
+template <class TK>
+struct MidOut {
+  uint16_t* no;
+  const TK* Pn;
+  unsigned long long *cmin_next, *cmax_next;
+  double *thr, *mglo, *mghi;
+  unsigned long long* tie_count;
+};
+
+// wave path: pivot bins of <= 128 points, one wave per (tree, node), 4 per block, no LDS.
+// grid = (ceil(M/4), T), 256 threads
+template <class TK>
+__global__ __launch_bounds__(256) void stream_mid_wave(
+    const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
+    int has_next, const SNode<TK>* __restrict__ nd, const int32_t* __restrict__ pool,
+    unsigned long long* cmin_next, unsigned long long* cmax_next, int64_t heap0, double* thr,
+    double* mglo, double* mghi, int64_t nodes, unsigned long long* tie_count, int wave_max) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), t = blockIdx.y, lane = threadIdx.x & 63;
+  if (j >= M) return;
+  const SNode<TK> a = nd[(int64_t)t * M + j];
+  const int cMid = a.cMid;
+  if (cMid <= 0 || cMid > wave_max || cMid > 128) return;
+  Keys<TK> K{P + (int64_t)t * L * N, N, level, nullptr};
+  const int32_t* m = pool + (int64_t)t * N + a.midoff;
+  // at most 128 points: two per lane (the 4-register instantiation of wave_bitonic proved
+  // codegen-sensitive on ROCm 7.2 and is not used; larger bins take the block-level kernel)
+  TK k[2];
+  int id[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = r * 64 + lane;
+    id[r] = i < cMid ? m[i] : kPad;
+    k[r] = i < cMid ? K.key(id[r]) : pos_inf<TK>();
+  }
+  if (cMid <= 64) {
+    TK k1[1] = {k[0]};
+    int i1[1] = {id[0]};
+    wave_bitonic<TK, 1>(k1, i1, K);
+    k[0] = k1[0];
+    id[0] = i1[0];
+  } else {
+    wave_bitonic<TK, 2>(k, id, K);
+  }
+  const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
+  uint16_t* no = node_of + (int64_t)t * N;
+  const TK* Pn = P + ((int64_t)t * L + level + 1) * N;
+  unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
+  const int n = a.n, nh = a.nh;
+  const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
+  TK vthr = (TK)0, vlo = (TK)0, vhi = (TK)0;
+  int have = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = r * 64 + lane;
+    if (i < cMid) {
+      const int side = i >= kk;
+      no[id[r]] = (uint16_t)(2 * j + side);
+      if (has_next) {
+        const unsigned long long o = ord_of(Pn[id[r]]);
+        mn[side] = o < mn[side] ? o : mn[side];
+        mx[side] = o > mx[side] ? o : mx[side];
+      }
+      if (i == nh - a.cL) {
+        vthr = k[r];
+        have |= 1;
+      }
+      if (i == il - a.cL) {
+        vlo = k[r];
+        have |= 2;
+      }
+      if (i == ih - a.cL) {
+        vhi = k[r];
+        have |= 4;
+      }
+    }
+  }
+  if (has_next) {
+    for (int sd = 0; sd < 2; ++sd) {
+      unsigned long long x = mn[sd], y = mx[sd];
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long p = __shfl_xor(x, o), q = __shfl_xor(y, o);
+        x = p < x ? p : x;
+        y = q > y ? q : y;
+      }
+      if (lane == 0) {
+        if (x != ~0ULL) atomicMin(&cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
+        if (y != 0ULL) atomicMax(&cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
+      }
+    }
+  }
+  // gather the three order statistics on lane 0
+  const unsigned long long b1 = __ballot(have & 1), b2 = __ballot(have & 2), b4 = __ballot(have & 4);
+  const TK tthr = __shfl(vthr, __ffsll((long long)b1) - 1);
+  const TK tlo = b2 ? __shfl(vlo, __ffsll((long long)b2) - 1) : ord_to(a.maxL, TK());
+  const TK thi = b4 ? __shfl(vhi, __ffsll((long long)b4) - 1) : ord_to(a.minR, TK());
+  if (lane == 0) {
+    const int64_t h = (int64_t)t * nodes + heap0 + j;
+    thr[h] = (double)tthr;
+    mglo[h] = (double)tlo;
+    mghi[h] = (double)thi;
+    if (nh > 0 && !(tlo < tthr)) atomicAdd(tie_count, 1ULL);
+  }
+}
+
+// block path: pivot bins of 129..kSmallCap points. grid = (M, T), 256 threads, dynamic LDS
+template <class TK>
+__global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
+                                                  uint16_t* __restrict__ node_of, int64_t N, int L,
+                                                  int level, int M, int has_next,
+                                                  const SNode<TK>* __restrict__ nd,
+                                                  const int32_t* __restrict__ pool,
+                                                  unsigned long long* cmin_next,
+                                                  unsigned long long* cmax_next, int64_t heap0,
+                                                  double* thr, double* mglo, double* mghi,
+                                                  int64_t nodes, unsigned long long* tie_count,
+                                                  int wave_max) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int j = blockIdx.x, t = blockIdx.y;
+  const SNode<TK> a = nd[(int64_t)t * M + j];
+  const int cMid = a.cMid;
+  if (cMid <= wave_max || cMid > kSmallCap) return;
+  const int np = next_pow2(cMid);
+  TK* skey = reinterpret_cast<TK*>(smem);
+  int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
+  Keys<TK> K{P + (int64_t)t * L * N, N, level, nullptr};
+  const int32_t* m = pool + (int64_t)t * N + a.midoff;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) {
+    if (i < cMid) {
+      const int id = m[i];
+      sid[i] = id;
+      skey[i] = K.key(id);
+    } else {
+      sid[i] = kPad;
+      skey[i] = pos_inf<TK>();
+    }
+  }
+  __syncthreads();
+  lds_bitonic(skey, sid, np, K);
+  const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
+  uint16_t* no = node_of + (int64_t)t * N;
+  const TK* Pn = P + ((int64_t)t * L + level + 1) * N;
+  unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
+  for (int i = threadIdx.x; i < cMid; i += blockDim.x) {
+    const int side = i >= kk;
+    no[sid[i]] = (uint16_t)(2 * j + side);
+    if (has_next) {
+      const unsigned long long o = ord_of(Pn[sid[i]]);
+      mn[side] = o < mn[side] ? o : mn[side];
+      mx[side] = o > mx[side] ? o : mx[side];
+    }
+  }
+  if (has_next) {
+    for (int sd = 0; sd < 2; ++sd) {
+      unsigned long long x = mn[sd], y = mx[sd];
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long p = __shfl_xor(x, o), q = __shfl_xor(y, o);
+        x = p < x ? p : x;
+        y = q > y ? q : y;
+      }
+      if ((threadIdx.x & 63) == 0) {
+        if (x != ~0ULL) atomicMin(&cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
+        if (y != 0ULL) atomicMax(&cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    const int n = a.n, nh = a.nh;
+    const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
+    const int64_t h = (int64_t)t * nodes + heap0 + j;
+    const TK vthr = skey[nh - a.cL];
+    const TK vlo = il >= a.cL ? skey[il - a.cL] : ord_to(a.maxL, TK());
+    const TK vhi = ih < a.cL + cMid ? skey[ih - a.cL] : ord_to(a.minR, TK());
+    thr[h] = (double)vthr;
+    mglo[h] = (double)vlo;
+    mghi[h] = (double)vhi;
+    if (nh > 0 && !(vlo < vthr)) atomicAdd(tie_count, 1ULL);
+  }
+}
+
+// counting sort of the points by node -> perm segments; the keys of the next `klevs` levels
+// are written in perm order alongside (coalesced input of wsub_kernel). grid = (nblk, T)
+template <class TK>
+__global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
+    const uint16_t* __restrict__ node_of, int64_t N, int M, int64_t per,
+    const int64_t* __restrict__ noff, unsigned int* __restrict__ gcur, int32_t* __restrict__ perm,
+    const TK* __restrict__ P, int L, int T, int klev0, int klevs, TK* __restrict__ Kperm) {
+  __shared__ unsigned int cnt[2 * kStreamMaxNodes], base[2 * kStreamMaxNodes];
+  const int t = blockIdx.y;
+  const uint16_t* no = node_of + (int64_t)t * N;
+  int32_t* pm = perm + (int64_t)t * N;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+  constexpr int SUB = kStreamThreads * 4;
+  for (int64_t s0 = i0; s0 < i1; s0 += SUB) {
+    for (int j = threadIdx.x; j < M; j += kStreamThreads) cnt[j] = 0;
+    __syncthreads();
+    int nj[4];
+    unsigned int rk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = s0 + e * kStreamThreads + threadIdx.x;
+      nj[e] = -1;
+      if (i < i1) {
+        nj[e] = no[i];
+        rk[e] = atomicAdd(&cnt[nj[e]], 1u);
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < M; j += kStreamThreads)
+      base[j] = cnt[j] ? atomicAdd(&gcur[(int64_t)t * M + j], cnt[j]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = s0 + e * kStreamThreads + threadIdx.x;
+      if (nj[e] >= 0) {
+        const int64_t pos = noff[nj[e]] + base[nj[e]] + rk[e];
+        pm[pos] = (int32_t)i;
+        for (int l = 0; l < klevs; ++l)
+          Kperm[((int64_t)l * T + t) * N + pos] = P[((int64_t)t * L + klev0 + l) * N + i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, int64_t n, unsigned long long v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
 // HBM merge sort of arbitrary segments (rare path: pivot bins / leaves larger than LDS).
 // GSeg list lives in device memory; buf holds ids, sorted in place (tmp = scratch).
 // ---------------------------------------------------------------------------------------
@@ -1083,7 +2043,7 @@ int32_t gsort(rpt_ctx* ctx, int32_t* buf, int32_t* tmp, int64_t N, const TK* P, 
   RPT_TRY(dlist.alloc(list.size()));
   RPT_HIP(hipMemcpyAsync(dlist.p, list.data(), list.size() * sizeof(GSeg), hipMemcpyHostToDevice,
                          ctx->stream));
-  RPT_HIP(hipStreamSynchronize(ctx->stream));  // list is host stack memory
+  RPT_HIP(stream_sync(ctx->stream));  // list is host stack memory
   int64_t nmax = 0;
   for (const GSeg& g : list) nmax = g.n > nmax ? g.n : nmax;
   const unsigned G = (unsigned)list.size();
@@ -1104,8 +2064,14 @@ int32_t gsort(rpt_ctx* ctx, int32_t* buf, int32_t* tmp, int64_t N, const TK* P, 
   return RPT_OK;
 }
 
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define HT(label) do { if (getenv("RPT_DEBUG_HOST")) { (void)stream_sync(ctx->stream); double t__ = now_ms(); fprintf(stderr, "host %-28s %8.3f ms\n", label, t__ - ht_last); ht_last = t__; } } while (0)
+
 template <class TK>
 int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode) {
+  double ht_last = now_ms();
   const int64_t N = f->n;
   const int T = f->T, L = f->L;
   hipStream_t st = ctx->stream;
@@ -1152,6 +2118,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
                               P + (int64_t)t * L * N));
   }
 
+  HT("projection");
   // ---- work buffers ----
   DevBuf<int32_t> bufA, bufB;
   DevBuf<TK> Kst;
@@ -1169,6 +2136,10 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   DevBuf<unsigned int> hist, bigflags;
   DevBuf<unsigned long long> counters;  // [0] tie nodes, [1] (uint) big-mid count
   DevBuf<GSeg> dglist;
+  DevBuf<unsigned int> ovf;
+  DevBuf<TK> Kleaf;
+  DevBuf<Seg> dsegs3;
+  DevBuf<int> dlv;
   RPT_TRY(counters.alloc(2));
   RPT_HIP(hipMemsetAsync(counters.p, 0, 16, st));
   bool have_big = false;
@@ -1188,7 +2159,6 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     RPT_TRY(bigflags.alloc((size_t)T * sb));
     RPT_HIP(hipMemsetAsync(hist.p, 0, (size_t)T * sb * kNB * 4, st));
   }
-  hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, st, bufA.p, N, T);
 
   int32_t* F = f->perm.p;
   unsigned long long* dbgbuf = nullptr;
@@ -1204,7 +2174,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   auto upload = [&](const std::vector<Seg>& v, DevBuf<Seg>& d) -> int32_t {
     RPT_TRY(d.ensure(v.size()));
     RPT_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(Seg), hipMemcpyHostToDevice, st));
-    RPT_HIP(hipStreamSynchronize(st));  // v may be a temporary
+    RPT_HIP(stream_sync(st));  // v may be a temporary
     return RPT_OK;
   };
 
@@ -1215,7 +2185,153 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   };
   std::vector<std::vector<PNode>> pending((size_t)Lused + kRmax + 1);
   int32_t* bufs[2] = {bufA.p, bufB.p};
-  if (!splits[0].empty()) pending[0].push_back(PNode{splits[0][0], 0});
+  HT("alloc work buffers");
+  // ---- streaming path for the leading levels ----
+  int Lstream = 0;
+  if (N >= 2048 && !getenv("RPT_NO_STREAM"))
+    while (Lstream < Lused && splits[(size_t)Lstream].size() == ((size_t)1 << Lstream) &&
+           (1 << Lstream) <= kStreamMaxNodes)
+      ++Lstream;
+  int streamed = 0;  // levels completed by the streaming path
+  DevBuf<TK> Kperm;   // keys of levels [streamed, streamed + kperm_levs) in perm order
+  int kperm_levs = 0;
+  if (Lstream > 0) {
+    DevBuf<uint16_t> node_of;
+    DevBuf<unsigned int> ghist, poolcur, bigmid, gcur;
+    DevBuf<SNode<TK>> snodes;
+    DevBuf<unsigned long long> mm[4];  // cmin/cmax ping-pong
+    DevBuf<int64_t> dnoff;
+    RPT_TRY(node_of.alloc((size_t)T * N));
+    RPT_TRY(ghist.alloc((size_t)T * kStreamBins));
+    RPT_TRY(poolcur.alloc((size_t)T));
+    RPT_TRY(bigmid.alloc(1));
+    RPT_TRY(snodes.alloc((size_t)T * kStreamMaxNodes));
+    for (auto& b : mm) RPT_TRY(b.alloc((size_t)T * 2 * kStreamMaxNodes));
+    RPT_HIP(hipMemsetAsync(node_of.p, 0, (size_t)T * N * 2, st));
+    RPT_HIP(hipMemsetAsync(ghist.p, 0, (size_t)T * kStreamBins * 4, st));
+    int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
+    if (nblk > (N + 4095) / 4096) nblk = (N + 4095) / 4096;
+    if (nblk < 1) nblk = 1;
+    const int64_t per = (N + nblk - 1) / nblk;
+    const dim3 sgrid((unsigned)nblk, (unsigned)T);
+    unsigned long long *cmin = mm[0].p, *cmax = mm[1].p, *cminN = mm[2].p, *cmaxN = mm[3].p;
+    const int64_t mmn = (int64_t)T * 2 * kStreamMaxNodes;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cmin, mmn, ~0ULL);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cmax, mmn, 0ULL);
+    hipLaunchKernelGGL(stream_minmax0<TK>, sgrid, dim3(kStreamThreads), 0, st, P, N, L, per, cmin,
+                       cmax);
+    HT("stream alloc+minmax0");
+    int32_t* pool = bufB.p;  // the ping-pong buffers are idle while nothing moves
+    for (int level = 0; level < Lstream; ++level) {
+      ProfScope ps(ctx, RPT_PROF_SPLIT);
+      const int M = 1 << level;
+      const int has_next = level + 1 < Lstream ? 1 : 0;
+      hipLaunchKernelGGL(stream_setup<TK>, dim3((unsigned)((M + 63) / 64), (unsigned)T), dim3(64),
+                         0, st, N, level, M, cmin, cmax, snodes.p);
+      RPT_HIP(hipMemsetAsync(poolcur.p, 0, (size_t)T * 4, st));
+      RPT_HIP(hipMemsetAsync(bigmid.p, 0, 4, st));
+      if (has_next) {
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cminN, mmn, ~0ULL);
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cmaxN, mmn, 0ULL);
+      }
+      hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
+                         level, M, per, snodes.p, ghist.p);
+      hipLaunchKernelGGL(stream_pick<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T), dim3(256), 0, st, M,
+                         snodes.p, ghist.p, poolcur.p, bigmid.p);
+      unsigned int nbig = 0;
+      RPT_HIP(hipMemcpyAsync(&nbig, bigmid.p, 4, hipMemcpyDeviceToHost, st));
+      RPT_HIP(stream_sync(st));
+      if (nbig) break;  // pivot bin larger than LDS: the gather path takes over at this level
+      hipLaunchKernelGGL(stream_assign<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
+                         level, M, per, has_next, snodes.p, pool, cminN, cmaxN);
+      const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
+      const int wave_max = getenv("RPT_NO_WMID") ? 0 : (getenv("RPT_WMID_MAX") ? atoi(getenv("RPT_WMID_MAX")) : 128);
+      if (wave_max)
+        hipLaunchKernelGGL(stream_mid_wave<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T),
+                           dim3(256), 0, st, P, node_of.p, N, L, level, M, has_next, snodes.p, pool,
+                           cminN, cmaxN, (int64_t)M - 1, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
+                           tie_count, wave_max);
+      hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)M, (unsigned)T), dim3(256), smem, st, P,
+                         node_of.p, N, L, level, M, has_next, snodes.p, pool, cminN, cmaxN,
+                         (int64_t)M - 1, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count,
+                         wave_max);
+      RPT_HIP(hipGetLastError());
+      std::swap(cmin, cminN);
+      std::swap(cmax, cmaxN);
+      streamed = level + 1;
+    }
+    HT("stream levels");
+    if (streamed > 0) {
+      ProfScope ps(ctx, RPT_PROF_SPLIT);
+      const int M = 1 << streamed;
+      std::vector<int64_t> noff((size_t)M);
+      std::vector<Seg> lvl((size_t)M);
+      for (int j = 0; j < M; ++j) {
+        int64_t off = 0, n = N;
+        for (int b = streamed - 1; b >= 0; --b) {
+          const int64_t nh = n / 2;
+          if ((j >> b) & 1) {
+            off += nh;
+            n -= nh;
+          } else {
+            n = nh;
+          }
+        }
+        noff[(size_t)j] = off;
+        lvl[(size_t)j] = Seg{off, (int32_t)n, (int32_t)(M - 1 + j)};
+      }
+      RPT_TRY(dnoff.alloc((size_t)M));
+      RPT_TRY(gcur.alloc((size_t)T * M));
+      RPT_HIP(hipMemcpyAsync(dnoff.p, noff.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
+      RPT_HIP(hipMemsetAsync(gcur.p, 0, (size_t)T * M * 4, st));
+      // nodes of the next level small enough for the wave kernel: hand it their keys in perm order
+      if (getenv("RPT_KPERM") && (N >> streamed) + 1 <= kWCap) {
+        kperm_levs = Lused - streamed < kWRmax ? Lused - streamed : kWRmax;
+        if (kperm_levs > 0) RPT_TRY(Kperm.alloc((size_t)kperm_levs * T * N));
+      }
+      hipLaunchKernelGGL(stream_to_perm<TK>, sgrid, dim3(kStreamThreads), 0, st, node_of.p, N, M,
+                         per, dnoff.p, gcur.p, bufA.p, P, L, T, streamed, kperm_levs, Kperm.p);
+      RPT_HIP(hipGetLastError());
+      RPT_HIP(stream_sync(st));  // noff is host memory
+      // nodes of level `streamed`: Bins stay pending, Tips get their final order now
+      std::vector<Seg> lsmall;
+      std::vector<GSeg> lbig;
+      std::vector<Seg> lbig_copy;
+      for (const Seg& c : lvl) {
+        if (!is_leaf(streamed, c.n, L, f->min_leaf)) {
+          pending[(size_t)streamed].push_back(PNode{c, 0});
+        } else if (c.n <= kSmallCap) {
+          lsmall.push_back(Seg{c.off, c.n, -1});
+        } else {
+          lbig_copy.push_back(Seg{c.off, c.n, -1});
+          for (int t = 0; t < T; ++t)
+            lbig.push_back(GSeg{(int64_t)t * N + c.off, c.n, t, -1, -1, -1, -1});
+        }
+      }
+      if (!lsmall.empty()) {
+        RPT_TRY(upload(lsmall, dsegs));
+        int nm = 0;
+        for (const Seg& sgm : lsmall) nm = sgm.n > nm ? sgm.n : nm;
+        const size_t sm2 = (size_t)next_pow2(nm) * (sizeof(TK) + 4);
+        hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)lsmall.size(), T), dim3(256), sm2,
+                           st, bufA.p, F, N, P, L, streamed - 1, dsegs.p, (const int32_t*)nullptr,
+                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
+      }
+      if (!lbig.empty()) {
+        RPT_TRY(gsort<TK>(ctx, bufA.p, bufB.p, N, P, L, streamed - 1, lbig, dglist, nullptr));
+        RPT_TRY(upload(lbig_copy, dsegs));
+        hipLaunchKernelGGL(copy_segs_kernel, dim3((unsigned)lbig_copy.size(), T), dim3(256), 0, st,
+                           bufA.p, F, N, dsegs.p);
+      }
+      RPT_HIP(hipGetLastError());
+      RPT_HIP(stream_sync(st));  // node_of & co are released at the end of this scope
+    }
+  }
+  HT("stream to_perm + free");
+  if (streamed == 0) {
+    hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, st, bufA.p, N, T);
+    if (!splits[0].empty()) pending[0].push_back(PNode{splits[0][0], 0});
+  }
   // descendants of a node `depth` levels below it that are still split nodes
   std::function<void(const Seg&, int, int, int, std::vector<Seg>&)> descend =
       [&](const Seg& sgm, int level, int depth, int want, std::vector<Seg>& out) {
@@ -1239,14 +2355,100 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       int32_t* cur = bufs[b];
       int32_t* nxt = bufs[1 - b];
 
-      if (!small.empty()) {  // whole subtrees in LDS, kRmax levels per launch
-        RPT_TRY(upload(small, dsegs));
-        hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)small.size(), T), dim3(kSubThreads), 0, st,
-                           cur, nxt, F, N, P, L, level, f->min_leaf, dsegs.p, f->thr.p, f->mglo.p,
-                           f->mghi.p, f->nodes, tie_count, dbgbuf);
+      // small nodes: n <= kWCap -> one wave per subtree; kWCap < n <= kSmallCap -> one block
+      std::vector<Seg> wsmall, bsmall;
+      const bool no_wsub = getenv("RPT_NO_WSUB") != nullptr;
+      for (const Seg& sgm : small) ((sgm.n <= kWCap && !no_wsub) ? wsmall : bsmall).push_back(sgm);
+      if (!wsmall.empty()) {
+        RPT_TRY(upload(wsmall, dsegs));
+        const unsigned S = (unsigned)wsmall.size();
+        RPT_TRY(ovf.ensure((size_t)S + 1));
+        RPT_HIP(hipMemsetAsync(ovf.p, 0, ((size_t)S + 1) * 4, st));
+        RPT_TRY(Kleaf.ensure((size_t)T * N));
+        hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
+                           st, cur, nxt, F, Kleaf.p, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
+                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, ovf.p + 1, ovf.p);
+        unsigned int novf = 0;
+        RPT_HIP(hipMemcpyAsync(&novf, ovf.p, 4, hipMemcpyDeviceToHost, st));
+        RPT_HIP(stream_sync(st));
+        std::vector<Seg> redo;
+        if (novf) {  // pivot bin / leaf larger than a wave slab: block-level kernel for those nodes
+          std::vector<unsigned int> fl((size_t)S);
+          RPT_HIP(hipMemcpy(fl.data(), ovf.p + 1, (size_t)S * 4, hipMemcpyDeviceToHost));
+          for (unsigned i = 0; i < S; ++i)
+            if (fl[i]) redo.push_back(wsmall[i]);
+        }
+        // leaves created by the wave kernel still need their order; nodes it left active stay
+        // pending
+        std::vector<Seg> wl_small, wl_mid;
+        std::vector<int> wl_small_lv;
+        std::vector<std::pair<Seg, int>> wl_mid_lv;
+        std::vector<Seg> rest;
+        std::function<void(const Seg&, int, int)> walk = [&](const Seg& sgm, int lv, int dp) {
+          if (is_leaf(lv, sgm.n, L, f->min_leaf)) {
+            if (sgm.n > 1) {
+              if (sgm.n <= 128) {
+                wl_small.push_back(Seg{sgm.off, sgm.n, -1});
+                wl_small_lv.push_back(lv);
+              } else {
+                wl_mid_lv.push_back({Seg{sgm.off, sgm.n, -1}, lv});
+              }
+            }
+            return;
+          }
+          if (dp == kWRmax) {
+            rest.push_back(sgm);
+            return;
+          }
+          const int nh = sgm.n / 2;
+          walk(Seg{sgm.off, nh, 2 * sgm.heap + 1}, lv + 1, dp + 1);
+          walk(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, lv + 1, dp + 1);
+        };
+        for (size_t i = 0; i < wsmall.size(); ++i) {
+          bool again = false;
+          for (const Seg& r : redo) again = again || r.off == wsmall[i].off;
+          if (!again) walk(wsmall[i], level, 0);
+        }
+        for (const Seg& sgm : rest) pending[(size_t)level + kWRmax].push_back(PNode{sgm, 1 - b});
+        if (!wl_small.empty()) {
+          RPT_TRY(upload(wl_small, dsegs3));
+          RPT_TRY(dlv.ensure(wl_small_lv.size()));
+          RPT_HIP(hipMemcpyAsync(dlv.p, wl_small_lv.data(), wl_small_lv.size() * 4,
+                                 hipMemcpyHostToDevice, st));
+          const unsigned SL = (unsigned)wl_small.size();
+          hipLaunchKernelGGL(leaf_sort_kernel<TK>, dim3((unsigned)(((int64_t)SL * T + 3) / 4)),
+                             dim3(256), 0, st, F, Kleaf.p, N, P, L, T, dsegs3.p, (int)SL, dlv.p);
+          RPT_HIP(stream_sync(st));  // wl_small_lv is host memory
+        }
+        // buckets of 129..kSmallCap points: the block-level LDS sort, grouped by key level
+        while (!wl_mid_lv.empty()) {
+          const int lv = wl_mid_lv.back().second;
+          std::vector<Seg> grp;
+          for (auto it = wl_mid_lv.begin(); it != wl_mid_lv.end();)
+            if (it->second == lv) {
+              grp.push_back(it->first);
+              it = wl_mid_lv.erase(it);
+            } else {
+              ++it;
+            }
+          RPT_TRY(upload(grp, dsegs3));
+          int nm = 0;
+          for (const Seg& sgm : grp) nm = sgm.n > nm ? sgm.n : nm;
+          const size_t sm2 = (size_t)next_pow2(nm) * (sizeof(TK) + 4);
+          hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)grp.size(), T), dim3(256), sm2,
+                             st, F, F, N, P, L, lv - 1, dsegs3.p, (const int32_t*)nullptr,
+                             f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
+        }
+        for (const Seg& r : redo) bsmall.push_back(r);
+      }
+      if (!bsmall.empty()) {  // whole subtrees in LDS, kRmax levels per launch
+        RPT_TRY(upload(bsmall, dsegs));
+        hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)bsmall.size(), T), dim3(kSubThreads),
+                           0, st, cur, nxt, F, N, P, L, level, f->min_leaf, dsegs.p, f->thr.p,
+                           f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
         if (level + kRmax < Lused) {
           std::vector<Seg> rest;
-          for (const Seg& sgm : small) descend(sgm, level, 0, kRmax, rest);
+          for (const Seg& sgm : bsmall) descend(sgm, level, 0, kRmax, rest);
           for (const Seg& sgm : rest) pending[(size_t)level + kRmax].push_back(PNode{sgm, 1 - b});
         }
       }
@@ -1273,7 +2475,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         RPT_HIP(hipGetLastError());
         unsigned int nbig = 0;
         RPT_HIP(hipMemcpyAsync(&nbig, big_count, 4, hipMemcpyDeviceToHost, st));
-        RPT_HIP(hipStreamSynchronize(st));
+        RPT_HIP(stream_sync(st));
         if (nbig) {  // rare: pivot bins larger than LDS -> HBM merge sort of those bins
           std::vector<unsigned int> flags((size_t)T * S);
           std::vector<NodeAux> haux((size_t)T * S);
@@ -1309,7 +2511,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           hipLaunchKernelGGL(gsort_emit_kernel<TK>, dim3((unsigned)((gl.size() + 63) / 64)),
                              dim3(64), 0, st, nxt, N, P, L, level, dglist.p, (int)gl.size(),
                              aux.p, didx.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
-          RPT_HIP(hipStreamSynchronize(st));
+          RPT_HIP(stream_sync(st));
         }
         // children: leaves get their final (sorted) order now, the rest stays pending
         std::vector<Seg> lsmall;
@@ -1350,15 +2552,16 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       RPT_HIP(hipGetLastError());
     }
   }
+  HT("pending loop");
   if (dbgbuf) {
     unsigned long long hs[256];
-    RPT_HIP(hipStreamSynchronize(st));
+    RPT_HIP(stream_sync(st));
     RPT_HIP(hipMemcpy(hs, dbgbuf, sizeof(hs), hipMemcpyDeviceToHost));
     for (int i = 1; i < 256 && hs[i]; ++i) fprintf(stderr, "stamp %d: +%llu\n", i, hs[i] - hs[i - 1]);
   }
   unsigned long long ties = 0;
   RPT_HIP(hipMemcpyAsync(&ties, tie_count, 8, hipMemcpyDeviceToHost, st));
-  RPT_HIP(hipStreamSynchronize(st));
+  RPT_HIP(stream_sync(st));
   f->tie_nodes = (int64_t)ties;
   return RPT_OK;
 }
@@ -1439,7 +2642,7 @@ int32_t split_segments(rpt_ctx* ctx, const double* key_host, int64_t n, int32_t*
                        (int64_t)S, tie.p);
   }
   RPT_HIP(hipGetLastError());
-  RPT_HIP(hipStreamSynchronize(st));
+  RPT_HIP(stream_sync(st));
   RPT_HIP(hipMemcpy(perm_io_host, dperm.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   std::vector<double> a((size_t)S), b((size_t)S), c((size_t)S);
   RPT_HIP(hipMemcpy(a.data(), dthr.p, (size_t)S * 8, hipMemcpyDeviceToHost));

@@ -26,6 +26,7 @@ SYMBOLS = {
     "rpt_ctx_create": (i32, [i32, C.POINTER(vp)]),
     "rpt_ctx_destroy": (i32, [vp]),
     "rpt_ctx_sync": (i32, [vp]),
+    "rpt_ctx_trim": (i32, [vp]),
     "rpt_ctx_stream": (i32, [vp, C.POINTER(vp)]),
     "rpt_prof_enable": (i32, [vp, i32]),
     "rpt_prof_reset": (i32, [vp]),
