@@ -17,6 +17,7 @@
 //   expand_kernel : materialises candidate ids for rpt_candidates
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
 #include <limits>
 
 #include "common.h"
@@ -327,6 +328,241 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
   if (threadIdx.x == 0) out_cnt[q] = best;
 }
 
+// ---------------------------------------------------------------------------------------
+// fused query kernel (dense data): one workgroup per query does everything after the query
+// projections — traversal of every tree (thread = tree, twice: count, then emit ranges in
+// tree order), candidate ids gathered into LDS, distances (each wave keeps EIGHT whole rows in
+// flight, 16-byte loads, butterfly reduction), top-k.  No global scan, no range list in HBM.
+// Batches of kFC candidates; the running best k re-enter the next batch at the front with
+// their original candidate positions, so the order (distance, position) is global.
+// k <= kFK: k rounds of block-wide arg-min; larger k or a range list that does not fit the
+// LDS slab -> the query is flagged and the host falls back to the general path.
+// ---------------------------------------------------------------------------------------
+constexpr int kFC = 2048;     // candidates per batch
+constexpr int kFR = 512;      // leaf ranges per query in LDS
+constexpr int kFK = 64;       // largest k served by the arg-min selection
+
+template <class TD, class TK>
+__global__ __launch_bounds__(256) void knn_fused_kernel(
+    const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
+    const double* __restrict__ thr, const double* __restrict__ mglo,
+    const double* __restrict__ mghi, int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T,
+    int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
+    double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
+    unsigned int* ovf_count, unsigned long long* cand_total) {
+  typedef typename AccOf<TD>::type TA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* cdist = reinterpret_cast<double*>(smem);                 // [kFC]
+  int* cid = reinterpret_cast<int*>(cdist + kFC);                  // [kFC]
+  int* cpos = cid + kFC;                                           // [kFC]
+  int64_t* rpoff = reinterpret_cast<int64_t*>(cpos + kFC);         // [kFR]
+  int* rn = reinterpret_cast<int*>(rpoff + kFR);                   // [kFR]
+  int* tcnt = rn + kFR;                                            // [1024] per-tree counts
+  int* trng = tcnt + 1024;                                         // [1024]
+  double* bdist = reinterpret_cast<double*>(trng + 1024);          // [kFK]
+  int* bid = reinterpret_cast<int*>(bdist + kFK);                  // [kFK]
+  int* bpos = bid + kFK;                                           // [kFK]
+  TA* qs = reinterpret_cast<TA*>(bpos + kFK);                      // [d]
+  __shared__ int s_nr, s_nc;
+  __shared__ double s_red_d[4];
+  __shared__ int s_red_p[4], s_red_i[4];
+
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
+
+  // ---- traversal 1: counts per tree ----
+  for (int t = tid; t < T; t += 256) {
+    int nc = 0, nr = 0;
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                 nq, L, min_leaf, N, [&](int, int n) {
+                   nc += n;
+                   ++nr;
+                 });
+    tcnt[t] = nc;
+    trng[t] = nr;
+  }
+  __syncthreads();
+  if (tid == 0) {  // exclusive scans over <= 1024 trees
+    int c = 0, r = 0;
+    for (int t = 0; t < T; ++t) {
+      const int a = tcnt[t], b = trng[t];
+      tcnt[t] = c;
+      trng[t] = r;
+      c += a;
+      r += b;
+    }
+    s_nc = c;
+    s_nr = r;
+  }
+  __syncthreads();
+  const int nr_tot = s_nr, nc_tot = s_nc;
+  if (nr_tot > kFR) {  // too many leaf ranges for the slab: general path
+    if (tid == 0) {
+      ovf_flags[q] = 1u;
+      atomicAdd(ovf_count, 1u);
+    }
+    return;
+  }
+  if (tid == 0) atomicAdd(cand_total, (unsigned long long)nc_tot);
+  // ---- traversal 2: ranges in tree order ----
+  for (int t = tid; t < T; t += 256) {
+    int r = trng[t];
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                 nq, L, min_leaf, N, [&](int off, int n) {
+                   rpoff[r] = (int64_t)t * N + off;
+                   rn[r] = n;
+                   ++r;
+                 });
+  }
+  __syncthreads();
+
+  int best = 0;       // entries of the running best list
+  int r_next = 0;     // next range to consume
+  int r_done = 0;     // candidates of range r_next already consumed
+  int pos_base = 0;   // candidate position of the next unconsumed candidate
+  while (r_next < nr_tot || best == 0) {
+    // ---- fill the batch: best list first (keeps its positions), then new candidates ----
+    for (int i = tid; i < best; i += 256) {
+      cdist[i] = bdist[i];
+      cid[i] = bid[i];
+      cpos[i] = bpos[i];
+    }
+    int fill = best;
+    const int first_new = fill;
+    // every thread walks the same range list (uniform control flow)
+    int rr = r_next, rd = r_done, pb = pos_base;
+    while (rr < nr_tot && fill < kFC) {
+      int take = rn[rr] - rd;
+      if (take > kFC - fill) take = kFC - fill;
+      for (int i = tid; i < take; i += 256) {
+        cid[fill + i] = perm[rpoff[rr] + rd + i];
+        cpos[fill + i] = pb + i;
+      }
+      fill += take;
+      rd += take;
+      pb += take;
+      if (rd == rn[rr]) {
+        ++rr;
+        rd = 0;
+      }
+    }
+    r_next = rr;
+    r_done = rd;
+    pos_base = pb;
+    __syncthreads();
+    // ---- distances of the new candidates: 8 rows in flight per wave ----
+    for (int i0 = first_new + wave * 8; i0 < fill; i0 += 32) {
+      TA s[8];
+      const TD* rows[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u < fill ? i0 + u : i0;
+        rows[u] = X + (int64_t)cid[i] * d;
+        s[u] = (TA)0;
+      }
+      constexpr int V = 16 / (int)sizeof(TD);
+      if ((d % V) == 0) {
+        struct alignas(16) Raw { TD v[V]; };
+        for (int j = lane * V; j < d; j += 64 * V) {
+          Raw x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const Raw*>(rows[u] + j);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              const TA df = ld<TD>(&x[u].v[v]) - qs[j + v];
+              s[u] += df * df;
+            }
+        }
+      } else {
+        for (int j = lane; j < d; j += 64) {
+          const TA qj = qs[j];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const TA df = ld<TD>(rows[u] + j) - qj;
+            s[u] += df * df;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const TA tot = wave_sum(s[u]);
+        if (lane == 0 && i0 + u < fill) cdist[i0 + u] = (double)sqrt((double)tot);
+      }
+    }
+    __syncthreads();
+    // ---- selection: k rounds of block-wide arg-min by (distance, position) ----
+    int nb = 0;
+    double last_d = -1.0;
+    while (nb < k) {
+      double bd = __longlong_as_double(0x7ff0000000000000LL);
+      int bp = 0x7fffffff, bi = -1;
+      for (int i = tid; i < fill; i += 256) {
+        const double dd = cdist[i];
+        const int pp = cpos[i];
+        if (pp >= 0 && (dd < bd || (dd == bd && pp < bp))) {
+          bd = dd;
+          bp = pp;
+          bi = i;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double od = __shfl_xor(bd, o);
+        const int op = __shfl_xor(bp, o), oi = __shfl_xor(bi, o);
+        if (od < bd || (od == bd && op < bp)) {
+          bd = od;
+          bp = op;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        s_red_d[wave] = bd;
+        s_red_p[wave] = bp;
+        s_red_i[wave] = bi;
+      }
+      __syncthreads();
+      bd = s_red_d[0];
+      bp = s_red_p[0];
+      bi = s_red_i[0];
+      for (int w = 1; w < 4; ++w)
+        if (s_red_d[w] < bd || (s_red_d[w] == bd && s_red_p[w] < bp)) {
+          bd = s_red_d[w];
+          bp = s_red_p[w];
+          bi = s_red_i[w];
+        }
+      __syncthreads();
+      if (bi < 0) break;  // candidates exhausted
+      bool keep = true;
+      if (dedup && bd == last_d)  // same id => same distance: duplicates are among equal dist
+        for (int j = nb - 1; j >= 0 && bdist[j] == bd; --j)
+          if (bid[j] == cid[bi]) keep = false;
+      if (tid == 0) {
+        if (keep) {
+          bdist[nb] = bd;
+          bid[nb] = cid[bi];
+          bpos[nb] = bp;
+        }
+        cpos[bi] = -1;  // consumed
+      }
+      __syncthreads();
+      if (keep) {
+        ++nb;
+        last_d = bd;
+      }
+    }
+    best = nb;
+    if (r_next >= nr_tot) break;
+  }
+  for (int i = tid; i < k; i += 256) {
+    const bool ok = i < best;
+    out_ids[q * k + i] = ok ? bid[i] : -1;
+    out_dist[q * k + i] = ok ? bdist[i] : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  if (tid == 0) out_cnt[q] = best;
+}
+
 // CSR data and CSR queries: the query is densified into LDS; distance of a sparse row x:
 // d^2 = |q|^2 + sum_{j in nz(x)} ((x_j - q_j)^2 - q_j^2)   (true Euclidean distance)
 template <class TD>
@@ -537,11 +773,29 @@ static int32_t launch_topk_dense(rpt_ctx* ctx, const rpt_dataset* data, const rp
   return RPT_OK;
 }
 
-int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
-                int32_t k, int32_t flags, int32_t* ids_dev, double* dist_dev, int32_t* count_dev) {
-  RPT_ARG(data->dtype == q->dtype, "data and query dtype must match");
-  RPT_ARG(k <= kBuf / 2, "k too large for the LDS merge buffer");
-  RPT_ARG((size_t)data->d * 8 + (sizeof(Entry) + 4) * kBuf <= 150 * 1024, "d too large");
+template <class TD, class TK>
+static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                            const rpt_dataset* q, const void* Pq, int32_t k, int dedup,
+                            int32_t* ids, double* dist, int32_t* cnt, unsigned int* ovf,
+                            unsigned long long* cand_total) {
+  typedef typename AccOf<TD>::type TA;
+  const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFK * 16 +
+                      (size_t)data->d * sizeof(TA) + 64;
+  if (smem > 64 * 1024)
+    RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
+  hipLaunchKernelGGL((knn_fused_kernel<TD, TK>), dim3((unsigned)q->n), dim3(256), smem,
+                     ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
+                     f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
+                     f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total);
+  RPT_HIP(hipGetLastError());
+  return RPT_OK;
+}
+
+static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                           const rpt_dataset* q, int32_t k, int32_t flags, int32_t* ids_dev,
+                           double* dist_dev, int32_t* count_dev) {
   QueryPlan pl;
   RPT_TRY(make_plan(ctx, f, q, pl));
   ctx->last_candidates = pl.total_cand;
@@ -578,6 +832,54 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
                                               f->T, 0, k, dedup, ids_dev, dist_dev, count_dev));
   }
   RPT_HIP(stream_sync(ctx->stream));  // the plan's buffers are released on return
+  return RPT_OK;
+}
+
+int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
+                int32_t k, int32_t flags, int32_t* ids_dev, double* dist_dev, int32_t* count_dev) {
+  RPT_ARG(data->dtype == q->dtype, "data and query dtype must match");
+  RPT_ARG(k <= kBuf / 2, "k too large for the LDS merge buffer");
+  RPT_ARG((size_t)data->d * 8 + (sizeof(Entry) + 4) * kBuf <= 150 * 1024, "d too large");
+  RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
+          "query dtype must have the forest's projection type (f64 vs f32/bf16)");
+  const bool fused = !data->csr && k <= kFK && f->T <= 1024 && !getenv("RPT_KNN_GENERAL") &&
+                     (size_t)data->d * 8 <= 32 * 1024;
+  if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
+  const int64_t nq = q->n;
+  const int dedup = (flags & RPT_KNN_DEDUP) ? 1 : 0;
+  DevBuf<char> Pq;
+  DevBuf<unsigned int> ovf;
+  DevBuf<unsigned long long> ctot;
+  const size_t esz = f->pdtype == RPT_F64 ? 8 : 4;
+  RPT_TRY(Pq.alloc((size_t)f->T * f->L * nq * esz + 16));
+  RPT_TRY(ovf.alloc((size_t)nq + 1));
+  RPT_TRY(ctot.alloc(1));
+  RPT_HIP(hipMemsetAsync(ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
+  RPT_HIP(hipMemsetAsync(ctot.p, 0, 8, ctx->stream));
+  {
+    ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
+    if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
+  }
+  int32_t s = RPT_OK;
+  if (f->pdtype == RPT_F64) {
+    s = launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev, count_dev,
+                                     ovf.p, ctot.p);
+  } else if (data->dtype == RPT_F32) {
+    s = launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev, count_dev,
+                                   ovf.p, ctot.p);
+  } else {
+    s = launch_fused<__hip_bfloat16, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
+                                            count_dev, ovf.p, ctot.p);
+  }
+  RPT_TRY(s);
+  unsigned int novf = 0;
+  unsigned long long tot = 0;
+  RPT_HIP(hipMemcpyAsync(&novf, ovf.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RPT_HIP(hipMemcpyAsync(&tot, ctot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
+  ctx->last_candidates = (int64_t)tot;
+  if (novf)  // some query reached more leaf ranges than the LDS slab holds: general path
+    return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
   return RPT_OK;
 }
 

@@ -22,6 +22,8 @@
 // HBM traffic per launch (algorithmic): N*d*sizeof(x) + d*CB*8 + N*CB*sizeof(p).
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rpt {
@@ -216,6 +218,119 @@ __global__ __launch_bounds__(256, 2) void proj_exact_fast(const T* __restrict__ 
       }
 #pragma unroll
       for (int c = 0; c < CB; ++c) acc[c] = (T)0;
+    }
+    t = tn;
+    ch = chn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact-order kernel, LDS-broadcast form (rows of exactly D elements).  proj_exact_fast is
+// bounded by the scalar cache: 32 hyperplane values per k arrive through four serialized
+// s_load_dwordx16.  Here a wave owns 128 rows (two per lane) and walks k-chunks of KC from the
+// last to the first; the chunk of X ([128][KC]) and the chunk of hyperplanes ([KC][32]) are
+// staged in a wave-private LDS slab (next chunk prefetched into registers meanwhile); per k the
+// 32 hyperplane values are read with eight uniform-address ds_read_b128 (LDS broadcast) and
+// each feeds two rows: acc = r*x + acc, separate multiply and add, k descending — the
+// reference's innerSD order (Internal.hs:382), bit for bit.
+// ---------------------------------------------------------------------------------------
+template <class T, int D, int KC>
+__global__ __launch_bounds__(256, 1) void proj_exact_lds(const T* __restrict__ X, int64_t n,
+                                                         const T* __restrict__ Rt /*[D][32]*/,
+                                                         T* __restrict__ P, int64_t ldp, int ncol,
+                                                         int64_t ntiles) {
+  constexpr int CB = 32;
+  constexpr int ROWS = 128;
+  constexpr int PIECE = 16 / (int)sizeof(T);
+  constexpr int PPR = KC / PIECE;                  // pieces per row per chunk
+  constexpr int NPX = ROWS * PPR / 64;             // X pieces per lane per chunk
+  constexpr int NPR = KC * CB / PIECE / 64;        // hyperplane pieces per lane per chunk
+  constexpr int NCH = D / KC;
+  constexpr int LDW = KC + PIECE;                  // X row stride (keeps 16-B alignment)
+  static_assert(NPR >= 1, "chunk too small");
+  __shared__ __attribute__((aligned(16))) T xt[4][ROWS * LDW];
+  __shared__ __attribute__((aligned(16))) T rt[4][KC * CB];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  T* myx = xt[wave];
+  T* myr = rt[wave];
+  typedef typename Vec16<T>::type Raw;
+  const int64_t last_row = n - 1;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+
+  Raw sx[NPX], sr[NPR];
+  auto issue = [&](int64_t t, int ch) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = i * 64 + lane;
+      int64_t row = t * ROWS + p / PPR;
+      row = row < last_row ? row : last_row;
+      sx[i] = *reinterpret_cast<const Raw*>(X + row * D + ch * KC + (p % PPR) * PIECE);
+    }
+#pragma unroll
+    for (int i = 0; i < NPR; ++i)
+      sr[i] = *reinterpret_cast<const Raw*>(Rt + (int64_t)ch * KC * CB + (i * 64 + lane) * PIECE);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = i * 64 + lane;
+      *reinterpret_cast<Raw*>(myx + (p / PPR) * LDW + (p % PPR) * PIECE) = sx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPR; ++i) *reinterpret_cast<Raw*>(myr + (i * 64 + lane) * PIECE) = sr[i];
+  };
+
+  T acc0[CB], acc1[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    acc0[c] = (T)0;
+    acc1[c] = (T)0;
+  }
+  int64_t t = wave_global;
+  int ch = NCH - 1;
+  if (t < ntiles) issue(t, ch);
+  while (t < ntiles) {
+    __builtin_amdgcn_wave_barrier();
+    commit();
+    int64_t tn = t;
+    int chn = ch - 1;
+    if (chn < 0) {
+      chn = NCH - 1;
+      tn = t + wave_stride;
+    }
+    if (tn < ntiles) issue(tn, chn);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int k = KC - 1; k >= 0; --k) {
+      const T x0 = myx[lane * LDW + k];
+      const T x1 = myx[(lane + 64) * LDW + k];
+      const Raw* rk = reinterpret_cast<const Raw*>(myr + k * CB);  // same address in every lane
+#pragma unroll
+      for (int c2 = 0; c2 < CB / PIECE; ++c2) {
+        const Raw rv = rk[c2];
+#pragma unroll
+        for (int q = 0; q < PIECE; ++q) {
+          const int c = c2 * PIECE + q;
+          acc0[c] = add_rn(mul_rn(rv[q], x0), acc0[c]);
+          acc1[c] = add_rn(mul_rn(rv[q], x1), acc1[c]);
+        }
+      }
+    }
+    if (ch == 0) {
+      const int64_t row0 = t * ROWS + lane, row1 = row0 + 64;
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+        if (c < ncol) {
+          if (row0 < n) P[(int64_t)c * ldp + row0] = acc0[c];
+          if (row1 < n) P[(int64_t)c * ldp + row1] = acc1[c];
+        }
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        acc0[c] = (T)0;
+        acc1[c] = (T)0;
+      }
     }
     t = tn;
     ch = chn;
@@ -578,7 +693,14 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
     const int c0 = b * CB;
     const int ncol = C - c0 < CB ? C - c0 : CB;
     ProfScope ps(ctx, RPT_PROF_PROJECT);
-    if (fast)
+    if (fast && !getenv("RPT_EXACT_SGPR")) {
+      const int64_t nt128 = (n + 127) / 128;
+      int64_t lb = (nt128 + 3) / 4;
+      if (lb > (int64_t)ctx->n_cu * 2) lb = (int64_t)ctx->n_cu * 2;
+      hipLaunchKernelGGL((proj_exact_lds<T, 128, 8>), dim3((unsigned)lb), dim3(256), 0, ctx->stream,
+                         (const T*)ds->X, n, Rt.p + (size_t)b * d * CB, P + (int64_t)c0 * n, n, ncol,
+                         nt128);
+    } else if (fast)
       hipLaunchKernelGGL((proj_exact_fast<T, 128, CB, 32, false>), dim3((unsigned)fblocks), dim3(256), 0,
                          ctx->stream, (const T*)ds->X, n, Rt.p + (size_t)b * d * CB,
                          masks.p + (size_t)b * d, P + (int64_t)c0 * n, n, ncol, ntiles);

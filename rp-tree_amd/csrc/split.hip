@@ -1412,7 +1412,8 @@ __global__ __launch_bounds__(256) void mid_kernel(int32_t* __restrict__ dst, int
 // streaming path at that level (the gather path has the general fallbacks).
 // ---------------------------------------------------------------------------------------
 constexpr int kStreamMaxNodes = 512;
-constexpr int kStreamBins = 16384;      // LDS histogram entries per block (64 KB)
+constexpr int kStreamBins = 32768;      // histogram entries per block: 16-bit counters packed
+                                        // two per LDS word (64 KB); a block sees < 65536 points
 constexpr int kStreamThreads = 1024;
 
 template <class TK>
@@ -1499,11 +1500,11 @@ template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_hist(
     const TK* __restrict__ P, const uint16_t* __restrict__ node_of, int64_t N, int L, int level,
     int M, int64_t per, const SNode<TK>* __restrict__ nd, unsigned int* __restrict__ ghist) {
-  __shared__ unsigned int hist[kStreamBins];
+  __shared__ unsigned int hist[kStreamBins / 2];  // two 16-bit counters per word
   __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
   const int t = blockIdx.y;
   const int B = stream_bins(M);
-  for (int i = threadIdx.x; i < M * B; i += kStreamThreads) hist[i] = 0;
+  for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) hist[i] = 0;
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
     nlo[j] = nd[(int64_t)t * M + j].lo;
     nsc[j] = nd[(int64_t)t * M + j].scale;
@@ -1514,13 +1515,63 @@ __global__ __launch_bounds__(kStreamThreads) void stream_hist(
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
   for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
     const int j = no[i];
-    const int b = stream_bin(Pl[i], nlo[j], nsc[j], B);
-    atomicAdd(&hist[j * B + b], 1u);
+    const int e = j * B + stream_bin(Pl[i], nlo[j], nsc[j], B);
+    atomicAdd(&hist[e >> 1], 1u << ((e & 1) * 16));  // per < 65536: no carry between halves
   }
   __syncthreads();
   unsigned int* gh = ghist + (int64_t)t * kStreamBins;
-  for (int i = threadIdx.x; i < M * B; i += kStreamThreads)
-    if (hist[i]) atomicAdd(&gh[i], hist[i]);
+  for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) {
+    const unsigned int w = hist[i];
+    if (w & 0xffffu) atomicAdd(&gh[2 * i], w & 0xffffu);
+    if (w >> 16) atomicAdd(&gh[2 * i + 1], w >> 16);
+  }
+}
+
+// many small nodes (B <= 128 bins): one THREAD per (tree, node). grid = (ceil(M/256), T)
+template <class TK>
+__global__ __launch_bounds__(256) void stream_pick_small(int M, SNode<TK>* nd, unsigned int* ghist,
+                                                         unsigned int* poolcur,
+                                                         unsigned int* bigmid) {
+  const int j = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  if (j >= M) return;
+  SNode<TK>* a = &nd[(int64_t)t * M + j];
+  const int B = stream_bins(M);
+  unsigned int* h = ghist + (int64_t)t * kStreamBins + (int64_t)j * B;
+  const unsigned int nh = (unsigned int)a->nh;
+  unsigned int run = 0;
+  int pb = -1, cL = 0, cMid = 0, lastne = -1, lowb = -1, highb = B;
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    const uint4 c4 = *reinterpret_cast<const uint4*>(h + b0);
+    const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = b0 + q;
+      if (pb < 0) {
+        if (run <= nh && nh < run + c[q]) {
+          pb = b;
+          cL = (int)run;
+          cMid = (int)c[q];
+          lowb = lastne;
+        }
+      } else if (highb == B && c[q]) {
+        highb = b;
+      }
+      if (c[q]) lastne = b;
+      run += c[q];
+    }
+    *reinterpret_cast<uint4*>(h + b0) = make_uint4(0, 0, 0, 0);  // clean for the next level
+  }
+  const int n = a->n;
+  const int il = nh > 0 ? (int)nh - 1 : 0, ih = (int)nh + 1 < n ? (int)nh + 1 : n - 1;
+  if (!(il < cL)) lowb = -2;
+  if (!(ih >= cL + cMid)) highb = B + 1;
+  a->pb = pb;
+  a->cL = cL;
+  a->cMid = cMid;
+  a->lowb = lowb;
+  a->highb = highb;
+  a->midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
+  if (cMid > kSmallCap) atomicAdd(bigmid, 1u);
 }
 
 // one wave per (tree, node), four nodes per block. grid = (ceil(M/4), T), 256 threads
@@ -2211,6 +2262,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     RPT_HIP(hipMemsetAsync(ghist.p, 0, (size_t)T * kStreamBins * 4, st));
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblk > (N + 4095) / 4096) nblk = (N + 4095) / 4096;
+    if (nblk < (N + 65534) / 65535) nblk = (N + 65534) / 65535;  // 16-bit LDS counters
     if (nblk < 1) nblk = 1;
     const int64_t per = (N + nblk - 1) / nblk;
     const dim3 sgrid((unsigned)nblk, (unsigned)T);
@@ -2236,8 +2288,12 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       }
       hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
                          level, M, per, snodes.p, ghist.p);
-      hipLaunchKernelGGL(stream_pick<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T), dim3(256), 0, st, M,
-                         snodes.p, ghist.p, poolcur.p, bigmid.p);
+      if (stream_bins(M) <= 128)
+        hipLaunchKernelGGL(stream_pick_small<TK>, dim3((unsigned)((M + 255) / 256), (unsigned)T),
+                           dim3(256), 0, st, M, snodes.p, ghist.p, poolcur.p, bigmid.p);
+      else
+        hipLaunchKernelGGL(stream_pick<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T), dim3(256), 0,
+                           st, M, snodes.p, ghist.p, poolcur.p, bigmid.p);
       unsigned int nbig = 0;
       RPT_HIP(hipMemcpyAsync(&nbig, bigmid.p, 4, hipMemcpyDeviceToHost, st));
       RPT_HIP(stream_sync(st));
