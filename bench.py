@@ -52,7 +52,10 @@ def main():
     ap.add_argument("--min-leaf", type=int, default=128)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nq", type=int, default=10_000)
-    ap.add_argument("--mode", choices=["auto", "exact", "mfma"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "exact", "mfma"], default="mfma",
+                    help="projection kernel of the timed build: mfma = the north-star MFMA tile "
+                         "kernel (values within 1e-5*|x||r|), exact = reference summation order "
+                         "(bit-identical leaf assignment); the other mode is timed as a side leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -168,12 +171,46 @@ def main():
     t_knn = time.perf_counter() - t0
     _lib.check(L_.rpt_prof_enable(ctx._h, 0))
 
+    prof_q = read_prof()
+    # ---- side leg: the same K builds with the OTHER projection kernel + leaf agreement ----
+    alt_name = "exact" if args.mode == "mfma" else "mfma"
+    alt_mode = rp.RPT_PROJ_EXACT if alt_name == "exact" else rp.RPT_PROJ_MFMA
+    alt = rp._build(ctx, ds, Rl, maxd, args.min_leaf, alt_mode)       # warm
+    alt.close()
+    _lib.check(L_.rpt_prof_reset(ctx._h))
+    _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        alt = rp._build(ctx, ds, Rl, maxd, args.min_leaf, alt_mode)
+        if _ != args.steps - 1:
+            alt.close()
+    barrier()
+    t_alt = time.perf_counter() - t0
+    prof_alt = read_prof()
+    _lib.check(L_.rpt_prof_enable(ctx._h, 0))
+    # leaf-assignment agreement between the two kernels (same leaf <=> same position range)
+    topo = forest.topology()
+    leaf_off = np.array([o for (_, _, o, n, lf) in topo if lf], dtype=np.int64)
+    pa, pb = forest.perm, alt.perm
+
+    def leaf_index(perm_row):
+        inv = np.empty(N, dtype=np.int64)
+        inv[perm_row] = np.arange(N)
+        return np.searchsorted(leaf_off, inv, side="right")
+
+    flips = 0
+    nt_cmp = min(Tl, 4)
+    for t in range(nt_cmp):
+        flips += int((leaf_index(pa[t]) != leaf_index(pb[t])).sum())
+    leaf_flip_rate = flips / float(nt_cmp * N)
+    alt.close()
+
     tt = torch.tensor([t_build, t_knn], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t_build, t_knn = float(tt[0]), float(tt[1])
 
-    prof_q = read_prof()
     prof["knn_plan"], prof["knn_topk"] = prof_q["knn_plan"], prof_q["knn_topk"]
     cand_total = C.c_int64()
     _lib.check(L_.rpt_knn_last_candidates(ctx._h, C.byref(cand_total)))
@@ -274,6 +311,13 @@ def main():
                              "queries": nq_eval},
             "build_breakdown_ms": {"projection_total": p_ms / args.steps,
                                    "split_total": prof["split"][0] / args.steps},
+            "other_projection_mode": {
+                "mode": alt_name, "value": N * args.steps / t_alt, "unit": "vectors/s",
+                "ms_per_step": t_alt / args.steps * 1e3,
+                "projection_avg_launch_ms": prof_alt["project"][0] / max(prof_alt["project"][1], 1),
+                "leaf_assignment_flip_rate_vs_timed_mode": leaf_flip_rate,
+                "note": "exact = reference summation order, bit-identical to the oracle; "
+                        "flips are points whose projection is within rounding of a median"},
             "forest_stats": forest.stats(),
         }
         print(json.dumps(out))

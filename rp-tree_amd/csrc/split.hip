@@ -755,9 +755,9 @@ template <class TK>
 __global__ __launch_bounds__(256) void wsub_kernel(
     const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
     TK* __restrict__ Kleaf, int64_t N, const TK* __restrict__ P, int L, int T, int level0,
-    int min_leaf, const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
-    int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
-    unsigned int* ovf_count) {
+    int min_leaf, const Seg* __restrict__ segs, int S, const TK* __restrict__ Kperm, int klev0,
+    int klevs, double* thr, double* mglo, double* mghi, int64_t nodes,
+    unsigned long long* tie_count, unsigned int* ovf_flags, unsigned int* ovf_count) {
   __shared__ WSlab slabs[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
@@ -794,8 +794,13 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     const int M = 1 << depth;
     const int B = kWHist / M;
     Keys<TK> K{Pt, N, level, nullptr};
-    // ---- a. keys ----
-    {
+    // ---- a. keys: coalesced from Kperm (perm order) when the host provided them ----
+    if (Kperm && level >= klev0 && level < klev0 + klevs) {
+      const TK* kp = Kperm + ((int64_t)(level - klev0) * T + t) * N + sg.off;
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0) key[e] = kp[e * 64 + lane];
+    } else {
       const TK* Pl = Pt + (int64_t)level * N;
 #pragma unroll
       for (int e = 0; e < kWE; ++e)
@@ -1924,47 +1929,46 @@ __global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
 }
 
 // counting sort of the points by node -> perm segments; the keys of the next `klevs` levels
-// are written in perm order alongside (coalesced input of wsub_kernel). grid = (nblk, T)
+// are written in perm order alongside (coalesced input of wsub_kernel).  A block ranks ALL its
+// points (< 65536) in one round, so every node receives one contiguous run per block
+// (~per/M points: a few hundred bytes) instead of 16-byte crumbs.  grid = (nblk, T)
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
     const uint16_t* __restrict__ node_of, int64_t N, int M, int64_t per,
     const int64_t* __restrict__ noff, unsigned int* __restrict__ gcur, int32_t* __restrict__ perm,
     const TK* __restrict__ P, int L, int T, int klev0, int klevs, TK* __restrict__ Kperm) {
+  constexpr int EPT = 64;  // per <= 65535 = 64 * 1024 - 1
   __shared__ unsigned int cnt[2 * kStreamMaxNodes], base[2 * kStreamMaxNodes];
   const int t = blockIdx.y;
   const uint16_t* no = node_of + (int64_t)t * N;
   int32_t* pm = perm + (int64_t)t * N;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
-  constexpr int SUB = kStreamThreads * 4;
-  for (int64_t s0 = i0; s0 < i1; s0 += SUB) {
-    for (int j = threadIdx.x; j < M; j += kStreamThreads) cnt[j] = 0;
-    __syncthreads();
-    int nj[4];
-    unsigned int rk[4];
+  for (int j = threadIdx.x; j < M; j += kStreamThreads) cnt[j] = 0;
+  __syncthreads();
+  unsigned int pk[EPT];  // (node << 16) | rank inside this block
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t i = s0 + e * kStreamThreads + threadIdx.x;
-      nj[e] = -1;
-      if (i < i1) {
-        nj[e] = no[i];
-        rk[e] = atomicAdd(&cnt[nj[e]], 1u);
-      }
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = i0 + e * kStreamThreads + threadIdx.x;
+    pk[e] = 0xffffffffu;
+    if (i < i1) {
+      const unsigned int j = no[i];
+      pk[e] = (j << 16) | atomicAdd(&cnt[j], 1u);
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < M; j += kStreamThreads)
-      base[j] = cnt[j] ? atomicAdd(&gcur[(int64_t)t * M + j], cnt[j]) : 0u;
-    __syncthreads();
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < M; j += kStreamThreads)
+    base[j] = cnt[j] ? atomicAdd(&gcur[(int64_t)t * M + j], cnt[j]) : 0u;
+  __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t i = s0 + e * kStreamThreads + threadIdx.x;
-      if (nj[e] >= 0) {
-        const int64_t pos = noff[nj[e]] + base[nj[e]] + rk[e];
-        pm[pos] = (int32_t)i;
-        for (int l = 0; l < klevs; ++l)
-          Kperm[((int64_t)l * T + t) * N + pos] = P[((int64_t)t * L + klev0 + l) * N + i];
-      }
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = i0 + e * kStreamThreads + threadIdx.x;
+    if (pk[e] != 0xffffffffu) {
+      const unsigned int j = pk[e] >> 16;
+      const int64_t pos = noff[j] + base[j] + (pk[e] & 0xffffu);
+      pm[pos] = (int32_t)i;
+      for (int l = 0; l < klevs; ++l)
+        Kperm[((int64_t)l * T + t) * N + pos] = P[((int64_t)t * L + klev0 + l) * N + i];
     }
-    __syncthreads();
   }
 }
 
@@ -2341,6 +2345,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       RPT_HIP(hipMemcpyAsync(dnoff.p, noff.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
       RPT_HIP(hipMemsetAsync(gcur.p, 0, (size_t)T * M * 4, st));
       // nodes of the next level small enough for the wave kernel: hand it their keys in perm order
+      // measured: carrying the keys through the counting sort is store-rate bound (2.6 ms vs the
+      // 0.8 ms of gathers it saves at C2) -> off unless asked for
       if (getenv("RPT_KPERM") && (N >> streamed) + 1 <= kWCap) {
         kperm_levs = Lused - streamed < kWRmax ? Lused - streamed : kWRmax;
         if (kperm_levs > 0) RPT_TRY(Kperm.alloc((size_t)kperm_levs * T * N));
@@ -2423,7 +2429,10 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         RPT_TRY(Kleaf.ensure((size_t)T * N));
         hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
                            st, cur, nxt, F, Kleaf.p, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
-                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, ovf.p + 1, ovf.p);
+                           (kperm_levs > 0 && level == streamed && b == 0) ? Kperm.p
+                                                                           : (const TK*)nullptr,
+                           streamed, kperm_levs, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
+                           tie_count, ovf.p + 1, ovf.p);
         unsigned int novf = 0;
         RPT_HIP(hipMemcpyAsync(&novf, ovf.p, 4, hipMemcpyDeviceToHost, st));
         RPT_HIP(stream_sync(st));
