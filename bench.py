@@ -46,11 +46,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--npoints", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--dim", dest="d", type=int, default=128)
     ap.add_argument("--trees", type=int, default=32)
     ap.add_argument("--min-leaf", type=int, default=128)
-    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--knn-k", dest="k", type=int, default=10)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--mode", choices=["auto", "exact", "mfma"], default="mfma",
                     help="projection kernel of the timed build: mfma = the north-star MFMA tile "
@@ -65,11 +65,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # rehearsal switch: several ranks on ONE GPU (RCCL refuses duplicate devices, so the
+    # collective goes over gloo); never used by the driver
+    one_gpu = os.environ.get("RPT_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import rptree_amd as rp
     from rptree_amd import _lib
@@ -95,7 +103,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if one_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         ctx.sync()
         torch.cuda.synchronize()
 
@@ -119,9 +130,15 @@ def main():
         if world == 1:
             return ids_l, dist_l, cnt_l
         ctx.sync()
-        dist.all_gather_into_tensor(ids_g, ids_l)        # RCCL over xGMI: nq*k*(4+8)+nq*4 B/rank
-        dist.all_gather_into_tensor(dist_g, dist_l)
-        dist.all_gather_into_tensor(cnt_g, cnt_l)
+        if one_gpu:                                       # gloo rehearsal: stage through the host
+            for g_, l_ in ((ids_g, ids_l), (dist_g, dist_l), (cnt_g, cnt_l)):
+                parts = [torch.empty_like(l_, device="cpu") for _ in range(world)]
+                dist.all_gather(parts, l_.cpu())
+                g_.copy_(torch.stack(parts))
+        else:
+            dist.all_gather_into_tensor(ids_g, ids_l)    # RCCL over xGMI: nq*k*(4+8)+nq*4 B/rank
+            dist.all_gather_into_tensor(dist_g, dist_l)
+            dist.all_gather_into_tensor(cnt_g, cnt_l)
         torch.cuda.synchronize()
         _lib.check(L_.rpt_knn_merge_dev(ctx._h, ids_g.data_ptr(), dist_g.data_ptr(),
                                         cnt_g.data_ptr(), world, nq, k, flags, ids_o.data_ptr(),
@@ -206,7 +223,7 @@ def main():
     leaf_flip_rate = flips / float(nt_cmp * N)
     alt.close()
 
-    tt = torch.tensor([t_build, t_knn], dtype=torch.float64, device=dev)
+    tt = torch.tensor([t_build, t_knn], dtype=torch.float64, device="cpu" if one_gpu else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t_build, t_knn = float(tt[0]), float(tt[1])
@@ -276,6 +293,18 @@ def main():
         bytes_per_launch = N * d * 8 + d * avg_cols * 8 + N * avg_cols * 8
         avg_ms = p_ms / max(p_n, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic of the same kernel from the PMC passes committed under profiles/
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per MI355X_MICROARCH.md); only
+        # valid for the exact configuration it was measured on, otherwise null
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            c = pj["config"]
+            kname = "proj_mfma_fast" if args.mode == "mfma" else "proj_exact_lds"
+            if (c["N"], c["d"], c["cols"]) == (N, d, int(round(avg_cols))) and world == 1:
+                traffic = pj[kname]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "forest-build vectors/s (1M x 128 dense, 32 trees); kNN queries/s and "
                       "recall@10 in `knn` / `recall_at_10`",
@@ -297,7 +326,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "projection batch (proj_exact / proj_mfma), "
                                                    "%.1f hyperplanes per launch" % avg_cols,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": p_n,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": cpu,
