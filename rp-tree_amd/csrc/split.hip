@@ -1463,10 +1463,17 @@ __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __res
 // per-level node table from the min/max gathered so far. grid = (ceil(M/64), T)
 template <class TK>
 __global__ void stream_setup(int64_t N, int level, int M, const unsigned long long* cmin,
-                             const unsigned long long* cmax, SNode<TK>* nodes_out) {
+                             const unsigned long long* cmax, SNode<TK>* nodes_out,
+                             unsigned int* poolcur, unsigned long long* cmin_next,
+                             unsigned long long* cmax_next) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (j >= M) return;
+  if (j == 0) poolcur[t] = 0;
+  cmin_next[(int64_t)t * 2 * M + 2 * j] = ~0ULL;      // children of this level's nodes
+  cmin_next[(int64_t)t * 2 * M + 2 * j + 1] = ~0ULL;
+  cmax_next[(int64_t)t * 2 * M + 2 * j] = 0ULL;
+  cmax_next[(int64_t)t * 2 * M + 2 * j + 1] = 0ULL;
   SNode<TK> a;
   int64_t n = N;
   for (int b = level - 1; b >= 0; --b) {
@@ -2264,6 +2271,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     for (auto& b : mm) RPT_TRY(b.alloc((size_t)T * 2 * kStreamMaxNodes));
     RPT_HIP(hipMemsetAsync(node_of.p, 0, (size_t)T * N * 2, st));
     RPT_HIP(hipMemsetAsync(ghist.p, 0, (size_t)T * kStreamBins * 4, st));
+    RPT_HIP(hipMemsetAsync(bigmid.p, 0, 4, st));
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblk > (N + 4095) / 4096) nblk = (N + 4095) / 4096;
     if (nblk < (N + 65534) / 65535) nblk = (N + 65534) / 65535;  // 16-bit LDS counters
@@ -2283,13 +2291,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       const int M = 1 << level;
       const int has_next = level + 1 < Lstream ? 1 : 0;
       hipLaunchKernelGGL(stream_setup<TK>, dim3((unsigned)((M + 63) / 64), (unsigned)T), dim3(64),
-                         0, st, N, level, M, cmin, cmax, snodes.p);
-      RPT_HIP(hipMemsetAsync(poolcur.p, 0, (size_t)T * 4, st));
-      RPT_HIP(hipMemsetAsync(bigmid.p, 0, 4, st));
-      if (has_next) {
-        hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cminN, mmn, ~0ULL);
-        hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cmaxN, mmn, 0ULL);
-      }
+                         0, st, N, level, M, cmin, cmax, snodes.p, poolcur.p, cminN, cmaxN);
       hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
                          level, M, per, snodes.p, ghist.p);
       if (stream_bins(M) <= 128)
@@ -2298,10 +2300,6 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       else
         hipLaunchKernelGGL(stream_pick<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T), dim3(256), 0,
                            st, M, snodes.p, ghist.p, poolcur.p, bigmid.p);
-      unsigned int nbig = 0;
-      RPT_HIP(hipMemcpyAsync(&nbig, bigmid.p, 4, hipMemcpyDeviceToHost, st));
-      RPT_HIP(stream_sync(st));
-      if (nbig) break;  // pivot bin larger than LDS: the gather path takes over at this level
       hipLaunchKernelGGL(stream_assign<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
                          level, M, per, has_next, snodes.p, pool, cminN, cmaxN);
       const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
@@ -2319,6 +2317,15 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       std::swap(cmin, cminN);
       std::swap(cmax, cmaxN);
       streamed = level + 1;
+    }
+    {
+      // a pivot bin larger than LDS (heavy ties / extreme outliers) at ANY level: the levels
+      // after it worked on inconsistent node ids (harmless, all accesses stay in bounds) and the
+      // whole forest is rebuilt by the general path, which has the fallbacks.  Checked once.
+      unsigned int nbig = 0;
+      RPT_HIP(hipMemcpyAsync(&nbig, bigmid.p, 4, hipMemcpyDeviceToHost, st));
+      RPT_HIP(stream_sync(st));
+      if (nbig) streamed = 0;
     }
     HT("stream levels");
     if (streamed > 0) {
