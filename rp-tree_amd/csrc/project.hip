@@ -616,6 +616,72 @@ __global__ __launch_bounds__(256) void proj_csr(const int64_t* __restrict__ rowp
   if (c < ncol) P[(int64_t)c * ldp + row] = acc;
 }
 
+// ---------------------------------------------------------------------------------------
+// CSR fast path: the 16-hyperplane tile Rt[d][16] lives in LDS (d*16*sizeof(T) <= 128 KB, e.g.
+// 100 KB for the 784-dim C3 rows), one workgroup of 16 waves per CU.  A wave works on 4 rows
+// (16 lanes each, lane = hyperplane); the row's nonzeros are fetched 16 at a time, coalesced
+// and in REVERSE order, then broadcast one by one inside the 16-lane group (width-16 shuffle):
+// every lane accumulates `acc = val*r[col] + acc` from the last nonzero to the first — the
+// reference's innerSS order (Internal.hs:353-366).  Padding entries (val 0) add an exact zero.
+// ---------------------------------------------------------------------------------------
+// broadcast lane U of every 16-lane DPP row to the whole row (gfx90a+ row_newbcast): a VALU
+// move — the width-16 __shfl goes through ds_bpermute, i.e. the LDS pipe this kernel is bound by
+template <int U>
+__device__ inline int bcast16(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false);
+}
+template <int U>
+__device__ inline float bcast16(float x) {
+  return __int_as_float(bcast16<U>(__float_as_int(x)));
+}
+template <int U>
+__device__ inline double bcast16(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = bcast16<U>((int)(b & 0xffffffffLL)), hi = bcast16<U>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <class T, int U>
+__device__ inline void csr_terms(int mycol, T myval, const T* rl, int c, T& acc) {
+  const int cu = bcast16<U>(mycol);
+  const T vu = bcast16<U>(myval);
+  acc = add_rn(mul_rn(vu, rl[cu * 16 + c]), acc);
+  if constexpr (U < 15) csr_terms<T, U + 1>(mycol, myval, rl, c, acc);
+}
+
+template <class T>
+__global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const T* __restrict__ val, int64_t n, int d,
+                                                     const T* __restrict__ Rt /*[d][16]*/,
+                                                     T* __restrict__ P, int64_t ldp, int ncol) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* rl = reinterpret_cast<T*>(smem_raw);
+  for (int i = threadIdx.x; i < d * 16; i += blockDim.x) rl[i] = Rt[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15;
+  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t nquads = (n + 3) / 4;
+  for (int64_t qd = wave_global; qd < nquads; qd += wave_stride) {
+    const int64_t row = qd * 4 + (lane >> 4);
+    const bool rv = row < n;
+    const int64_t a = rv ? rowptr[row] : 0, b = rv ? rowptr[row + 1] : 0;
+    T acc = (T)0;
+    int64_t j0 = b;
+    while (__any(j0 > a)) {
+      const int64_t idx = j0 - 1 - c;
+      const bool ok = idx >= a && j0 > a;
+      const int mycol = ok ? col[idx] : 0;
+      const T myval = ok ? val[idx] : (T)0;
+      csr_terms<T, 0>(mycol, myval, rl, c, acc);
+      j0 -= 16;
+    }
+    if (rv && c < ncol) P[(int64_t)c * ldp + row] = acc;
+  }
+}
+
 template <class TIn, class TC>
 int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
                     TC* P) {
@@ -723,14 +789,24 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
   DevBuf<T> Rt;
   RPT_TRY(Rt.alloc((size_t)nblk * d * CB));
   hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
+  const size_t tile = (size_t)d * CB * sizeof(T);
+  const bool lds_path = tile <= 128 * 1024 && !getenv("RPT_CSR_L2");
+  if (lds_path && tile > 64 * 1024)
+    RPT_HIP(hipFuncSetAttribute((const void*)proj_csr_lds<T>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile));
   const int64_t blocks = (n + 15) / 16;  // 256 threads = 4 waves x 4 rows
   for (int b = 0; b < nblk; ++b) {
     const int c0 = b * CB;
     const int ncol = C - c0 < CB ? C - c0 : CB;
     ProfScope ps(ctx, RPT_PROF_PROJECT);
-    hipLaunchKernelGGL((proj_csr<T, CB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                       ds->rowptr, ds->col, (const T*)ds->val, n, Rt.p + (size_t)b * d * CB,
-                       P + (int64_t)c0 * n, n, ncol);
+    if (lds_path)
+      hipLaunchKernelGGL(proj_csr_lds<T>, dim3((unsigned)ctx->n_cu), dim3(1024), tile, ctx->stream,
+                         ds->rowptr, ds->col, (const T*)ds->val, n, d, Rt.p + (size_t)b * d * CB,
+                         P + (int64_t)c0 * n, n, ncol);
+    else
+      hipLaunchKernelGGL((proj_csr<T, CB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                         ds->rowptr, ds->col, (const T*)ds->val, n, Rt.p + (size_t)b * d * CB,
+                         P + (int64_t)c0 * n, n, ncol);
   }
   RPT_HIP(hipGetLastError());
   RPT_HIP(stream_sync(ctx->stream));

@@ -1,0 +1,52 @@
+"""C3-shaped check (BASELINE configs[2]): sparse 784-dim rows (density 0.19, values U(0,1]),
+hyperplane density by rpTreeCfg.  Times the build, verifies validity and the cut property."""
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/rp-tree_amd/python')
+import numpy as np
+import rptree_amd as rp
+from rptree_amd import _lib
+import ctypes as C
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+d, dens, min_leaf = 784, 0.19, 128
+rng = np.random.default_rng(1)
+cols, counts = [], []
+for r0 in range(0, n, 20000):            # Bernoulli support per entry (sparse, Gen.hs:178-195)
+    m = rng.random((min(20000, n - r0), d)) < dens
+    counts.append(m.sum(axis=1))
+    cols.append(np.nonzero(m)[1].astype(np.int32))
+col = np.concatenate(cols)
+rowptr = np.zeros(n + 1, dtype=np.int64); rowptr[1:] = np.cumsum(np.concatenate(counts))
+val = 1.0 - rng.random(rowptr[-1])
+cfg = rp.rpTreeCfg(min_leaf, n, d)
+ctx = rp.default_context()
+ds = rp.Dataset.csr(ctx, rowptr, col, val, d)
+_, R = rp.gen.forest_hyperplanes(5, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
+L_ = _lib.lib()
+for it in range(3):
+    _lib.check(L_.rpt_prof_reset(ctx._h)); _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+    t0 = time.perf_counter()
+    f = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)
+    ctx.sync(); dt = time.perf_counter() - t0
+    ms, cnt = C.c_double(), C.c_int64()
+    _lib.check(L_.rpt_prof_get(ctx._h, 0, C.byref(ms), C.byref(cnt)))
+    print("build %.2f ms  (N=%d nnz=%d T=%d L=%d)  projection %.2f ms in %d launches" % (dt*1e3, n, rowptr[-1], T, cfg.fpMaxTreeDepth, ms.value, cnt.value))
+    if it < 2: f.close()
+for t in range(T):
+    assert np.array_equal(np.bincount(f.perm[t], minlength=n), np.ones(n, dtype=np.int64))
+P = f.proj()
+topo = [r for r in f.topology() if not r[4]]
+for (level, heap, off, m, _) in topo[:10] + topo[-10:]:
+    for t in range(T):
+        nh = m // 2
+        left = P[t, level][f.perm[t, off:off+nh]]; right = P[t, level][f.perm[t, off+nh:off+m]]
+        assert left.max() <= f.thr[t, heap] == right.min()
+# projection exactness vs the reference order on a few (row, hyperplane) pairs
+for (t, l, i) in [(0, 0, 0), (1, 3, 17), (T-1, cfg.fpMaxTreeDepth-1, n-1)]:
+    a, b = rowptr[i], rowptr[i+1]
+    acc = 0.0
+    for j in range(b-1, a-1, -1):
+        if R[t, l, col[j]] != 0: acc = val[j] * R[t, l, col[j]] + acc
+    assert P[t, l, i] == acc, (P[t, l, i], acc)
+print("valid; stats", f.stats())
