@@ -1454,9 +1454,21 @@ __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __res
     mn = a < mn ? a : mn;
     mx = b > mx ? b : mx;
   }
-  if ((threadIdx.x & 63) == 0 && mn != ~0ULL) {
-    atomicMin(&cmin[t], mn);
-    atomicMax(&cmax[t], mx);
+  __shared__ unsigned long long smn[kStreamThreads / 64], smx[kStreamThreads / 64];
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic pair per block: all waves hit the same two words
+    for (int w = 1; w < kStreamThreads / 64; ++w) {
+      mn = smn[w] < mn ? smn[w] : mn;
+      mx = smx[w] > mx ? smx[w] : mx;
+    }
+    if (mn != ~0ULL) {
+      atomicMin(&cmin[t], mn);
+      atomicMax(&cmax[t], mx);
+    }
   }
 }
 
@@ -1465,11 +1477,12 @@ template <class TK>
 __global__ void stream_setup(int64_t N, int level, int M, const unsigned long long* cmin,
                              const unsigned long long* cmax, SNode<TK>* nodes_out,
                              unsigned int* poolcur, unsigned long long* cmin_next,
-                             unsigned long long* cmax_next) {
+                             unsigned long long* cmax_next, unsigned int* big_list) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (j >= M) return;
   if (j == 0) poolcur[t] = 0;
+  if (j == 0 && t == 0) big_list[0] = 0;
   cmin_next[(int64_t)t * 2 * M + 2 * j] = ~0ULL;      // children of this level's nodes
   cmin_next[(int64_t)t * 2 * M + 2 * j + 1] = ~0ULL;
   cmax_next[(int64_t)t * 2 * M + 2 * j] = 0ULL;
@@ -1772,12 +1785,18 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
     const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
     int has_next, const SNode<TK>* __restrict__ nd, const int32_t* __restrict__ pool,
     unsigned long long* cmin_next, unsigned long long* cmax_next, int64_t heap0, double* thr,
-    double* mglo, double* mghi, int64_t nodes, unsigned long long* tie_count, int wave_max) {
+    double* mglo, double* mghi, int64_t nodes, unsigned long long* tie_count, int wave_max,
+    unsigned int* big_list /* [0] = count, then (t << 16 | j) entries */) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6), t = blockIdx.y, lane = threadIdx.x & 63;
   if (j >= M) return;
   const SNode<TK> a = nd[(int64_t)t * M + j];
   const int cMid = a.cMid;
-  if (cMid <= 0 || cMid > wave_max || cMid > 128) return;
+  if (cMid > wave_max || cMid > 128) {  // leave it to the block-level kernel
+    if (lane == 0 && cMid <= kSmallCap)
+      big_list[1 + atomicAdd(&big_list[0], 1u)] = ((unsigned int)t << 16) | (unsigned int)j;
+    return;
+  }
+  if (cMid <= 0) return;
   Keys<TK> K{P + (int64_t)t * L * N, N, level, nullptr};
   const int32_t* m = pool + (int64_t)t * N + a.midoff;
   // at most 128 points: two per lane (the 4-register instantiation of wave_bitonic proved
@@ -1860,7 +1879,7 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
   }
 }
 
-// block path: pivot bins of 129..kSmallCap points. grid = (M, T), 256 threads, dynamic LDS
+// block path: pivot bins of 129..kSmallCap points. persistent grid of 256-thread blocks, dynamic LDS
 template <class TK>
 __global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
                                                   uint16_t* __restrict__ node_of, int64_t N, int L,
@@ -1871,12 +1890,15 @@ __global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
                                                   unsigned long long* cmax_next, int64_t heap0,
                                                   double* thr, double* mglo, double* mghi,
                                                   int64_t nodes, unsigned long long* tie_count,
-                                                  int wave_max) {
+                                                  const unsigned int* big_list) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int j = blockIdx.x, t = blockIdx.y;
+  // persistent grid over the nodes flagged by stream_mid_wave (usually none)
+  const unsigned int nflag = big_list[0];
+  for (unsigned int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
+  __syncthreads();
+  const int t = (int)(big_list[1 + fi] >> 16), j = (int)(big_list[1 + fi] & 0xffffu);
   const SNode<TK> a = nd[(int64_t)t * M + j];
   const int cMid = a.cMid;
-  if (cMid <= wave_max || cMid > kSmallCap) return;
   const int np = next_pow2(cMid);
   TK* skey = reinterpret_cast<TK*>(smem);
   int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
@@ -1932,6 +1954,7 @@ __global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
     mglo[h] = (double)vlo;
     mghi[h] = (double)vhi;
     if (nh > 0 && !(vlo < vthr)) atomicAdd(tie_count, 1ULL);
+  }
   }
 }
 
@@ -2259,7 +2282,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   int kperm_levs = 0;
   if (Lstream > 0) {
     DevBuf<uint16_t> node_of;
-    DevBuf<unsigned int> ghist, poolcur, bigmid, gcur;
+    DevBuf<unsigned int> ghist, poolcur, bigmid, gcur, biglist;
     DevBuf<SNode<TK>> snodes;
     DevBuf<unsigned long long> mm[4];  // cmin/cmax ping-pong
     DevBuf<int64_t> dnoff;
@@ -2267,13 +2290,15 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     RPT_TRY(ghist.alloc((size_t)T * kStreamBins));
     RPT_TRY(poolcur.alloc((size_t)T));
     RPT_TRY(bigmid.alloc(1));
+    RPT_TRY(biglist.alloc((size_t)T * kStreamMaxNodes + 1));
     RPT_TRY(snodes.alloc((size_t)T * kStreamMaxNodes));
     for (auto& b : mm) RPT_TRY(b.alloc((size_t)T * 2 * kStreamMaxNodes));
     RPT_HIP(hipMemsetAsync(node_of.p, 0, (size_t)T * N * 2, st));
     RPT_HIP(hipMemsetAsync(ghist.p, 0, (size_t)T * kStreamBins * 4, st));
     RPT_HIP(hipMemsetAsync(bigmid.p, 0, 4, st));
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
-    if (nblk > (N + 4095) / 4096) nblk = (N + 4095) / 4096;
+    // every block flushes up to one atomic per histogram bin: keep >= 32768 points per block
+    if (nblk > (N + 32767) / 32768) nblk = (N + 32767) / 32768;
     if (nblk < (N + 65534) / 65535) nblk = (N + 65534) / 65535;  // 16-bit LDS counters
     if (nblk < 1) nblk = 1;
     const int64_t per = (N + nblk - 1) / nblk;
@@ -2291,7 +2316,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       const int M = 1 << level;
       const int has_next = level + 1 < Lstream ? 1 : 0;
       hipLaunchKernelGGL(stream_setup<TK>, dim3((unsigned)((M + 63) / 64), (unsigned)T), dim3(64),
-                         0, st, N, level, M, cmin, cmax, snodes.p, poolcur.p, cminN, cmaxN);
+                         0, st, N, level, M, cmin, cmax, snodes.p, poolcur.p, cminN, cmaxN, biglist.p);
       hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
                          level, M, per, snodes.p, ghist.p);
       if (stream_bins(M) <= 128)
@@ -2304,15 +2329,14 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
                          level, M, per, has_next, snodes.p, pool, cminN, cmaxN);
       const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
       const int wave_max = getenv("RPT_NO_WMID") ? 0 : (getenv("RPT_WMID_MAX") ? atoi(getenv("RPT_WMID_MAX")) : 128);
-      if (wave_max)
-        hipLaunchKernelGGL(stream_mid_wave<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T),
+      hipLaunchKernelGGL(stream_mid_wave<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T),
                            dim3(256), 0, st, P, node_of.p, N, L, level, M, has_next, snodes.p, pool,
                            cminN, cmaxN, (int64_t)M - 1, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
-                           tie_count, wave_max);
-      hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)M, (unsigned)T), dim3(256), smem, st, P,
+                           tie_count, wave_max, biglist.p);
+      hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)ctx->n_cu), dim3(256), smem, st, P,
                          node_of.p, N, L, level, M, has_next, snodes.p, pool, cminN, cmaxN,
                          (int64_t)M - 1, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count,
-                         wave_max);
+                         biglist.p);
       RPT_HIP(hipGetLastError());
       std::swap(cmin, cminN);
       std::swap(cmax, cmaxN);
