@@ -28,7 +28,7 @@ __all__ = [
     "fromVectorSv", "fromListDv", "fromVectorDv", "forestBatch", "treeBatch", "knn", "knnBatch",
     "candidates", "recallWith", "rpTreeCfg", "RPTreeConfig", "leaves", "levels", "points",
     "treeSize", "leafSizes", "metricL2", "inner", "project", "splitSegments", "topology",
-    "bruteKnn", "RPTError",
+    "bruteKnn", "RPTError", "forest", "tree", "saveForest", "loadForest", "importForest",
 ]
 
 _DT = {np.dtype(np.float64): RPT_F64, np.dtype(np.float32): RPT_F32}
@@ -362,6 +362,42 @@ def forestBatch(seed, maxd, minl, ntrees, pnz, dim, src, *, ctx=None, mode=RPT_P
 def treeBatch(seed, maxDepth, minLeaf, pnz, dim, src, **kw):
     """Batch.hs:29-41 (= forestBatch with one tree: same draw order for a single tree)."""
     return forestBatch(seed, maxDepth, minLeaf, 1, pnz, dim, src, **kw)
+
+
+def forest(seed, maxd, minl, ntrees, chunksize, pnz, dim, src, **kw):
+    """Conduit.hs:104-121 `forest` (streaming build), SURVEY §8(f)-2: the source is SUNK and
+    the forest is built in one batch.  This is NOT the reference's chunk-wise semantics (chunk-
+    local medians averaged into the thresholds, Internal.hs:274-285, which is inherently
+    sequential and drops data when a chunk half is empty): same signature, same
+    hyperplanes (same draw order, Conduit.hs:116-118), batch thresholds.  `chunksize` is
+    accepted for signature compatibility and ignored."""
+    del chunksize
+    xs = list(src) if not isinstance(src, (np.ndarray, Dataset, tuple)) else src
+    return forestBatch(seed, maxd, minl, ntrees, pnz, dim, xs, **kw)
+
+
+def tree(seed, maxDepth, minLeaf, chunksize, pnz, dim, src, **kw):
+    """Conduit.hs:58-72 `tree`: see `forest`."""
+    return forest(seed, maxDepth, minLeaf, 1, chunksize, pnz, dim, src, **kw)
+
+
+def saveForest(path, forest_):
+    """Flat on-disk format: hyperplanes, perm and node arrays in one .npz —
+    a 10M-point forest needs no boxed `Embed`s.  The counterpart of serialiseRPForest
+    (Internal.hs:185-188) for the flat layout; the data itself is not stored."""
+    np.savez_compressed(path, R=forest_.R, min_leaf=forest_.min_leaf, N=forest_.N,
+                        perm=forest_.perm, thr=forest_.thr, mglo=forest_.mglo, mghi=forest_.mghi)
+
+
+def loadForest(path, data, ctx=None):
+    """deserialiseRPForest (Internal.hs:191-196) for the flat format: back into HBM via
+    rpt_forest_import.  `data` is the point set the forest was built on."""
+    ctx = ctx or (data.ctx if isinstance(data, Dataset) else default_context())
+    z = np.load(path)
+    ds = Dataset.of(ctx, data)
+    if int(z["N"]) != ds.n:
+        raise ValueError("forest was built on %d points, data has %d" % (int(z["N"]), ds.n))
+    return importForest(ctx, ds, z["R"], int(z["min_leaf"]), z["perm"], z["thr"], z["mglo"], z["mghi"])
 
 
 def importForest(ctx, data, R, min_leaf, perm, thr, mglo, mghi):

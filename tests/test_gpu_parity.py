@@ -356,3 +356,27 @@ def test_knn_merge_shards(rp, ctx, small_forest, oracle):
     full = rp.knnBatch(k, f, Q)
     assert np.array_equal(oi.cpu().numpy(), full[0])
     assert np.array_equal(od.cpu().numpy(), full[1])
+
+
+def test_forest_save_load_roundtrip(rp, ctx, small_forest, tmp_path):
+    X, f, fo, Q = small_forest
+    path = str(tmp_path / "forest.npz")
+    rp.saveForest(path, f)
+    g = rp.loadForest(path, X, ctx=ctx)
+    assert np.array_equal(g.perm, f.perm) and np.array_equal(g.thr, f.thr, equal_nan=True)
+    a, b = rp.knnBatch(10, f, Q), rp.knnBatch(10, g, Q)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    off_a, ids_a = rp.candidatesBatch(f, Q)
+    off_b, ids_b = rp.candidatesBatch(g, Q)
+    assert np.array_equal(off_a, off_b) and np.array_equal(ids_a, ids_b)
+
+
+def test_streaming_forest_api_sinks_then_batches(rp, ctx, oracle):
+    # Conduit.hs:104-121 signature; batch semantics (documented difference)
+    X = oracle.data_circle2d2(3, 3000)
+    cfg = rp.rpTreeCfg(20, 3000, 2)
+    src = (rp.Embed(rp.fromListDv(x), ()) for x in X)          # a one-shot source
+    tts = rp.forest(3, cfg.fpMaxTreeDepth, 20, 4, cfg.fpDataChunkSize, 1.0, 2, src, ctx=ctx)
+    ref = rp.forestBatch(3, cfg.fpMaxTreeDepth, 20, 4, 1.0, 2, X, ctx=ctx)
+    assert np.array_equal(tts.perm, ref.perm)
+    assert all(rp.treeSize(t) == 3000 for t in tts)
