@@ -380,3 +380,53 @@ def test_streaming_forest_api_sinks_then_batches(rp, ctx, oracle):
     ref = rp.forestBatch(3, cfg.fpMaxTreeDepth, 20, 4, 1.0, 2, X, ctx=ctx)
     assert np.array_equal(tts.perm, ref.perm)
     assert all(rp.treeSize(t) == 3000 for t in tts)
+
+
+# ------------------------------------------------------------------ fallback paths
+@pytest.mark.parametrize("n", [1000, 1800, 3000])
+def test_heavy_ties_take_the_fallback_paths(rp, ctx, oracle, n):
+    """Pivot bins larger than a wave slab (wsub -> subtree_kernel), than the block LDS
+    (streaming -> general path) ... all must still reproduce the reference order."""
+    rng = np.random.default_rng(n)
+    X = np.round(rng.standard_normal((n, 3)), 0)           # ~7 distinct values per coordinate
+    X[: n // 3] = 1.0                                      # one third identical points
+    R, _ = oracle.forest_hyperplanes(11, 3, 7, 0.7, 3)
+    fo = oracle.forest_build_dense(X, R, 8)
+    f = rp.forestBatch(0, 7, 8, 3, 0, 3, X, ctx=ctx, hyperplanes=R)
+    assert_forest_equal(f, fo)
+    off, ids = rp.candidatesBatch(f, X[:5])
+    for i in range(5):
+        for t in range(3):
+            assert np.array_equal(ids[off[i * 3 + t]:off[i * 3 + t + 1]],
+                                  oracle.candidates_dense(fo, X[i], t))
+
+
+def test_knn_general_path_large_k_and_many_ranges(rp, ctx, small_forest, oracle):
+    X, f, fo, Q = small_forest
+    ids, dist, cnt = rp.knnBatch(100, f, Q[:8])              # k > 64: bitonic-merge path
+    for i in range(8):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], 100)
+        assert np.array_equal(ids[i, :cnt[i]], wi)
+    # more leaf ranges per query than the fused kernel's LDS slab (512): 600 one-level trees
+    Xs = oracle.data_normal_dense2(5, 300, 4)
+    R, _ = oracle.forest_hyperplanes(3, 600, 1, 1.0, 4)
+    fs = rp.forestBatch(0, 1, 10, 600, 0, 4, Xs, ctx=ctx, hyperplanes=R)
+    fos = oracle.forest_build_dense(Xs, R, 10)
+    ids, dist, cnt = rp.knnBatch(5, fs, Xs[:4])
+    for i in range(4):
+        wi, wd = oracle.knn_dense(fos, Xs, Xs[i], 5)
+        assert np.array_equal(ids[i, :cnt[i]], wi)
+
+
+def test_knn_f32_data(rp, ctx, oracle):
+    n, d = 5000, 24
+    X = oracle.data_normal_dense2(8, n, d).astype(np.float32)
+    cfg = rp.rpTreeCfg(30, n, d)
+    f = rp.forestBatch(4, cfg.fpMaxTreeDepth, 30, 4, cfg.fpProjNzDensity, d, X, ctx=ctx)
+    ids, dist, cnt = rp.knnBatch(5, f, X[:50])
+    assert (ids[:, 0] == np.arange(50)).all() and (dist[:, 0] == 0).all()
+    bi, bd = rp.bruteKnn(f, X[:50], 5)
+    # every returned neighbour's distance is a true distance (f32 arithmetic)
+    ref = np.sqrt(((X[ids[:, 1]].astype(np.float64) - X[:50].astype(np.float64)) ** 2).sum(1))
+    assert np.allclose(dist[:, 1], ref, rtol=1e-5)
+    assert (bi[:, 0] == np.arange(50)).all()
