@@ -115,6 +115,44 @@ hipError_t stream_sync(hipStream_t s) {
   return e;
 }
 
+constexpr size_t kPinBytes = 8u << 20;
+
+void* pin_alloc(rpt_ctx* ctx, size_t bytes) {
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (bytes > kPinBytes) return nullptr;
+  if (!ctx->pin) {
+    if (hipHostMalloc((void**)&ctx->pin, kPinBytes, hipHostMallocDefault) != hipSuccess) {
+      ctx->pin = nullptr;
+      return nullptr;
+    }
+    ctx->pin_cap = kPinBytes;
+    ctx->pin_off = 0;
+  }
+  if (ctx->pin_off + bytes > ctx->pin_cap) (void)ctx_sync(ctx);  // in-flight copies drain first
+  void* r = ctx->pin + ctx->pin_off;
+  ctx->pin_off += bytes;
+  return r;
+}
+
+int32_t upload_async(rpt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (bytes == 0) return RPT_OK;
+  void* stage = pin_alloc(ctx, bytes);
+  if (!stage) {
+    RPT_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RPT_HIP(stream_sync(ctx->stream));
+    return RPT_OK;
+  }
+  std::memcpy(stage, src_host, bytes);
+  RPT_HIP(hipMemcpyAsync(dst_dev, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return RPT_OK;
+}
+
+hipError_t ctx_sync(rpt_ctx* ctx) {
+  const hipError_t e = stream_sync(ctx->stream);
+  ctx->pin_off = 0;
+  return e;
+}
+
 void dev_trim() {
   (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -203,6 +241,7 @@ int32_t rpt_ctx_destroy(rpt_ctx* ctx) {
     prof_resolve(ctx);
     (void)hipStreamDestroy(ctx->stream);
   }
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
   dev_trim();
   delete ctx;
   return RPT_OK;
@@ -442,11 +481,7 @@ int32_t rpt_topology(int64_t n, int32_t max_depth, int32_t min_leaf, int64_t* ou
 // ---- projection -----------------------------------------------------------------------
 static int32_t upload_R(rpt_ctx* ctx, const double* R_host, size_t count, DevBuf<double>& buf) {
   RPT_TRY(buf.alloc(count));
-  if (count) {
-    RPT_HIP(hipMemcpyAsync(buf.p, R_host, count * 8, hipMemcpyHostToDevice, ctx->stream));
-    RPT_HIP(stream_sync(ctx->stream));
-  }
-  return RPT_OK;
+  return upload_async(ctx, buf.p, R_host, count * 8);
 }
 
 int32_t rpt_project_dev(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t C,

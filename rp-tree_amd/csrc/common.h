@@ -111,6 +111,9 @@ struct rpt_prof_span {
 struct rpt_ctx {
   int32_t device = 0;
   hipStream_t stream = nullptr;
+  // pinned bump arena for small asynchronous host<->device transfers (api.hip: pin_alloc)
+  char* pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
   int64_t last_candidates = 0;
   int32_t n_cu = 256;
   bool prof = false;
@@ -172,6 +175,16 @@ struct rpt_forest {
 };
 
 namespace rpt {
+
+// ---- pinned staging (api.hip) ------------------------------------------------------------
+// pin_alloc: `bytes` of pinned host memory that stays valid until the next ctx_sync (or until
+// the arena wraps, which synchronises the stream first).  nullptr if bytes exceeds the arena.
+void* pin_alloc(rpt_ctx* ctx, size_t bytes);
+// H2D copy ordered on the ctx stream that does NOT wait: the source is staged in the arena
+// (falls back to a synchronous copy for sources larger than the arena).
+int32_t upload_async(rpt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+// stream_sync + recycle the arena
+hipError_t ctx_sync(rpt_ctx* ctx);
 
 // ---- projection (project.hip) -----------------------------------------------------------
 // P_dev[C][n] (compute type) = R_dev[C][d] applied to every row of ds.  R_dev is a device

@@ -26,12 +26,14 @@
 //
 // Algorithmic HBM bytes per point per tree per level (SURVEY.md §8d lower bound: 16):
 //   big path: perm 4 + key gather 8 + key stash 8+8 + perm 4+4 = 36; small path: 4 + 8 + 4.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <limits>
+#include <list>
 
 #include "common.h"
 
@@ -755,13 +757,14 @@ template <class TK>
 __global__ __launch_bounds__(256) void wsub_kernel(
     const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
     TK* __restrict__ Kleaf, int64_t N, const TK* __restrict__ P, int L, int T, int level0,
-    int min_leaf, const Seg* __restrict__ segs, int S, const TK* __restrict__ Kperm, int klev0,
-    int klevs, double* thr, double* mglo, double* mghi, int64_t nodes,
-    unsigned long long* tie_count, unsigned int* ovf_flags, unsigned int* ovf_count) {
+    int min_leaf, const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
+    int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
+    unsigned int* ovf_count, const unsigned int* __restrict__ abort) {
   __shared__ WSlab slabs[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
   if (wg >= (int64_t)S * T) return;
+  if (abort && *abort) return;  // the streaming levels above are being rebuilt by the host
   const int si = (int)(wg % S), t = (int)(wg / S);
   WSlab& W = slabs[wave];
   const Seg sg = segs[si];
@@ -794,13 +797,8 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     const int M = 1 << depth;
     const int B = kWHist / M;
     Keys<TK> K{Pt, N, level, nullptr};
-    // ---- a. keys: coalesced from Kperm (perm order) when the host provided them ----
-    if (Kperm && level >= klev0 && level < klev0 + klevs) {
-      const TK* kp = Kperm + ((int64_t)(level - klev0) * T + t) * N + sg.off;
-#pragma unroll
-      for (int e = 0; e < kWE; ++e)
-        if (id[e] >= 0 && st[e] >= 0) key[e] = kp[e * 64 + lane];
-    } else {
+    // ---- a. keys of this level (gathered by id) ----
+    {
       const TK* Pl = Pt + (int64_t)level * N;
 #pragma unroll
       for (int e = 0; e < kWE; ++e)
@@ -1049,22 +1047,29 @@ __global__ __launch_bounds__(256) void wsub_kernel(
 
 // order one leaf bucket per wave: (key of the parent's level, earlier levels, id).  The bucket
 // (<= 128 points, two per lane) is sorted by a bitonic network over lane shuffles.
-// segs: leaf segments (identical for every tree); key level = leaf level - 1.
+// segs: leaf segments (identical for every tree); seg_info = leaf level | (index of the
+// wsub_kernel node that produced the leaf << 6): leaves of a node that kernel flagged as
+// overflowed are skipped (the host re-runs those nodes), key level = leaf level - 1.
 // grid = ceil(S*T/4) blocks of 256 threads.
 template <class TK>
 __global__ __launch_bounds__(256) void leaf_sort_kernel(int32_t* __restrict__ F,
                                                         const TK* __restrict__ Kleaf, int64_t N,
                                                         const TK* __restrict__ P, int L, int T,
                                                         const Seg* __restrict__ segs, int S,
-                                                        const int* __restrict__ seg_level) {
+                                                        const int* __restrict__ seg_info,
+                                                        const unsigned int* __restrict__ ovf_flags,
+                                                        const unsigned int* __restrict__ abort) {
   const int lane = threadIdx.x & 63;
   const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wg >= (int64_t)S * T) return;
+  if (abort && *abort) return;
   const int si = (int)(wg % S), t = (int)(wg / S);
   const Seg sg = segs[si];
   const int tn = sg.n;
   if (tn <= 1) return;
-  Keys<TK> K{P + (int64_t)t * L * N, N, seg_level[si] - 1, nullptr};
+  const int info = seg_info[si];
+  if (ovf_flags[info >> 6]) return;
+  Keys<TK> K{P + (int64_t)t * L * N, N, (info & 63) - 1, nullptr};
   int32_t* f = F + (int64_t)t * N + sg.off;
   const TK* kk = Kleaf + (int64_t)t * N + sg.off;
   const bool v0 = lane < tn, v1 = lane + 64 < tn;
@@ -1472,47 +1477,17 @@ __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __res
   }
 }
 
-// per-level node table from the min/max gathered so far. grid = (ceil(M/64), T)
+// bin geometry of one node from the min / max of its keys (hist and pick must agree bit for bit)
 template <class TK>
-__global__ void stream_setup(int64_t N, int level, int M, const unsigned long long* cmin,
-                             const unsigned long long* cmax, SNode<TK>* nodes_out,
-                             unsigned int* poolcur, unsigned long long* cmin_next,
-                             unsigned long long* cmax_next, unsigned int* big_list) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
-  if (j >= M) return;
-  if (j == 0) poolcur[t] = 0;
-  if (j == 0 && t == 0) big_list[0] = 0;
-  cmin_next[(int64_t)t * 2 * M + 2 * j] = ~0ULL;      // children of this level's nodes
-  cmin_next[(int64_t)t * 2 * M + 2 * j + 1] = ~0ULL;
-  cmax_next[(int64_t)t * 2 * M + 2 * j] = 0ULL;
-  cmax_next[(int64_t)t * 2 * M + 2 * j + 1] = 0ULL;
-  SNode<TK> a;
-  int64_t n = N;
-  for (int b = level - 1; b >= 0; --b) {
-    const int64_t nh = n >> 1;
-    n = ((j >> b) & 1) ? n - nh : nh;
-  }
-  a.n = (int)n;
-  a.nh = (int)(n >> 1);
-  const unsigned long long mn = cmin[(int64_t)t * M + j], mx = cmax[(int64_t)t * M + j];
-  const int B = stream_bins(M);
+__device__ inline void stream_geom(unsigned long long mn, unsigned long long mx, int B, TK& lo,
+                                   TK& scale) {
+  lo = (TK)0;
+  scale = (TK)0;
   if (mn != ~0ULL) {
-    const TK lo = ord_to(mn, TK()), hi = ord_to(mx, TK());
-    a.lo = lo;
-    a.scale = lo < hi ? (TK)B / (hi - lo) : (TK)0;
-  } else {
-    a.lo = (TK)0;
-    a.scale = (TK)0;
+    const TK l = ord_to(mn, TK()), h = ord_to(mx, TK());
+    lo = l;
+    scale = l < h ? (TK)B / (h - l) : (TK)0;
   }
-  a.pb = a.cL = a.cMid = 0;
-  a.lowb = -1;
-  a.highb = B;
-  a.midoff = 0;
-  a.midcur = 0;
-  a.maxL = 0ULL;
-  a.minR = ~0ULL;
-  nodes_out[(int64_t)t * M + j] = a;
 }
 
 template <class TK>
@@ -1521,19 +1496,22 @@ __device__ inline int stream_bin(TK key, TK lo, TK scale, int B) {
   return b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
 }
 
+// per-block value histogram of one level (16-bit counters packed two per word), written as a
+// PARTIAL to part[t][block][kStreamBins/2] with plain coalesced stores: stream_pick adds the
+// partials up (an atomic flush costs one L2 atomic per bin per block — as many as there are
+// points when a rank holds few trees).  grid = (nblk, T)
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_hist(
     const TK* __restrict__ P, const uint16_t* __restrict__ node_of, int64_t N, int L, int level,
-    int M, int64_t per, const SNode<TK>* __restrict__ nd, unsigned int* __restrict__ ghist) {
+    int M, int64_t per, const unsigned long long* __restrict__ cmin,
+    const unsigned long long* __restrict__ cmax, unsigned int* __restrict__ part) {
   __shared__ unsigned int hist[kStreamBins / 2];  // two 16-bit counters per word
   __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
   const int t = blockIdx.y;
   const int B = stream_bins(M);
   for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) hist[i] = 0;
-  for (int j = threadIdx.x; j < M; j += kStreamThreads) {
-    nlo[j] = nd[(int64_t)t * M + j].lo;
-    nsc[j] = nd[(int64_t)t * M + j].scale;
-  }
+  for (int j = threadIdx.x; j < M; j += kStreamThreads)
+    stream_geom<TK>(cmin[(int64_t)t * M + j], cmax[(int64_t)t * M + j], B, nlo[j], nsc[j]);
   __syncthreads();
   const TK* Pl = P + ((int64_t)t * L + level) * N;
   const uint16_t* no = node_of + (int64_t)t * N;
@@ -1544,134 +1522,146 @@ __global__ __launch_bounds__(kStreamThreads) void stream_hist(
     atomicAdd(&hist[e >> 1], 1u << ((e & 1) * 16));  // per < 65536: no carry between halves
   }
   __syncthreads();
-  unsigned int* gh = ghist + (int64_t)t * kStreamBins;
-  for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) {
-    const unsigned int w = hist[i];
-    if (w & 0xffffu) atomicAdd(&gh[2 * i], w & 0xffffu);
-    if (w >> 16) atomicAdd(&gh[2 * i + 1], w >> 16);
-  }
+  unsigned int* gp = part + ((int64_t)t * gridDim.x + blockIdx.x) * (kStreamBins / 2);
+  for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) gp[i] = hist[i];
 }
 
-// many small nodes (B <= 128 bins): one THREAD per (tree, node). grid = (ceil(M/256), T)
-template <class TK>
-__global__ __launch_bounds__(256) void stream_pick_small(int M, SNode<TK>* nd, unsigned int* ghist,
-                                                         unsigned int* poolcur,
-                                                         unsigned int* bigmid) {
-  const int j = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
-  if (j >= M) return;
-  SNode<TK>* a = &nd[(int64_t)t * M + j];
-  const int B = stream_bins(M);
-  unsigned int* h = ghist + (int64_t)t * kStreamBins + (int64_t)j * B;
-  const unsigned int nh = (unsigned int)a->nh;
-  unsigned int run = 0;
-  int pb = -1, cL = 0, cMid = 0, lastne = -1, lowb = -1, highb = B;
-  for (int b0 = 0; b0 < B; b0 += 4) {
-    const uint4 c4 = *reinterpret_cast<const uint4*>(h + b0);
-    const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+// BPT consecutive 16-bit counters added into c[]
+template <int BPT>
+__device__ inline void add_u16(const uint16_t* p, unsigned int (&c)[BPT]) {
+  if constexpr (BPT == 1) {
+    c[0] += *p;
+  } else if constexpr (BPT == 2) {
+    const unsigned int w = *reinterpret_cast<const unsigned int*>(p);
+    c[0] += w & 0xffffu;
+    c[1] += w >> 16;
+  } else if constexpr (BPT == 4) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    c[0] += w.x & 0xffffu;
+    c[1] += w.x >> 16;
+    c[2] += w.y & 0xffffu;
+    c[3] += w.y >> 16;
+  } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int b = b0 + q;
-      if (pb < 0) {
-        if (run <= nh && nh < run + c[q]) {
-          pb = b;
-          cL = (int)run;
-          cMid = (int)c[q];
-          lowb = lastne;
-        }
-      } else if (highb == B && c[q]) {
-        highb = b;
-      }
-      if (c[q]) lastne = b;
-      run += c[q];
+    for (int q = 0; q < BPT / 8; ++q) {
+      const uint4 w = *reinterpret_cast<const uint4*>(p + 8 * q);
+      c[8 * q + 0] += w.x & 0xffffu;
+      c[8 * q + 1] += w.x >> 16;
+      c[8 * q + 2] += w.y & 0xffffu;
+      c[8 * q + 3] += w.y >> 16;
+      c[8 * q + 4] += w.z & 0xffffu;
+      c[8 * q + 5] += w.z >> 16;
+      c[8 * q + 6] += w.w & 0xffffu;
+      c[8 * q + 7] += w.w >> 16;
     }
-    *reinterpret_cast<uint4*>(h + b0) = make_uint4(0, 0, 0, 0);  // clean for the next level
   }
-  const int n = a->n;
-  const int il = nh > 0 ? (int)nh - 1 : 0, ih = (int)nh + 1 < n ? (int)nh + 1 : n - 1;
-  if (!(il < cL)) lowb = -2;
-  if (!(ih >= cL + cMid)) highb = B + 1;
-  a->pb = pb;
-  a->cL = cL;
-  a->cMid = cMid;
-  a->lowb = lowb;
-  a->highb = highb;
-  a->midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
-  if (cMid > kSmallCap) atomicAdd(bigmid, 1u);
 }
 
-// one wave per (tree, node), four nodes per block. grid = (ceil(M/4), T), 256 threads
-template <class TK>
-__global__ __launch_bounds__(256) void stream_pick(int M, SNode<TK>* nd, unsigned int* ghist,
-                                                   unsigned int* poolcur, unsigned int* bigmid) {
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), t = blockIdx.y, lane = threadIdx.x & 63;
-  if (j >= M) return;
-  SNode<TK>* a = &nd[(int64_t)t * M + j];
-  const int B = stream_bins(M);
-  unsigned int* h = ghist + (int64_t)t * kStreamBins + (int64_t)j * B;
-  const unsigned int nh = (unsigned int)a->nh;
-  const int per = (B + 63) / 64;
-  unsigned int loc = 0;
-  for (int i = 0; i < per; ++i) {
-    const int b = lane * per + i;
-    if (b < B) loc += h[b];
+// per (tree, node): sum of the histogram partials, pivot bin, counts, nearest non-empty bins;
+// also (re)initialises the node record and the children's min/max cells of the next level.
+// G threads per node (a wave for <= 512 bins, the block above), BPT bins per thread.
+// grid = (ceil(M / (256/G)), T), 256 threads
+template <class TK, int BPT, int G>
+__global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, int nblk,
+                                                   const unsigned int* __restrict__ part,
+                                                   const unsigned long long* __restrict__ cmin,
+                                                   const unsigned long long* __restrict__ cmax,
+                                                   SNode<TK>* __restrict__ nd,
+                                                   unsigned int* __restrict__ poolcur,
+                                                   unsigned long long* __restrict__ cmin_next,
+                                                   unsigned long long* __restrict__ cmax_next,
+                                                   unsigned int* __restrict__ bigmid) {
+  constexpr int NPB = 256 / G, B = G * BPT;
+  __shared__ unsigned int wtot[4];
+  __shared__ int s_pb[4], s_cL[4], s_cMid[4], s_low[4], s_high[4];
+  const int g = threadIdx.x / G, r = threadIdx.x % G, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * NPB + g, t = blockIdx.y;
+  const bool live = j < M;
+  unsigned int c[BPT];
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) c[q] = 0;
+  if (live) {
+    const uint16_t* p16 = reinterpret_cast<const uint16_t*>(part + (int64_t)t * nblk * (kStreamBins / 2)) +
+                          (int64_t)j * B + r * BPT;
+    for (int p = 0; p < nblk; ++p) add_u16<BPT>(p16 + (int64_t)p * kStreamBins, c);
   }
-  unsigned int inc = loc;
+  int64_t n = N;
+  for (int b = level - 1; b >= 0; --b) {
+    const int64_t h = n >> 1;
+    n = ((j >> b) & 1) ? n - h : h;
+  }
+  const unsigned int nh = (unsigned int)(n >> 1);
+  unsigned int tot = 0;
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) tot += c[q];
+  unsigned int inc = tot;
   for (int o = 1; o < 64; o <<= 1) {
     const unsigned int v = __shfl_up(inc, o);
     if (lane >= o) inc += v;
   }
-  unsigned int run = inc - loc;
-  int pb = -1, cL = 0, cMid = 0;
-  for (int i = 0; i < per; ++i) {
-    const int b = lane * per + i;
-    if (b < B) {
-      const unsigned int c = h[b];
-      if (run <= nh && nh < run + c) {
-        pb = b;
-        cL = (int)run;
-        cMid = (int)c;
+  if (r == 0) {
+    s_pb[g] = -1;
+    s_cL[g] = 0;
+    s_cMid[g] = 0;
+    s_low[g] = -1;
+    s_high[g] = B;
+  }
+  if (G == 256 && lane == 63) wtot[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned int run = inc - tot;
+  if (G == 256)
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wtot[w];
+  if (live && run <= nh && nh < run + tot) {  // exactly one thread of the group
+    unsigned int a = run;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      if (a <= nh && nh < a + c[q]) {
+        s_pb[g] = r * BPT + q;
+        s_cL[g] = (int)a;
+        s_cMid[g] = (int)c[q];
       }
-      run += c;
+      a += c[q];
     }
   }
-  const unsigned long long own = __ballot(pb >= 0);
-  const int src_lane = own ? __ffsll((long long)own) - 1 : 0;
-  pb = __shfl(pb, src_lane);
-  cL = __shfl(cL, src_lane);
-  cMid = __shfl(cMid, src_lane);
+  __syncthreads();
+  const int pb = s_pb[g], cL = s_cL[g], cMid = s_cMid[g];
   // the margins p'[nh-1] / p'[nh+1] fall outside the pivot bin only at its edges: only then
   // the assign pass has to track max(left) / min(right) (in the nearest non-empty bins)
-  const int n = a->n;
-  const int il = nh > 0 ? (int)nh - 1 : 0, ih = (int)nh + 1 < n ? (int)nh + 1 : n - 1;
+  const int il = nh > 0 ? (int)nh - 1 : 0, ih = (int)nh + 1 < (int)n ? (int)nh + 1 : (int)n - 1;
   const bool need_lo = il < cL, need_hi = ih >= cL + cMid;
-  int lowb = -1, highb = B;
-  if (need_lo || need_hi) {
-    for (int i = 0; i < per; ++i) {
-      const int b = lane * per + i;
-      if (b < B && h[b]) {
-        if (b < pb) lowb = b > lowb ? b : lowb;
-        if (b > pb) highb = b < highb ? b : highb;
+  if (live && (need_lo || need_hi)) {
+    int lowb = -1, highb = B;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      const int b = r * BPT + q;
+      if (c[q]) {
+        if (b < pb) lowb = b;                     // ascending: the last one wins
+        if (b > pb && highb == B) highb = b;      // the first one wins
       }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const int x = __shfl_xor(lowb, o), y = __shfl_xor(highb, o);
-      lowb = x > lowb ? x : lowb;
-      highb = y < highb ? y : highb;
-    }
+    if (lowb >= 0) atomicMax(&s_low[g], lowb);
+    if (highb < B) atomicMin(&s_high[g], highb);
   }
-  if (!need_lo) lowb = -2;
-  if (!need_hi) highb = B + 1;
-  for (int i = 0; i < per; ++i) {  // clean for the next level
-    const int b = lane * per + i;
-    if (b < B) h[b] = 0;
-  }
-  if (lane == 0) {
-    a->pb = pb;
-    a->cL = cL;
-    a->cMid = cMid;
-    a->lowb = lowb;
-    a->highb = highb;
-    a->midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
+  __syncthreads();
+  if (live && r == 0) {
+    SNode<TK> a;
+    stream_geom<TK>(cmin[(int64_t)t * M + j], cmax[(int64_t)t * M + j], B, a.lo, a.scale);
+    a.n = (int)n;
+    a.nh = (int)nh;
+    a.pb = pb;
+    a.cL = cL;
+    a.cMid = cMid;
+    a.lowb = need_lo ? s_low[g] : -2;
+    a.highb = need_hi ? s_high[g] : B + 1;
+    a.midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
+    a.midcur = 0;
+    a.maxL = 0ULL;
+    a.minR = ~0ULL;
+    nd[(int64_t)t * M + j] = a;
+    cmin_next[(int64_t)t * 2 * M + 2 * j] = ~0ULL;  // children of this node
+    cmin_next[(int64_t)t * 2 * M + 2 * j + 1] = ~0ULL;
+    cmax_next[(int64_t)t * 2 * M + 2 * j] = 0ULL;
+    cmax_next[(int64_t)t * 2 * M + 2 * j + 1] = 0ULL;
     if (cMid > kSmallCap) atomicAdd(bigmid, 1u);
   }
 }
@@ -1767,40 +1757,33 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     }
 }
 
-// exact order of the pivot bin, shared tail: children of the pivot-bin points, min/max of the
-// next level's key, thr / margins.  `sorted(i)` returns the i-th (key, id) of the sorted bin.
+// exact order of the pivot bins of one level: children of the pivot-bin points, min/max of the
+// next level's key, thr / margins.  Pivot bins of <= 128 points take a wave each (bitonic
+// network over lane shuffles, no LDS); larger ones (the first levels, or ties) are sorted by
+// the whole block in LDS afterwards.  grid = (ceil(M/npb), T), 256 threads, npb = 1 or 4.
 template <class TK>
-struct MidOut {
-  uint16_t* no;
-  const TK* Pn;
+struct MidArgs {
+  const TK* P;
+  uint16_t* node_of;
+  int64_t N;
+  int L, level, M, has_next;
+  const SNode<TK>* nd;
+  const int32_t* pool;
   unsigned long long *cmin_next, *cmax_next;
+  int64_t heap0, nodes;
   double *thr, *mglo, *mghi;
   unsigned long long* tie_count;
 };
 
-// wave path: pivot bins of <= 128 points, one wave per (tree, node), 4 per block, no LDS.
-// grid = (ceil(M/4), T), 256 threads
 template <class TK>
-__global__ __launch_bounds__(256) void stream_mid_wave(
-    const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
-    int has_next, const SNode<TK>* __restrict__ nd, const int32_t* __restrict__ pool,
-    unsigned long long* cmin_next, unsigned long long* cmax_next, int64_t heap0, double* thr,
-    double* mglo, double* mghi, int64_t nodes, unsigned long long* tie_count, int wave_max,
-    unsigned int* big_list /* [0] = count, then (t << 16 | j) entries */) {
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), t = blockIdx.y, lane = threadIdx.x & 63;
-  if (j >= M) return;
-  const SNode<TK> a = nd[(int64_t)t * M + j];
-  const int cMid = a.cMid;
-  if (cMid > wave_max || cMid > 128) {  // leave it to the block-level kernel
-    if (lane == 0 && cMid <= kSmallCap)
-      big_list[1 + atomicAdd(&big_list[0], 1u)] = ((unsigned int)t << 16) | (unsigned int)j;
-    return;
-  }
-  if (cMid <= 0) return;
-  Keys<TK> K{P + (int64_t)t * L * N, N, level, nullptr};
-  const int32_t* m = pool + (int64_t)t * N + a.midoff;
+__device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, int t, int j,
+                                     int lane) {
+  const int cMid = a.cMid, M = A.M;
+  const int64_t N = A.N;
+  Keys<TK> K{A.P + (int64_t)t * A.L * N, N, A.level, nullptr};
+  const int32_t* m = A.pool + (int64_t)t * N + a.midoff;
   // at most 128 points: two per lane (the 4-register instantiation of wave_bitonic proved
-  // codegen-sensitive on ROCm 7.2 and is not used; larger bins take the block-level kernel)
+  // codegen-sensitive on ROCm 7.2 and is not used; larger bins take the block-level path)
   TK k[2];
   int id[2];
 #pragma unroll
@@ -1819,8 +1802,8 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
     wave_bitonic<TK, 2>(k, id, K);
   }
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
-  uint16_t* no = node_of + (int64_t)t * N;
-  const TK* Pn = P + ((int64_t)t * L + level + 1) * N;
+  uint16_t* no = A.node_of + (int64_t)t * N;
+  const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
   const int n = a.n, nh = a.nh;
   const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
@@ -1832,7 +1815,7 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
     if (i < cMid) {
       const int side = i >= kk;
       no[id[r]] = (uint16_t)(2 * j + side);
-      if (has_next) {
+      if (A.has_next) {
         const unsigned long long o = ord_of(Pn[id[r]]);
         mn[side] = o < mn[side] ? o : mn[side];
         mx[side] = o > mx[side] ? o : mx[side];
@@ -1851,7 +1834,7 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
       }
     }
   }
-  if (has_next) {
+  if (A.has_next) {
     for (int sd = 0; sd < 2; ++sd) {
       unsigned long long x = mn[sd], y = mx[sd];
       for (int o = 32; o > 0; o >>= 1) {
@@ -1860,8 +1843,8 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
         y = q > y ? q : y;
       }
       if (lane == 0) {
-        if (x != ~0ULL) atomicMin(&cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
-        if (y != 0ULL) atomicMax(&cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
+        if (x != ~0ULL) atomicMin(&A.cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
+        if (y != 0ULL) atomicMax(&A.cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
       }
     }
   }
@@ -1871,39 +1854,24 @@ __global__ __launch_bounds__(256) void stream_mid_wave(
   const TK tlo = b2 ? __shfl(vlo, __ffsll((long long)b2) - 1) : ord_to(a.maxL, TK());
   const TK thi = b4 ? __shfl(vhi, __ffsll((long long)b4) - 1) : ord_to(a.minR, TK());
   if (lane == 0) {
-    const int64_t h = (int64_t)t * nodes + heap0 + j;
-    thr[h] = (double)tthr;
-    mglo[h] = (double)tlo;
-    mghi[h] = (double)thi;
-    if (nh > 0 && !(tlo < tthr)) atomicAdd(tie_count, 1ULL);
+    const int64_t h = (int64_t)t * A.nodes + A.heap0 + j;
+    A.thr[h] = (double)tthr;
+    A.mglo[h] = (double)tlo;
+    A.mghi[h] = (double)thi;
+    if (nh > 0 && !(tlo < tthr)) atomicAdd(A.tie_count, 1ULL);
   }
 }
 
-// block path: pivot bins of 129..kSmallCap points. persistent grid of 256-thread blocks, dynamic LDS
 template <class TK>
-__global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
-                                                  uint16_t* __restrict__ node_of, int64_t N, int L,
-                                                  int level, int M, int has_next,
-                                                  const SNode<TK>* __restrict__ nd,
-                                                  const int32_t* __restrict__ pool,
-                                                  unsigned long long* cmin_next,
-                                                  unsigned long long* cmax_next, int64_t heap0,
-                                                  double* thr, double* mglo, double* mghi,
-                                                  int64_t nodes, unsigned long long* tie_count,
-                                                  const unsigned int* big_list) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // persistent grid over the nodes flagged by stream_mid_wave (usually none)
-  const unsigned int nflag = big_list[0];
-  for (unsigned int fi = blockIdx.x; fi < nflag; fi += gridDim.x) {
-  __syncthreads();
-  const int t = (int)(big_list[1 + fi] >> 16), j = (int)(big_list[1 + fi] & 0xffffu);
-  const SNode<TK> a = nd[(int64_t)t * M + j];
-  const int cMid = a.cMid;
+__device__ inline void mid_block_path(const MidArgs<TK>& A, const SNode<TK>& a, int t, int j,
+                                      unsigned char* smem) {
+  const int cMid = a.cMid, M = A.M;
+  const int64_t N = A.N;
   const int np = next_pow2(cMid);
   TK* skey = reinterpret_cast<TK*>(smem);
   int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
-  Keys<TK> K{P + (int64_t)t * L * N, N, level, nullptr};
-  const int32_t* m = pool + (int64_t)t * N + a.midoff;
+  Keys<TK> K{A.P + (int64_t)t * A.L * N, N, A.level, nullptr};
+  const int32_t* m = A.pool + (int64_t)t * N + a.midoff;
   for (int i = threadIdx.x; i < np; i += blockDim.x) {
     if (i < cMid) {
       const int id = m[i];
@@ -1917,19 +1885,19 @@ __global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
   __syncthreads();
   lds_bitonic(skey, sid, np, K);
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
-  uint16_t* no = node_of + (int64_t)t * N;
-  const TK* Pn = P + ((int64_t)t * L + level + 1) * N;
+  uint16_t* no = A.node_of + (int64_t)t * N;
+  const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
   for (int i = threadIdx.x; i < cMid; i += blockDim.x) {
     const int side = i >= kk;
     no[sid[i]] = (uint16_t)(2 * j + side);
-    if (has_next) {
+    if (A.has_next) {
       const unsigned long long o = ord_of(Pn[sid[i]]);
       mn[side] = o < mn[side] ? o : mn[side];
       mx[side] = o > mx[side] ? o : mx[side];
     }
   }
-  if (has_next) {
+  if (A.has_next) {
     for (int sd = 0; sd < 2; ++sd) {
       unsigned long long x = mn[sd], y = mx[sd];
       for (int o = 32; o > 0; o >>= 1) {
@@ -1938,42 +1906,80 @@ __global__ __launch_bounds__(256) void stream_mid(const TK* __restrict__ P,
         y = q > y ? q : y;
       }
       if ((threadIdx.x & 63) == 0) {
-        if (x != ~0ULL) atomicMin(&cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
-        if (y != 0ULL) atomicMax(&cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
+        if (x != ~0ULL) atomicMin(&A.cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
+        if (y != 0ULL) atomicMax(&A.cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
       }
     }
   }
   if (threadIdx.x == 0) {
     const int n = a.n, nh = a.nh;
     const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
-    const int64_t h = (int64_t)t * nodes + heap0 + j;
+    const int64_t h = (int64_t)t * A.nodes + A.heap0 + j;
     const TK vthr = skey[nh - a.cL];
     const TK vlo = il >= a.cL ? skey[il - a.cL] : ord_to(a.maxL, TK());
     const TK vhi = ih < a.cL + cMid ? skey[ih - a.cL] : ord_to(a.minR, TK());
-    thr[h] = (double)vthr;
-    mglo[h] = (double)vlo;
-    mghi[h] = (double)vhi;
-    if (nh > 0 && !(vlo < vthr)) atomicAdd(tie_count, 1ULL);
-  }
+    A.thr[h] = (double)vthr;
+    A.mglo[h] = (double)vlo;
+    A.mghi[h] = (double)vhi;
+    if (nh > 0 && !(vlo < vthr)) atomicAdd(A.tie_count, 1ULL);
   }
 }
 
-// counting sort of the points by node -> perm segments; the keys of the next `klevs` levels
-// are written in perm order alongside (coalesced input of wsub_kernel).  A block ranks ALL its
-// points (< 65536) in one round, so every node receives one contiguous run per block
-// (~per/M points: a few hundred bytes) instead of 16-byte crumbs.  grid = (nblk, T)
+template <class TK>
+__global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, int wave_max) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int sbig[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, t = blockIdx.y;
+  const int jw = blockIdx.x * npb + w;
+  int big = 0;
+  if (w < npb && jw < A.M) {
+    const SNode<TK> a = A.nd[(int64_t)t * A.M + jw];
+    if (a.cMid > wave_max) big = a.cMid <= kSmallCap;  // larger: the host rebuilds (bigmid)
+    else if (a.cMid > 0) mid_wave_path<TK>(A, a, t, jw, lane);
+  }
+  if (lane == 0) sbig[w] = big;
+  __syncthreads();
+  for (int q = 0; q < npb; ++q) {
+    if (!sbig[q]) continue;  // block-uniform
+    const int j = blockIdx.x * npb + q;
+    const SNode<TK> a = A.nd[(int64_t)t * A.M + j];
+    mid_block_path<TK>(A, a, t, j, smem);
+    __syncthreads();
+  }
+}
+
+// counting sort of the points by node -> perm segments.  A block ranks ALL its points
+// (< 65536) in one round, so every node receives one contiguous run per block (~per/M points:
+// a few hundred bytes) instead of 16-byte crumbs.  Does nothing once *abort is set (a pivot
+// bin outgrew LDS: the host rebuilds with the general path).  grid = (nblk, T)
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
-    const uint16_t* __restrict__ node_of, int64_t N, int M, int64_t per,
-    const int64_t* __restrict__ noff, unsigned int* __restrict__ gcur, int32_t* __restrict__ perm,
-    const TK* __restrict__ P, int L, int T, int klev0, int klevs, TK* __restrict__ Kperm) {
+    const uint16_t* __restrict__ node_of, int64_t N, int levels, int64_t per,
+    unsigned int* __restrict__ gcur, int32_t* __restrict__ perm,
+    const unsigned int* __restrict__ abort) {
   constexpr int EPT = 64;  // per <= 65535 = 64 * 1024 - 1
   __shared__ unsigned int cnt[2 * kStreamMaxNodes], base[2 * kStreamMaxNodes];
+  __shared__ int64_t noff[2 * kStreamMaxNodes];
+  if (*abort) return;
   const int t = blockIdx.y;
+  const int M = 1 << levels;
   const uint16_t* no = node_of + (int64_t)t * N;
   int32_t* pm = perm + (int64_t)t * N;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
-  for (int j = threadIdx.x; j < M; j += kStreamThreads) cnt[j] = 0;
+  for (int j = threadIdx.x; j < M; j += kStreamThreads) {
+    cnt[j] = 0;
+    int64_t off = 0, n = N;
+    for (int b = levels - 1; b >= 0; --b) {
+      const int64_t nh = n >> 1;
+      if ((j >> b) & 1) {
+        off += nh;
+        n -= nh;
+      } else {
+        n = nh;
+      }
+    }
+    noff[j] = off;
+  }
   __syncthreads();
   unsigned int pk[EPT];  // (node << 16) | rank inside this block
 #pragma unroll
@@ -1994,10 +2000,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
     const int64_t i = i0 + e * kStreamThreads + threadIdx.x;
     if (pk[e] != 0xffffffffu) {
       const unsigned int j = pk[e] >> 16;
-      const int64_t pos = noff[j] + base[j] + (pk[e] & 0xffffu);
-      pm[pos] = (int32_t)i;
-      for (int l = 0; l < klevs; ++l)
-        Kperm[((int64_t)l * T + t) * N + pos] = P[((int64_t)t * L + klev0 + l) * N + i];
+      pm[noff[j] + base[j] + (pk[e] & 0xffffu)] = (int32_t)i;
     }
   }
 }
@@ -2155,7 +2158,8 @@ static double now_ms() {
 #define HT(label) do { if (getenv("RPT_DEBUG_HOST")) { (void)stream_sync(ctx->stream); double t__ = now_ms(); fprintf(stderr, "host %-28s %8.3f ms\n", label, t__ - ht_last); ht_last = t__; } } while (0)
 
 template <class TK>
-int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode) {
+int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode,
+                       bool no_stream = false) {
   double ht_last = now_ms();
   const int64_t N = f->n;
   const int T = f->T, L = f->L;
@@ -2258,9 +2262,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
 
   auto upload = [&](const std::vector<Seg>& v, DevBuf<Seg>& d) -> int32_t {
     RPT_TRY(d.ensure(v.size()));
-    RPT_HIP(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(Seg), hipMemcpyHostToDevice, st));
-    RPT_HIP(stream_sync(st));  // v may be a temporary
-    return RPT_OK;
+    return upload_async(ctx, d.p, v.data(), v.size() * sizeof(Seg));  // staged: no wait
   };
 
   // pending split nodes per level, each remembering which ping-pong buffer holds its points
@@ -2270,92 +2272,110 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   };
   std::vector<std::vector<PNode>> pending((size_t)Lused + kRmax + 1);
   int32_t* bufs[2] = {bufA.p, bufB.p};
+  // sflags[0]: a streaming level met a pivot bin larger than LDS (heavy ties / extreme
+  // outliers).  The levels after it work on inconsistent node ids (harmless: every access
+  // stays in bounds), the kernels that consume the streamed permutation do nothing once it is
+  // set, and the host — which looks at it at its next synchronisation point, normally the one
+  // at the very end — rebuilds the forest with the general path, which has the fallbacks.
+  DevBuf<unsigned int> sflags;
+  RPT_TRY(sflags.alloc(4));
+  RPT_HIP(hipMemsetAsync(sflags.p, 0, 16, st));
+  bool stream_unchecked = false;
+  auto stream_aborted = [&](bool* aborted) -> int32_t {  // call right after a sync point
+    *aborted = false;
+    if (!stream_unchecked) return RPT_OK;
+    unsigned int v = 0;
+    RPT_HIP(hipMemcpy(&v, sflags.p, 4, hipMemcpyDeviceToHost));
+    stream_unchecked = false;
+    *aborted = v != 0;
+    return RPT_OK;
+  };
   HT("alloc work buffers");
   // ---- streaming path for the leading levels ----
   int Lstream = 0;
-  if (N >= 2048 && !getenv("RPT_NO_STREAM"))
+  if (N >= 2048 && !no_stream && !getenv("RPT_NO_STREAM"))
     while (Lstream < Lused && splits[(size_t)Lstream].size() == ((size_t)1 << Lstream) &&
            (1 << Lstream) <= kStreamMaxNodes)
       ++Lstream;
   int streamed = 0;  // levels completed by the streaming path
-  DevBuf<TK> Kperm;   // keys of levels [streamed, streamed + kperm_levs) in perm order
-  int kperm_levs = 0;
   if (Lstream > 0) {
     DevBuf<uint16_t> node_of;
-    DevBuf<unsigned int> ghist, poolcur, bigmid, gcur, biglist;
+    DevBuf<unsigned int> part, poolcur, gcur;
     DevBuf<SNode<TK>> snodes;
     DevBuf<unsigned long long> mm[4];  // cmin/cmax ping-pong
-    DevBuf<int64_t> dnoff;
-    RPT_TRY(node_of.alloc((size_t)T * N));
-    RPT_TRY(ghist.alloc((size_t)T * kStreamBins));
-    RPT_TRY(poolcur.alloc((size_t)T));
-    RPT_TRY(bigmid.alloc(1));
-    RPT_TRY(biglist.alloc((size_t)T * kStreamMaxNodes + 1));
-    RPT_TRY(snodes.alloc((size_t)T * kStreamMaxNodes));
-    for (auto& b : mm) RPT_TRY(b.alloc((size_t)T * 2 * kStreamMaxNodes));
-    RPT_HIP(hipMemsetAsync(node_of.p, 0, (size_t)T * N * 2, st));
-    RPT_HIP(hipMemsetAsync(ghist.p, 0, (size_t)T * kStreamBins * 4, st));
-    RPT_HIP(hipMemsetAsync(bigmid.p, 0, 4, st));
+    // histogram pass: every block leaves a 64 KB partial that stream_pick reads back, so keep
+    // >= min_per points per block; 16-bit LDS counters cap a block at 65535 points
+    const int64_t min_per = getenv("RPT_STREAM_MINPER") ? atoll(getenv("RPT_STREAM_MINPER")) : 32768;
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
-    // every block flushes up to one atomic per histogram bin: keep >= 32768 points per block
-    if (nblk > (N + 32767) / 32768) nblk = (N + 32767) / 32768;
-    if (nblk < (N + 65534) / 65535) nblk = (N + 65534) / 65535;  // 16-bit LDS counters
+    if (nblk > (N + min_per - 1) / min_per) nblk = (N + min_per - 1) / min_per;
+    if (nblk < (N + 65534) / 65535) nblk = (N + 65534) / 65535;
     if (nblk < 1) nblk = 1;
     const int64_t per = (N + nblk - 1) / nblk;
     const dim3 sgrid((unsigned)nblk, (unsigned)T);
+    // assign pass: no per-block table to flush, fill the chip
+    int64_t nblkA = (4 * (int64_t)ctx->n_cu + T - 1) / T;
+    if (nblkA > (N + 8191) / 8192) nblkA = (N + 8191) / 8192;
+    if (nblkA < 1) nblkA = 1;
+    const int64_t perA = (N + nblkA - 1) / nblkA;
+    const dim3 agrid((unsigned)nblkA, (unsigned)T);
+    RPT_TRY(node_of.alloc((size_t)T * N));
+    RPT_TRY(part.alloc((size_t)T * nblk * (kStreamBins / 2)));
+    RPT_TRY(poolcur.alloc((size_t)T * Lstream));
+    RPT_TRY(snodes.alloc((size_t)T * kStreamMaxNodes));
+    for (auto& b : mm) RPT_TRY(b.alloc((size_t)T * 2 * kStreamMaxNodes));
+    RPT_HIP(hipMemsetAsync(node_of.p, 0, (size_t)T * N * 2, st));
+    RPT_HIP(hipMemsetAsync(poolcur.p, 0, (size_t)T * Lstream * 4, st));
     unsigned long long *cmin = mm[0].p, *cmax = mm[1].p, *cminN = mm[2].p, *cmaxN = mm[3].p;
-    const int64_t mmn = (int64_t)T * 2 * kStreamMaxNodes;
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cmin, mmn, ~0ULL);
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(64), dim3(256), 0, st, cmax, mmn, 0ULL);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(256), 0, st, cmin, (int64_t)T, ~0ULL);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(256), 0, st, cmax, (int64_t)T, 0ULL);
     hipLaunchKernelGGL(stream_minmax0<TK>, sgrid, dim3(kStreamThreads), 0, st, P, N, L, per, cmin,
                        cmax);
     HT("stream alloc+minmax0");
     int32_t* pool = bufB.p;  // the ping-pong buffers are idle while nothing moves
-    for (int level = 0; level < Lstream; ++level) {
-      ProfScope ps(ctx, RPT_PROF_SPLIT);
-      const int M = 1 << level;
-      const int has_next = level + 1 < Lstream ? 1 : 0;
-      hipLaunchKernelGGL(stream_setup<TK>, dim3((unsigned)((M + 63) / 64), (unsigned)T), dim3(64),
-                         0, st, N, level, M, cmin, cmax, snodes.p, poolcur.p, cminN, cmaxN, biglist.p);
-      hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
-                         level, M, per, snodes.p, ghist.p);
-      if (stream_bins(M) <= 128)
-        hipLaunchKernelGGL(stream_pick_small<TK>, dim3((unsigned)((M + 255) / 256), (unsigned)T),
-                           dim3(256), 0, st, M, snodes.p, ghist.p, poolcur.p, bigmid.p);
-      else
-        hipLaunchKernelGGL(stream_pick<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T), dim3(256), 0,
-                           st, M, snodes.p, ghist.p, poolcur.p, bigmid.p);
-      hipLaunchKernelGGL(stream_assign<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
-                         level, M, per, has_next, snodes.p, pool, cminN, cmaxN);
-      const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
-      const int wave_max = getenv("RPT_NO_WMID") ? 0 : (getenv("RPT_WMID_MAX") ? atoi(getenv("RPT_WMID_MAX")) : 128);
-      hipLaunchKernelGGL(stream_mid_wave<TK>, dim3((unsigned)((M + 3) / 4), (unsigned)T),
-                           dim3(256), 0, st, P, node_of.p, N, L, level, M, has_next, snodes.p, pool,
-                           cminN, cmaxN, (int64_t)M - 1, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
-                           tie_count, wave_max, biglist.p);
-      hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)ctx->n_cu), dim3(256), smem, st, P,
-                         node_of.p, N, L, level, M, has_next, snodes.p, pool, cminN, cmaxN,
-                         (int64_t)M - 1, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count,
-                         biglist.p);
-      RPT_HIP(hipGetLastError());
-      std::swap(cmin, cminN);
-      std::swap(cmax, cmaxN);
-      streamed = level + 1;
-    }
+    const int wave_max = getenv("RPT_NO_WMID") ? 0 : 128;
     {
-      // a pivot bin larger than LDS (heavy ties / extreme outliers) at ANY level: the levels
-      // after it worked on inconsistent node ids (harmless, all accesses stay in bounds) and the
-      // whole forest is rebuilt by the general path, which has the fallbacks.  Checked once.
-      unsigned int nbig = 0;
-      RPT_HIP(hipMemcpyAsync(&nbig, bigmid.p, 4, hipMemcpyDeviceToHost, st));
-      RPT_HIP(stream_sync(st));
-      if (nbig) streamed = 0;
+      ProfScope ps(ctx, RPT_PROF_SPLIT);
+      for (int level = 0; level < Lstream; ++level) {
+        const int M = 1 << level;
+        const int has_next = level + 1 < Lstream ? 1 : 0;
+        hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
+                           level, M, per, cmin, cmax, part.p);
+        unsigned int* pc = poolcur.p + (size_t)level * T;
+#define RPT_PICK(BPT, G)                                                                       \
+  hipLaunchKernelGGL((stream_pick<TK, BPT, G>), dim3((unsigned)((M + 256 / G - 1) / (256 / G)), \
+                                                      (unsigned)T),                            \
+                     dim3(256), 0, st, N, level, M, (int)nblk, part.p, cmin, cmax, snodes.p, pc, \
+                     cminN, cmaxN, sflags.p)
+        switch (stream_bins(M)) {
+          case 4096: RPT_PICK(16, 256); break;
+          case 2048: RPT_PICK(8, 256); break;
+          case 1024: RPT_PICK(4, 256); break;
+          case 512: RPT_PICK(8, 64); break;
+          case 256: RPT_PICK(4, 64); break;
+          case 128: RPT_PICK(2, 64); break;
+          default: RPT_PICK(1, 64); break;
+        }
+#undef RPT_PICK
+        hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, node_of.p, N,
+                           L, level, M, perA, has_next, snodes.p, pool, cminN, cmaxN);
+        const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
+        const int npb = M >= 16 ? 4 : 1;
+        MidArgs<TK> ma{P,     node_of.p, N,     L,        level,    M,
+                       has_next, snodes.p, pool, cminN, cmaxN, (int64_t)M - 1, f->nodes,
+                       f->thr.p, f->mglo.p, f->mghi.p, tie_count};
+        hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)((M + npb - 1) / npb), (unsigned)T),
+                           dim3(256), smem, st, ma, npb, wave_max);
+        std::swap(cmin, cminN);
+        std::swap(cmax, cmaxN);
+      }
+      RPT_HIP(hipGetLastError());
+      streamed = Lstream;
+      stream_unchecked = true;
     }
     HT("stream levels");
-    if (streamed > 0) {
+    {
       ProfScope ps(ctx, RPT_PROF_SPLIT);
       const int M = 1 << streamed;
-      std::vector<int64_t> noff((size_t)M);
       std::vector<Seg> lvl((size_t)M);
       for (int j = 0; j < M; ++j) {
         int64_t off = 0, n = N;
@@ -2368,24 +2388,13 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
             n = nh;
           }
         }
-        noff[(size_t)j] = off;
         lvl[(size_t)j] = Seg{off, (int32_t)n, (int32_t)(M - 1 + j)};
       }
-      RPT_TRY(dnoff.alloc((size_t)M));
       RPT_TRY(gcur.alloc((size_t)T * M));
-      RPT_HIP(hipMemcpyAsync(dnoff.p, noff.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
       RPT_HIP(hipMemsetAsync(gcur.p, 0, (size_t)T * M * 4, st));
-      // nodes of the next level small enough for the wave kernel: hand it their keys in perm order
-      // measured: carrying the keys through the counting sort is store-rate bound (2.6 ms vs the
-      // 0.8 ms of gathers it saves at C2) -> off unless asked for
-      if (getenv("RPT_KPERM") && (N >> streamed) + 1 <= kWCap) {
-        kperm_levs = Lused - streamed < kWRmax ? Lused - streamed : kWRmax;
-        if (kperm_levs > 0) RPT_TRY(Kperm.alloc((size_t)kperm_levs * T * N));
-      }
-      hipLaunchKernelGGL(stream_to_perm<TK>, sgrid, dim3(kStreamThreads), 0, st, node_of.p, N, M,
-                         per, dnoff.p, gcur.p, bufA.p, P, L, T, streamed, kperm_levs, Kperm.p);
+      hipLaunchKernelGGL(stream_to_perm<TK>, sgrid, dim3(kStreamThreads), 0, st, node_of.p, N,
+                         streamed, per, gcur.p, bufA.p, sflags.p);
       RPT_HIP(hipGetLastError());
-      RPT_HIP(stream_sync(st));  // noff is host memory
       // nodes of level `streamed`: Bins stay pending, Tips get their final order now
       std::vector<Seg> lsmall;
       std::vector<GSeg> lbig;
@@ -2400,6 +2409,13 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           for (int t = 0; t < T; ++t)
             lbig.push_back(GSeg{(int64_t)t * N + c.off, c.n, t, -1, -1, -1, -1});
         }
+      }
+      if (!lsmall.empty() || !lbig.empty()) {
+        // these consumers do not look at the abort flag: settle it first
+        RPT_HIP(ctx_sync(ctx));
+        bool aborted = false;
+        RPT_TRY(stream_aborted(&aborted));
+        if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
       }
       if (!lsmall.empty()) {
         RPT_TRY(upload(lsmall, dsegs));
@@ -2417,10 +2433,22 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
                            bufA.p, F, N, dsegs.p);
       }
       RPT_HIP(hipGetLastError());
-      RPT_HIP(stream_sync(st));  // node_of & co are released at the end of this scope
+      // node_of & co go back to the allocator here; it hands them out again only after the
+      // stream has been synchronised
     }
   }
   HT("stream to_perm + free");
+  if (stream_unchecked) {
+    // only wsub_kernel / leaf_sort_kernel honour the abort flag: anything else waits for it
+    bool all_wave = getenv("RPT_NO_WSUB") == nullptr;
+    for (const PNode& pn : pending[(size_t)streamed]) all_wave = all_wave && pn.seg.n <= kWCap;
+    if (!all_wave) {
+      RPT_HIP(ctx_sync(ctx));
+      bool aborted = false;
+      RPT_TRY(stream_aborted(&aborted));
+      if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
+    }
+  }
   if (streamed == 0) {
     hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, st, bufA.p, N, T);
     if (!splits[0].empty()) pending[0].push_back(PNode{splits[0][0], 0});
@@ -2437,6 +2465,14 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         descend(Seg{sgm.off, nh, 2 * sgm.heap + 1}, level + 1, depth + 1, want, out);
         descend(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, level + 1, depth + 1, want, out);
       };
+
+  // wsub_kernel launches whose overflow flags have not been looked at yet
+  struct Deferred {
+    int level = 0, b = 0;
+    std::vector<Seg> nodes;
+    DevBuf<unsigned int> ovf;  // [0] count, [1 + i] flag of node i
+  };
+  std::list<Deferred> deferred;
 
   for (int level = 0; level < Lused; ++level) {
     for (int b = 0; b < 2; ++b) {
@@ -2455,37 +2491,29 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       if (!wsmall.empty()) {
         RPT_TRY(upload(wsmall, dsegs));
         const unsigned S = (unsigned)wsmall.size();
-        RPT_TRY(ovf.ensure((size_t)S + 1));
-        RPT_HIP(hipMemsetAsync(ovf.p, 0, ((size_t)S + 1) * 4, st));
+        deferred.emplace_back();
+        Deferred& df = deferred.back();
+        df.level = level;
+        df.b = b;
+        RPT_TRY(df.ovf.alloc((size_t)S + 1));
+        RPT_HIP(hipMemsetAsync(df.ovf.p, 0, ((size_t)S + 1) * 4, st));
         RPT_TRY(Kleaf.ensure((size_t)T * N));
         hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
                            st, cur, nxt, F, Kleaf.p, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
-                           (kperm_levs > 0 && level == streamed && b == 0) ? Kperm.p
-                                                                           : (const TK*)nullptr,
-                           streamed, kperm_levs, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
-                           tie_count, ovf.p + 1, ovf.p);
-        unsigned int novf = 0;
-        RPT_HIP(hipMemcpyAsync(&novf, ovf.p, 4, hipMemcpyDeviceToHost, st));
-        RPT_HIP(stream_sync(st));
-        std::vector<Seg> redo;
-        if (novf) {  // pivot bin / leaf larger than a wave slab: block-level kernel for those nodes
-          std::vector<unsigned int> fl((size_t)S);
-          RPT_HIP(hipMemcpy(fl.data(), ovf.p + 1, (size_t)S * 4, hipMemcpyDeviceToHost));
-          for (unsigned i = 0; i < S; ++i)
-            if (fl[i]) redo.push_back(wsmall[i]);
-        }
+                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, df.ovf.p + 1,
+                           df.ovf.p, (const unsigned int*)sflags.p);
         // leaves created by the wave kernel still need their order; nodes it left active stay
         // pending
-        std::vector<Seg> wl_small, wl_mid;
-        std::vector<int> wl_small_lv;
+        std::vector<Seg> wl_small, rest;
+        std::vector<int> wl_small_info;  // leaf level | (index of the wsub node << 6)
         std::vector<std::pair<Seg, int>> wl_mid_lv;
-        std::vector<Seg> rest;
-        std::function<void(const Seg&, int, int)> walk = [&](const Seg& sgm, int lv, int dp) {
+        std::function<void(const Seg&, int, int, int)> walk = [&](const Seg& sgm, int lv, int dp,
+                                                                  int top) {
           if (is_leaf(lv, sgm.n, L, f->min_leaf)) {
             if (sgm.n > 1) {
               if (sgm.n <= 128) {
                 wl_small.push_back(Seg{sgm.off, sgm.n, -1});
-                wl_small_lv.push_back(lv);
+                wl_small_info.push_back(lv | (top << 6));
               } else {
                 wl_mid_lv.push_back({Seg{sgm.off, sgm.n, -1}, lv});
               }
@@ -2497,24 +2525,63 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
             return;
           }
           const int nh = sgm.n / 2;
-          walk(Seg{sgm.off, nh, 2 * sgm.heap + 1}, lv + 1, dp + 1);
-          walk(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, lv + 1, dp + 1);
+          walk(Seg{sgm.off, nh, 2 * sgm.heap + 1}, lv + 1, dp + 1, top);
+          walk(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, lv + 1, dp + 1, top);
         };
-        for (size_t i = 0; i < wsmall.size(); ++i) {
-          bool again = false;
-          for (const Seg& r : redo) again = again || r.off == wsmall[i].off;
-          if (!again) walk(wsmall[i], level, 0);
+        for (size_t i = 0; i < wsmall.size(); ++i) walk(wsmall[i], level, 0, (int)i);
+        // The overflow flags are only needed on the host when something other than
+        // leaf_sort_kernel (which skips flagged nodes itself) consumes this launch's output;
+        // otherwise they are looked at once, at the end of the build.
+        const bool defer = rest.empty() && wl_mid_lv.empty() && S < (1u << 25);
+        std::vector<Seg> redo;
+        if (!defer) {
+          unsigned int novf = 0;
+          RPT_HIP(hipMemcpyAsync(&novf, df.ovf.p, 4, hipMemcpyDeviceToHost, st));
+          RPT_HIP(ctx_sync(ctx));
+          bool aborted = false;
+          RPT_TRY(stream_aborted(&aborted));
+          if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
+          std::vector<unsigned int> fl((size_t)S, 0u);
+          if (novf) {  // pivot bin / leaf larger than a wave slab: block-level kernel for those
+            RPT_HIP(hipMemcpy(fl.data(), df.ovf.p + 1, (size_t)S * 4, hipMemcpyDeviceToHost));
+            for (unsigned i = 0; i < S; ++i)
+              if (fl[i]) redo.push_back(wsmall[i]);
+            auto drop = [&](const Seg& x) {  // inside a node that is run again
+              for (const Seg& r : redo)
+                if (x.off >= r.off && x.off < r.off + r.n) return true;
+              return false;
+            };
+            rest.erase(std::remove_if(rest.begin(), rest.end(), drop), rest.end());
+            wl_mid_lv.erase(std::remove_if(wl_mid_lv.begin(), wl_mid_lv.end(),
+                                           [&](const std::pair<Seg, int>& x) { return drop(x.first); }),
+                            wl_mid_lv.end());
+          }
+          deferred.pop_back();  // settled here (leaf_sort_kernel below still reads the flags:
+                                // the buffer returns to the allocator, which keeps it intact
+                                // until the next synchronisation)
+        } else {
+          df.nodes = wsmall;
+        }
+        const unsigned int* ovf_flags = defer ? df.ovf.p + 1 : nullptr;
+        DevBuf<unsigned int> settled;  // flags of a settled launch, kept for leaf_sort_kernel
+        if (!defer) {
+          RPT_TRY(settled.alloc((size_t)S));
+          std::vector<unsigned int> fl((size_t)S, 0u);
+          for (const Seg& r : redo)
+            for (unsigned i = 0; i < S; ++i)
+              if (wsmall[i].off == r.off) fl[i] = 1u;
+          RPT_TRY(upload_async(ctx, settled.p, fl.data(), (size_t)S * 4));
+          ovf_flags = settled.p;
         }
         for (const Seg& sgm : rest) pending[(size_t)level + kWRmax].push_back(PNode{sgm, 1 - b});
         if (!wl_small.empty()) {
           RPT_TRY(upload(wl_small, dsegs3));
-          RPT_TRY(dlv.ensure(wl_small_lv.size()));
-          RPT_HIP(hipMemcpyAsync(dlv.p, wl_small_lv.data(), wl_small_lv.size() * 4,
-                                 hipMemcpyHostToDevice, st));
+          RPT_TRY(dlv.ensure(wl_small_info.size()));
+          RPT_TRY(upload_async(ctx, dlv.p, wl_small_info.data(), wl_small_info.size() * 4));
           const unsigned SL = (unsigned)wl_small.size();
           hipLaunchKernelGGL(leaf_sort_kernel<TK>, dim3((unsigned)(((int64_t)SL * T + 3) / 4)),
-                             dim3(256), 0, st, F, Kleaf.p, N, P, L, T, dsegs3.p, (int)SL, dlv.p);
-          RPT_HIP(stream_sync(st));  // wl_small_lv is host memory
+                             dim3(256), 0, st, F, Kleaf.p, N, P, L, T, dsegs3.p, (int)SL, dlv.p,
+                             ovf_flags, (const unsigned int*)sflags.p);
         }
         // buckets of 129..kSmallCap points: the block-level LDS sort, grouped by key level
         while (!wl_mid_lv.empty()) {
@@ -2655,10 +2722,57 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     RPT_HIP(hipMemcpy(hs, dbgbuf, sizeof(hs), hipMemcpyDeviceToHost));
     for (int i = 1; i < 256 && hs[i]; ++i) fprintf(stderr, "stamp %d: +%llu\n", i, hs[i] - hs[i - 1]);
   }
-  unsigned long long ties = 0;
-  RPT_HIP(hipMemcpyAsync(&ties, tie_count, 8, hipMemcpyDeviceToHost, st));
-  RPT_HIP(stream_sync(st));
-  f->tie_nodes = (int64_t)ties;
+  // ---- the one synchronisation point of the common path ----
+  {
+    const size_t nd = deferred.size();
+    unsigned long long* hres = reinterpret_cast<unsigned long long*>(pin_alloc(ctx, (2 + nd) * 8));
+    std::vector<unsigned long long> hfallback;
+    if (!hres) {
+      hfallback.resize(2 + nd);
+      hres = hfallback.data();
+    }
+    for (size_t i = 0; i < 2 + nd; ++i) hres[i] = 0;
+    RPT_HIP(hipMemcpyAsync(&hres[0], tie_count, 8, hipMemcpyDeviceToHost, st));
+    RPT_HIP(hipMemcpyAsync(&hres[1], sflags.p, 4, hipMemcpyDeviceToHost, st));
+    size_t k = 2;
+    for (Deferred& df : deferred)
+      RPT_HIP(hipMemcpyAsync(&hres[k++], df.ovf.p, 4, hipMemcpyDeviceToHost, st));
+    RPT_HIP(stream_sync(st));
+    const unsigned long long ties0 = hres[0];
+    const bool aborted = stream_unchecked && (unsigned int)hres[1] != 0;
+    std::vector<unsigned int> novf(nd);
+    for (size_t i = 0; i < nd; ++i) novf[i] = (unsigned int)hres[2 + i];
+    ctx->pin_off = 0;
+    if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
+    f->tie_nodes = (int64_t)ties0;
+    bool redone = false;
+    k = 0;
+    for (Deferred& df : deferred) {
+      if (novf[k++] == 0) continue;
+      // pivot bin / leaf larger than a wave slab: those nodes again with the block-level kernel
+      // (a deferred launch covers the rest of its subtrees: kRmax > kWRmax)
+      const size_t S = df.nodes.size();
+      std::vector<unsigned int> fl(S);
+      RPT_HIP(hipMemcpy(fl.data(), df.ovf.p + 1, S * 4, hipMemcpyDeviceToHost));
+      std::vector<Seg> redo;
+      for (size_t i = 0; i < S; ++i)
+        if (fl[i]) redo.push_back(df.nodes[i]);
+      if (redo.empty()) continue;
+      ProfScope ps(ctx, RPT_PROF_SPLIT);
+      RPT_TRY(upload(redo, dsegs));
+      hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)redo.size(), T), dim3(kSubThreads), 0,
+                         st, bufs[df.b], bufs[1 - df.b], F, N, P, L, df.level, f->min_leaf, dsegs.p,
+                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
+      RPT_HIP(hipGetLastError());
+      redone = true;
+    }
+    if (redone) {
+      unsigned long long ties = 0;
+      RPT_HIP(hipMemcpyAsync(&ties, tie_count, 8, hipMemcpyDeviceToHost, st));
+      RPT_HIP(ctx_sync(ctx));
+      f->tie_nodes = (int64_t)ties;
+    }
+  }
   return RPT_OK;
 }
 
