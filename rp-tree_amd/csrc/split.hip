@@ -94,13 +94,23 @@ struct Keys {
   }
 };
 
+// barrier among the lanes of one wave (wave-private LDS regions need no workgroup barrier)
+__device__ inline void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // In-LDS bitonic sort of np (power of two) (key, id) pairs by Keys::less.  All threads of
-// the block must call it.
-template <class TK>
+// the block must call it; with WAVE the region belongs to the calling wave alone and only its
+// 64 lanes take part (no workgroup barrier).
+template <class TK, bool WAVE = false>
 __device__ void lds_bitonic(TK* skey, int* sid, int np, const Keys<TK>& K) {
+  const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int nthr = WAVE ? 64 : (int)blockDim.x;
   for (int k = 2; k <= np; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < (np >> 1); i += blockDim.x) {
+      for (int i = tid; i < (np >> 1); i += nthr) {
         const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
         const int hi = lo | j;
         const bool up = (lo & k) == 0;
@@ -115,7 +125,8 @@ __device__ void lds_bitonic(TK* skey, int* sid, int np, const Keys<TK>& K) {
           sid[hi] = il;
         }
       }
-      __syncthreads();
+      if (WAVE) wsync();
+      else __syncthreads();
     }
   }
 }
@@ -746,12 +757,6 @@ struct WSlab {
   int toff[32], tcur[32];
   double vthr[16], vlo[16];
 };
-
-__device__ inline void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <class TK>
 __global__ __launch_bounds__(256) void wsub_kernel(
@@ -1559,8 +1564,8 @@ __device__ inline void add_u16(const uint16_t* p, unsigned int (&c)[BPT]) {
 
 // per (tree, node): sum of the histogram partials, pivot bin, counts, nearest non-empty bins;
 // also (re)initialises the node record and the children's min/max cells of the next level.
-// G threads per node (a wave for <= 512 bins, the block above), BPT bins per thread.
-// grid = (ceil(M / (256/G)), T), 256 threads
+// G threads per node (8 .. 256), BPT consecutive bins per thread (wide loads of the 16-bit
+// partial counters), B = G * BPT bins per node.  grid = (ceil(M / (256/G)), T), 256 threads
 template <class TK, int BPT, int G>
 __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, int nblk,
                                                    const unsigned int* __restrict__ part,
@@ -1571,18 +1576,21 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
                                                    unsigned long long* __restrict__ cmin_next,
                                                    unsigned long long* __restrict__ cmax_next,
                                                    unsigned int* __restrict__ bigmid) {
-  constexpr int NPB = 256 / G, B = G * BPT;
+  constexpr int NPB = 256 / G, B = G * BPT, W = G < 64 ? G : 64, WPG = G / W;  // waves per group
   __shared__ unsigned int wtot[4];
-  __shared__ int s_pb[4], s_cL[4], s_cMid[4], s_low[4], s_high[4];
+  __shared__ int s_pb[NPB], s_cL[NPB], s_cMid[NPB], s_low[NPB], s_high[NPB];
   const int g = threadIdx.x / G, r = threadIdx.x % G, lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int j = blockIdx.x * NPB + g, t = blockIdx.y;
   const bool live = j < M;
   unsigned int c[BPT];
 #pragma unroll
   for (int q = 0; q < BPT; ++q) c[q] = 0;
   if (live) {
-    const uint16_t* p16 = reinterpret_cast<const uint16_t*>(part + (int64_t)t * nblk * (kStreamBins / 2)) +
-                          (int64_t)j * B + r * BPT;
+    const uint16_t* p16 =
+        reinterpret_cast<const uint16_t*>(part + (int64_t)t * nblk * (kStreamBins / 2)) +
+        (int64_t)j * B + r * BPT;
+#pragma unroll 4
     for (int p = 0; p < nblk; ++p) add_u16<BPT>(p16 + (int64_t)p * kStreamBins, c);
   }
   int64_t n = N;
@@ -1594,23 +1602,24 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
   unsigned int tot = 0;
 #pragma unroll
   for (int q = 0; q < BPT; ++q) tot += c[q];
-  unsigned int inc = tot;
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned int v = __shfl_up(inc, o);
-    if (lane >= o) inc += v;
+  unsigned int inc = tot;  // inclusive scan inside the group's lanes of this wave
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) {
+    const unsigned int v = __shfl_up(inc, o, W);
+    if ((lane & (W - 1)) >= o) inc += v;
   }
-  if (r == 0) {
-    s_pb[g] = -1;
-    s_cL[g] = 0;
-    s_cMid[g] = 0;
-    s_low[g] = -1;
-    s_high[g] = B;
+  if (threadIdx.x < NPB) {
+    s_pb[threadIdx.x] = -1;
+    s_cL[threadIdx.x] = 0;
+    s_cMid[threadIdx.x] = 0;
+    s_low[threadIdx.x] = -1;
+    s_high[threadIdx.x] = B;
   }
-  if (G == 256 && lane == 63) wtot[threadIdx.x >> 6] = inc;
+  if (WPG > 1 && lane == 63) wtot[wv] = inc;
   __syncthreads();
   unsigned int run = inc - tot;
-  if (G == 256)
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wtot[w];
+  if (WPG > 1)
+    for (int w = g * WPG; w < wv; ++w) run += wtot[w];
   if (live && run <= nh && nh < run + tot) {  // exactly one thread of the group
     unsigned int a = run;
 #pragma unroll
@@ -1635,8 +1644,8 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
     for (int q = 0; q < BPT; ++q) {
       const int b = r * BPT + q;
       if (c[q]) {
-        if (b < pb) lowb = b;                     // ascending: the last one wins
-        if (b > pb && highb == B) highb = b;      // the first one wins
+        if (b < pb) lowb = b;                 // ascending: the last one wins
+        if (b > pb && highb == B) highb = b;  // the first one wins
       }
     }
     if (lowb >= 0) atomicMax(&s_low[g], lowb);
@@ -1862,17 +1871,20 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
   }
 }
 
-template <class TK>
-__device__ inline void mid_block_path(const MidArgs<TK>& A, const SNode<TK>& a, int t, int j,
+// LDS sort of one pivot bin by the whole block, or (WAVE) by one wave in its private region
+template <class TK, bool WAVE>
+__device__ inline void mid_lds_path(const MidArgs<TK>& A, const SNode<TK>& a, int t, int j,
                                       unsigned char* smem) {
   const int cMid = a.cMid, M = A.M;
   const int64_t N = A.N;
   const int np = next_pow2(cMid);
+  const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int nthr = WAVE ? 64 : (int)blockDim.x;
   TK* skey = reinterpret_cast<TK*>(smem);
   int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
   Keys<TK> K{A.P + (int64_t)t * A.L * N, N, A.level, nullptr};
   const int32_t* m = A.pool + (int64_t)t * N + a.midoff;
-  for (int i = threadIdx.x; i < np; i += blockDim.x) {
+  for (int i = tid; i < np; i += nthr) {
     if (i < cMid) {
       const int id = m[i];
       sid[i] = id;
@@ -1882,13 +1894,14 @@ __device__ inline void mid_block_path(const MidArgs<TK>& A, const SNode<TK>& a, 
       skey[i] = pos_inf<TK>();
     }
   }
-  __syncthreads();
-  lds_bitonic(skey, sid, np, K);
+  if (WAVE) wsync();
+  else __syncthreads();
+  lds_bitonic<TK, WAVE>(skey, sid, np, K);
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
   uint16_t* no = A.node_of + (int64_t)t * N;
   const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
-  for (int i = threadIdx.x; i < cMid; i += blockDim.x) {
+  for (int i = tid; i < cMid; i += nthr) {
     const int side = i >= kk;
     no[sid[i]] = (uint16_t)(2 * j + side);
     if (A.has_next) {
@@ -1911,7 +1924,7 @@ __device__ inline void mid_block_path(const MidArgs<TK>& A, const SNode<TK>& a, 
       }
     }
   }
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     const int n = a.n, nh = a.nh;
     const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
     const int64_t h = (int64_t)t * A.nodes + A.heap0 + j;
@@ -1925,6 +1938,8 @@ __device__ inline void mid_block_path(const MidArgs<TK>& A, const SNode<TK>& a, 
   }
 }
 
+constexpr int kMidWaveLds = 512;  // pivot bins up to this size: LDS sort by one wave
+
 template <class TK>
 __global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, int wave_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1934,8 +1949,14 @@ __global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, 
   int big = 0;
   if (w < npb && jw < A.M) {
     const SNode<TK> a = A.nd[(int64_t)t * A.M + jw];
-    if (a.cMid > wave_max) big = a.cMid <= kSmallCap;  // larger: the host rebuilds (bigmid)
-    else if (a.cMid > 0) mid_wave_path<TK>(A, a, t, jw, lane);
+    if (a.cMid > wave_max) {
+      if (npb > 1 && a.cMid <= kMidWaveLds)  // the waves of the block work on four nodes at once
+        mid_lds_path<TK, true>(A, a, t, jw, smem + (size_t)w * kMidWaveLds * (sizeof(TK) + 4));
+      else
+        big = a.cMid <= kSmallCap;  // larger: the host rebuilds (sflags)
+    } else if (a.cMid > 0) {
+      mid_wave_path<TK>(A, a, t, jw, lane);
+    }
   }
   if (lane == 0) sbig[w] = big;
   __syncthreads();
@@ -1943,7 +1964,7 @@ __global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, 
     if (!sbig[q]) continue;  // block-uniform
     const int j = blockIdx.x * npb + q;
     const SNode<TK> a = A.nd[(int64_t)t * A.M + j];
-    mid_block_path<TK>(A, a, t, j, smem);
+    mid_lds_path<TK, false>(A, a, t, j, smem);
     __syncthreads();
   }
 }
@@ -2349,11 +2370,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         switch (stream_bins(M)) {
           case 4096: RPT_PICK(16, 256); break;
           case 2048: RPT_PICK(8, 256); break;
-          case 1024: RPT_PICK(4, 256); break;
+          case 1024: RPT_PICK(8, 128); break;
           case 512: RPT_PICK(8, 64); break;
-          case 256: RPT_PICK(4, 64); break;
-          case 128: RPT_PICK(2, 64); break;
-          default: RPT_PICK(1, 64); break;
+          case 256: RPT_PICK(8, 32); break;
+          case 128: RPT_PICK(8, 16); break;
+          default: RPT_PICK(8, 8); break;
         }
 #undef RPT_PICK
         hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, node_of.p, N,
