@@ -489,17 +489,17 @@ __global__ __launch_bounds__(WAVES * 64) void proj_mfma(const TIn* __restrict__ 
 //     with each other (wave-private LDS tile).
 // ---------------------------------------------------------------------------------------
 template <class TC>
-__global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, int nblk,
-                             TC* __restrict__ Apad /*[nblk][2][D/4][64]*/) {
+__global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, int nblk, int cbt,
+                             int col0, TC* __restrict__ Apad /*[nblk][cbt][D/4][64]*/) {
   const int steps = D / 4;
-  const int64_t total = (int64_t)nblk * 2 * steps * 64;
+  const int64_t total = (int64_t)nblk * cbt * steps * 64;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     const int s = (int)((i >> 6) % steps);
-    const int h = (int)((i / (64 * (int64_t)steps)) & 1);
-    const int blk = (int)(i / (128 * (int64_t)steps));
-    const int col = blk * 32 + h * 16 + (lane & 15);
+    const int h = (int)((i / (64 * (int64_t)steps)) % cbt);
+    const int blk = (int)(i / (64 * (int64_t)steps * cbt));
+    const int col = col0 + blk * 16 * cbt + h * 16 + (lane & 15);
     const int k = 4 * s + (lane >> 4);
     Apad[i] = (col < C && k < d) ? (TC)R[(int64_t)col * d + k] : (TC)0;
   }
@@ -574,6 +574,109 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
       for (int h = 0; h < CBT; ++h) acc[h] = Mfma<TC>::run(a[h][s], b, acc[h]);
     }
     const int64_t row = t * 16 + m;             // D col = lane&15 = point
+    if (row < n) {
+#pragma unroll
+      for (int h = 0; h < CBT; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
+          if (col < ncol) P[(int64_t)(c0 + col) * ldp + row] = acc[h][r];
+        }
+    }
+    t = tn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Wide MFMA path (rows of exactly D elements): 16*CBT hyperplanes per pass over X, so the
+// point set is read ceil(C / (16*CBT)) times instead of ceil(C / 32) times.  The hyperplane
+// fragments no longer fit in registers (CBT * D/4 values per lane): they live in LDS, in
+// fragment order (one conflict-free ds_read per MFMA), shared by the 8 waves of the one
+// workgroup a CU holds.  Each wave stages HALF a 16-row tile at a time (16 rows x D/2
+// elements, wave-private LDS region, same register-prefetch pipeline as proj_mfma_fast):
+//   LDS = CBT*D/4*64*sizeof(TC) + 8 * 16*(D/2 + pad)*sizeof(TC)   (f64, CBT 4: 64 + 66 KB)
+// f64: one v_mfma_f64_16x16x4 is 64 cycles, a tile costs CBT*32 of them per wave: at CBT = 4
+// the matrix pipe is ~70 % busy when HBM delivers its 5 TB/s — the kernel sits where the two
+// rooflines cross, which is the point of reading X less often.
+// ---------------------------------------------------------------------------------------
+template <class TIn, class TC, int D, int CBT>
+__global__ __launch_bounds__(512, 1) void proj_mfma_wide(const TIn* __restrict__ X, int64_t n,
+                                                         const TC* __restrict__ Apad, int c0,
+                                                         int ncol, TC* __restrict__ P,
+                                                         int64_t ldp, int64_t ntiles) {
+  constexpr int STEPS = D / 4, HSTEPS = STEPS / 2, KH = D / 2;
+  constexpr int PIECE = 16 / (int)sizeof(TIn);  // elements per 16-B piece
+  constexpr int PPR = KH / PIECE;               // pieces per half row
+  constexpr int NP = 16 * PPR / 64;             // pieces per lane per half tile
+  constexpr int LDW = KH + 16 / (int)sizeof(TC);
+  static_assert((16 * PPR) % 64 == 0, "half tile must be a multiple of 64 pieces");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
+  TC* As = reinterpret_cast<TC*>(wide_smem);                   // [CBT][STEPS][64]
+  TC* tiles = As + (size_t)CBT * STEPS * 64;                   // [8][16 * LDW]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  TC* my = tiles + (size_t)wave * 16 * LDW;
+  typedef typename Mfma<TC>::acc_t acc_t;
+  struct alignas(16) Raw { TIn v[PIECE]; };
+
+  for (int i = threadIdx.x; i < CBT * STEPS * 64; i += 512) As[i] = Apad[i];
+  __syncthreads();
+
+  const int64_t wave_global = (int64_t)blockIdx.x * 8 + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * 8;
+  const int64_t last_row = n - 1;
+
+  Raw stage[NP];
+  auto issue = [&](int64_t t, int half) {
+    const int64_t row0 = t * 16;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = i * 64 + lane;
+      int64_t row = row0 + p / PPR;
+      row = row < last_row ? row : last_row;
+      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + half * KH + (p % PPR) * PIECE);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = i * 64 + lane;
+      TC* dst = my + (p / PPR) * LDW + (p % PPR) * PIECE;
+#pragma unroll
+      for (int j = 0; j < PIECE; ++j) {
+        if constexpr (sizeof(TIn) == sizeof(TC)) dst[j] = (TC)stage[i].v[j];
+        else dst[j] = (TC)to_f32<TIn>(stage[i].v[j]);
+      }
+    }
+  };
+
+  int64_t t = wave_global;
+  if (t < ntiles) issue(t, 0);
+  while (t < ntiles) {
+    acc_t acc[CBT];
+#pragma unroll
+    for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
+    commit();          // first half: waits for the staged pieces, writes LDS
+    issue(t, 1);       // second half in flight during the MFMA phase
+#pragma unroll
+    for (int s = 0; s < HSTEPS; ++s) {
+      const TC b = my[m * LDW + 4 * s + q];
+#pragma unroll
+      for (int h = 0; h < CBT; ++h)
+        acc[h] = Mfma<TC>::run(As[(h * STEPS + s) * 64 + lane], b, acc[h]);
+    }
+    commit();
+    const int64_t tn = t + wave_stride;
+    if (tn < ntiles) issue(tn, 0);
+#pragma unroll
+    for (int s = 0; s < HSTEPS; ++s) {
+      const TC b = my[m * LDW + 4 * s + q];
+#pragma unroll
+      for (int h = 0; h < CBT; ++h)
+        acc[h] = Mfma<TC>::run(As[(h * STEPS + HSTEPS + s) * 64 + lane], b, acc[h]);
+    }
+    const int64_t row = t * 16 + m;  // D col = lane&15 = point
     if (row < n) {
 #pragma unroll
       for (int h = 0; h < CBT; ++h)
@@ -687,18 +790,52 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                     TC* P) {
   const int64_t n = ds->n;
   const int64_t ntiles = (n + 15) / 16;
-  if (ds->d == 128) {  // guard-free pipelined path
-    constexpr int D = 128;
-    const int nblk = (C + 31) / 32;
-    DevBuf<TC> Apad;
-    RPT_TRY(Apad.alloc((size_t)nblk * 2 * (D / 4) * 64));
-    hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D,
-                       nblk, Apad.p);
+  if (ds->d == 128) {  // guard-free pipelined paths
+    constexpr int D = 128, CBW = 4;  // wide passes: 64 hyperplanes per read of X
+    const bool wide_ok = !getenv("RPT_PROJ_NARROW");
+    // wide passes while more than 32 columns remain, the 32-column kernel for a short tail
+    int nwide = 0;
+    if (wide_ok) {
+      nwide = C / (16 * CBW);
+      if (C - nwide * 16 * CBW > 32) ++nwide;
+    }
+    const int cw = nwide * 16 * CBW < C ? nwide * 16 * CBW : C;  // columns done by wide passes
+    const int nblk = (C - cw + 31) / 32;
+    DevBuf<TC> ApadW, Apad;
+    if (nwide) {
+      RPT_TRY(ApadW.alloc((size_t)nwide * CBW * (D / 4) * 64));
+      hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D,
+                         nwide, CBW, 0, ApadW.p);
+      constexpr size_t smem = ((size_t)CBW * (D / 4) * 64 + (size_t)8 * 16 * (D / 2 + 16 / sizeof(TC))) *
+                              sizeof(TC);
+      static bool attr_done = false;
+      if (!attr_done) {
+        RPT_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBW>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+      }
+      int64_t blocks = (ntiles + 7) / 8;
+      if (blocks > ctx->n_cu) blocks = ctx->n_cu;
+      for (int b = 0; b < nwide; ++b) {
+        const int c0 = b * 16 * CBW;
+        const int ncol = C - c0 < 16 * CBW ? C - c0 : 16 * CBW;
+        ProfScope ps(ctx, RPT_PROF_PROJECT);
+        hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBW>), dim3((unsigned)blocks), dim3(512),
+                           smem, ctx->stream, (const TIn*)ds->X, n,
+                           ApadW.p + (size_t)b * CBW * (D / 4) * 64, c0, ncol, P, n, ntiles);
+      }
+    }
+    if (nblk) {
+      RPT_TRY(Apad.alloc((size_t)nblk * 2 * (D / 4) * 64));
+      hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D,
+                         nblk, 2, cw, Apad.p);
+    }
     int64_t blocks = (ntiles + 3) / 4;
     const int64_t cap = (int64_t)ctx->n_cu * 2;
     if (blocks > cap) blocks = cap;
     for (int b = 0; b < nblk; ++b) {
-      const int c0 = b * 32;
+      const int c0 = cw + b * 32;
       const int ncol = C - c0 < 32 ? C - c0 : 32;
       const TC* Ab = Apad.p + (size_t)b * 2 * (D / 4) * 64;
       ProfScope ps(ctx, RPT_PROF_PROJECT);
@@ -710,8 +847,8 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                            ctx->stream, (const TIn*)ds->X, n, Ab, c0, ncol, P, n, ntiles);
     }
     RPT_HIP(hipGetLastError());
-    RPT_HIP(stream_sync(ctx->stream));  // Apad is released on return
-    return RPT_OK;
+    return RPT_OK;  // the pad buffers return to the allocator, which recycles them only after
+                    // the stream has been synchronised
   }
   constexpr int WAVES = 4;
   int64_t blocks = (ntiles + WAVES - 1) / WAVES;
