@@ -764,8 +764,10 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     TK* __restrict__ Kleaf, int64_t N, const TK* __restrict__ P, int L, int T, int level0,
     int min_leaf, const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
     int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
-    unsigned int* ovf_count, const unsigned int* __restrict__ abort) {
+    unsigned int* ovf_count, const unsigned int* __restrict__ abort, unsigned long long* dbg) {
   __shared__ WSlab slabs[4];
+  int dbgi = 0;
+#define WSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) dbg[dbgi++] = clock64(); } while (0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
   if (wg >= (int64_t)S * T) return;
@@ -788,12 +790,13 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     st[e] = 0;
     key[e] = (TK)0;
   }
-
   int depth = 0;
   bool overflow = false;
+  WSTAMP();
   for (; depth < kWRmax; ++depth) {
     const int level = level0 + depth;
     if (level >= L) break;
+    WSTAMP();
     int act = 0;
 #pragma unroll
     for (int e = 0; e < kWE; ++e) act |= (id[e] >= 0 && st[e] >= 0);
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       for (int e = 0; e < kWE; ++e)
         if (id[e] >= 0 && st[e] >= 0) key[e] = Pl[id[e]];
     }
+    WSTAMP();
     // ---- b. per-node min / max ----
     if (lane < M) {
       W.nmin[lane] = ~0ULL;
@@ -848,6 +852,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
         }
     }
     wsync();
+    WSTAMP();
     // ---- c. bin geometry ----
     if (lane < M) {
       SubNode a;
@@ -878,6 +883,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     for (int e = 0; e < kWE; ++e)
       if (id[e] >= 0 && st[e] >= 0) atomicAdd(&W.hist[st[e] * B + bin_of_e(key[e], st[e])], 1u);
     wsync();
+    WSTAMP();
     // ---- e. pivot bin per node (the whole wave scans one node at a time) ----
     for (int j = 0; j < M; ++j) {
       if (W.sn[j].n <= 0) continue;
@@ -929,6 +935,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       }
     }
     wsync();
+    WSTAMP();
     // ---- f. pool the pivot bins ----
     int tot = 0;
     if (lane == 0) {
@@ -959,6 +966,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       }
     }
     wsync();
+    WSTAMP();
     // ---- g. exact rank inside the pivot bin, node outputs, h. descend ----
 #pragma unroll
     for (int e = 0; e < kWE; ++e) {
@@ -1005,6 +1013,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       if (a.nh > 0 && !(vlo < W.vthr[lane])) atomicAdd(tie_count, 1ULL);
     }
     wsync();
+    WSTAMP();
   }
   if (overflow) {
     if (lane == 0) {
@@ -1014,6 +1023,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     return;
   }
 
+  WSTAMP();
   // ---- scatter every point to the slot range of its terminal node ----
   // lane v < 32: offset of the terminal whose left-aligned path is v
   if (lane < (1 << kWRmax)) {
@@ -1048,6 +1058,8 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       on[slot] = id[e];
     }
   }
+  WSTAMP();
+#undef WSTAMP
 }
 
 // order one leaf bucket per wave: (key of the parent's level, earlier levels, id).  The bucket
@@ -1426,7 +1438,7 @@ __global__ __launch_bounds__(256) void mid_kernel(int32_t* __restrict__ dst, int
 // A pivot bin larger than LDS (heavy ties / extreme outliers) makes the host leave the
 // streaming path at that level (the gather path has the general fallbacks).
 // ---------------------------------------------------------------------------------------
-constexpr int kStreamMaxNodes = 512;
+constexpr int kStreamMaxNodes = 1024;
 constexpr int kStreamBins = 32768;      // histogram entries per block: 16-bit counters packed
                                         // two per LDS word (64 KB); a block sees < 65536 points
 constexpr int kStreamThreads = 1024;
@@ -1681,8 +1693,8 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
     unsigned long long* cmin_next, unsigned long long* cmax_next) {
   __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
-  __shared__ int npb[kStreamMaxNodes], nlowb[kStreamMaxNodes], nhighb[kStreamMaxNodes],
-      nmidoff[kStreamMaxNodes];
+  __shared__ short npb[kStreamMaxNodes], nlowb[kStreamMaxNodes], nhighb[kStreamMaxNodes];
+  __shared__ int nmidoff[kStreamMaxNodes];
   __shared__ unsigned long long smin[2 * kStreamMaxNodes], smax[2 * kStreamMaxNodes];
   const int t = blockIdx.y;
   const int B = stream_bins(M);
@@ -1690,9 +1702,9 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
     nlo[j] = ndt[j].lo;
     nsc[j] = ndt[j].scale;
-    npb[j] = ndt[j].pb;
-    nlowb[j] = ndt[j].lowb;
-    nhighb[j] = ndt[j].highb;
+    npb[j] = (short)ndt[j].pb;  // bins <= 4096: -2 .. 4097 fit 16 bits
+    nlowb[j] = (short)ndt[j].lowb;
+    nhighb[j] = (short)ndt[j].highb;
     nmidoff[j] = ndt[j].midoff;
   }
   for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
@@ -1705,6 +1717,10 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   uint16_t* no = node_of + (int64_t)t * N;
   int32_t* pl = pool + (int64_t)t * N;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+  // The children's min/max of the NEXT level's key only shape that level's bins (keys outside
+  // the range are clamped into the edge bins), so a sample is enough: the first quarter of the
+  // block's points — every point while nodes are small.
+  const int64_t isamp = (N >> level) < 8192 ? i1 : i0 + ((i1 - i0 + 3) >> 2);
   // few nodes: a per-thread running min/max per child avoids hammering one LDS word
   const bool few = M <= 4;
   unsigned long long tmn[8], tmx[8];
@@ -1727,7 +1743,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     no[i] = (uint16_t)child;
     if (b == nlowb[j]) atomicMax(&ndt[j].maxL, ord_of(key));
     if (b == nhighb[j]) atomicMin(&ndt[j].minR, ord_of(key));
-    if (has_next) {
+    if (has_next && i < isamp) {
       const unsigned long long o = ord_of(Pn[i]);
       if (few) {
 #pragma unroll
@@ -2315,9 +2331,15 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   // ---- streaming path for the leading levels ----
   int Lstream = 0;
   if (N >= 2048 && !no_stream && !getenv("RPT_NO_STREAM"))
+  {
+    // measured at C2: with 32 bins per node (1024 nodes) an eighth of all points lands in pivot
+    // bins and the exact resolution eats what the shorter wave phase saves -> 512 by default
+    int max_nodes = getenv("RPT_STREAM_MAXNODES") ? atoi(getenv("RPT_STREAM_MAXNODES")) : 512;
+    if (max_nodes > kStreamMaxNodes) max_nodes = kStreamMaxNodes;
     while (Lstream < Lused && splits[(size_t)Lstream].size() == ((size_t)1 << Lstream) &&
-           (1 << Lstream) <= kStreamMaxNodes)
+           (1 << Lstream) <= max_nodes)
       ++Lstream;
+  }
   int streamed = 0;  // levels completed by the streaming path
   if (Lstream > 0) {
     DevBuf<uint16_t> node_of;
@@ -2374,7 +2396,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           case 512: RPT_PICK(8, 64); break;
           case 256: RPT_PICK(8, 32); break;
           case 128: RPT_PICK(8, 16); break;
-          default: RPT_PICK(8, 8); break;
+          case 64: RPT_PICK(8, 8); break;
+          default: RPT_PICK(8, 4); break;  // 32 bins: 1024 nodes
         }
 #undef RPT_PICK
         hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, node_of.p, N,
@@ -2522,7 +2545,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
                            st, cur, nxt, F, Kleaf.p, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
                            f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, df.ovf.p + 1,
-                           df.ovf.p, (const unsigned int*)sflags.p);
+                           df.ovf.p, (const unsigned int*)sflags.p, dbgbuf);
         // leaves created by the wave kernel still need their order; nodes it left active stay
         // pending
         std::vector<Seg> wl_small, rest;
