@@ -746,14 +746,17 @@ constexpr int kWRmax = 5;         // levels per launch (<= 16 nodes at the deepe
 constexpr int kWHist = 1024;      // histogram entries per wave
 constexpr int kWMid = 192;        // pivot-bin pool per wave
 
+constexpr int kWPivot = 1 << 30;  // st flag: the point sits in its node's pivot-bin pool
+
 struct WSlab {
-  unsigned int hist[kWHist];
-  unsigned long long nmin[16], nmax[16], nmaxL[16], nminR[16];
-  double nlo[16], nscale[16];
-  SubNode sn[16];
+  unsigned int hist[kWHist + 64];  // skewed: bin idx lives at idx + (idx >> 4)
+  unsigned long long nmaxL[16], nminR[16];
+  int4 pf[16];  // per node: pivot bin, low edge bin, high edge bin, pool offset
+  int4 pg[16];  // per node: cL, nh, n, cMid
   int midcur[16];
   double midkey[kWMid];
   int midid[kWMid];
+  int midnode[kWMid], midside[kWMid];
   int toff[32], tcur[32];
   double vthr[16], vlo[16];
 };
@@ -813,204 +816,214 @@ __global__ __launch_bounds__(256) void wsub_kernel(
         if (id[e] >= 0 && st[e] >= 0) key[e] = Pl[id[e]];
     }
     WSTAMP();
-    // ---- b. per-node min / max ----
-    if (lane < M) {
-      W.nmin[lane] = ~0ULL;
-      W.nmax[lane] = 0ULL;
+    // ---- b. one value range for all nodes of the level (the children of a node are random
+    // halves of it with respect to THIS level's key, so they span about the same range; keys
+    // outside the range clamp to the edge bins).  No per-node LDS atomics.
+    double kmn = __builtin_huge_val(), kmx = -__builtin_huge_val();
+#pragma unroll
+    for (int e = 0; e < kWE; ++e)
+      if (id[e] >= 0 && st[e] >= 0) {
+        const double k = (double)key[e];
+        kmn = k < kmn ? k : kmn;
+        kmx = k > kmx ? k : kmx;
+      }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double a = __shfl_xor(kmn, o), b = __shfl_xor(kmx, o);
+      kmn = a < kmn ? a : kmn;
+      kmx = b > kmx ? b : kmx;
+    }
+    const TK lo = (TK)kmn;
+    const TK scale = kmn < kmx ? (TK)((double)B / (kmx - kmn)) : (TK)0;
+#pragma unroll
+    for (int i = 0; i < (kWHist + 64) / 64; ++i) W.hist[i * 64 + lane] = 0;
+    if (lane < 16) {
       W.nmaxL[lane] = 0ULL;
       W.nminR[lane] = ~0ULL;
       W.midcur[lane] = 0;
     }
-#pragma unroll
-    for (int i = 0; i < kWHist / 64; ++i) W.hist[i * 64 + lane] = 0;
-    wsync();
-    if (M == 1) {
-      unsigned long long mn = ~0ULL, mx = 0ULL;
-#pragma unroll
-      for (int e = 0; e < kWE; ++e)
-        if (id[e] >= 0 && st[e] >= 0) {
-          const unsigned long long o = ord_of(key[e]);
-          mn = o < mn ? o : mn;
-          mx = o > mx ? o : mx;
-        }
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-      }
-      if (lane == 0) {
-        W.nmin[0] = mn;
-        W.nmax[0] = mx;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < kWE; ++e)
-        if (id[e] >= 0 && st[e] >= 0) {
-          const unsigned long long o = ord_of(key[e]);
-          atomicMin(&W.nmin[st[e]], o);
-          atomicMax(&W.nmax[st[e]], o);
-        }
-    }
     wsync();
     WSTAMP();
-    // ---- c. bin geometry ----
-    if (lane < M) {
-      SubNode a;
-      a.n = sub_node_size(n_top, depth, lane);
-      a.nh = a.n >> 1;
-      a.pb = -1;
-      a.cL = a.cMid = 0;
-      a.lowb = -1;
-      a.highb = B;
-      a.midoff = 0;
-      W.sn[lane] = a;
-      if (W.nmin[lane] != ~0ULL) {
-        const TK lo = ord_to(W.nmin[lane], TK()), hi = ord_to(W.nmax[lane], TK());
-        W.nlo[lane] = (double)lo;
-        W.nscale[lane] = lo < hi ? (double)((TK)B / (hi - lo)) : 0.0;
-      } else {
-        W.nlo[lane] = 0.0;
-        W.nscale[lane] = 0.0;
-      }
-    }
-    wsync();
-    auto bin_of_e = [&](TK k, int j) {
-      int b = (int)((k - (TK)W.nlo[j]) * (TK)W.nscale[j]);
-      return b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
-    };
-    // ---- d. histogram ----
+    // ---- c. bins + histogram.  st keeps (bin << 8 | node) for the later phases; the
+    // histogram is skewed by one word per 16 bins so that lane-strided scans are conflict-free
 #pragma unroll
     for (int e = 0; e < kWE; ++e)
-      if (id[e] >= 0 && st[e] >= 0) atomicAdd(&W.hist[st[e] * B + bin_of_e(key[e], st[e])], 1u);
+      if (id[e] >= 0 && st[e] >= 0) {
+        const int j = st[e];
+        int b = (int)((key[e] - lo) * scale);
+        b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
+        const int idx = j * B + b;
+        atomicAdd(&W.hist[idx + (idx >> 4)], 1u);
+        st[e] = j | (b << 8);
+      }
     wsync();
     WSTAMP();
-    // ---- e. pivot bin per node (the whole wave scans one node at a time) ----
-    for (int j = 0; j < M; ++j) {
-      if (W.sn[j].n <= 0) continue;
-      const unsigned int nh = (unsigned int)W.sn[j].nh;
-      const int per = B / 64;  // B >= 64
-      unsigned int loc = 0;
-      for (int i = 0; i < per; ++i) loc += W.hist[j * B + lane * per + i];
-      unsigned int inc = loc;
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned int v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-      }
-      unsigned int run = inc - loc;
-      int pb = -1, cL = 0, cMid = 0, lowb = -1, highb = B;
-      for (int i = 0; i < per; ++i) {
-        const int b = lane * per + i;
-        const unsigned int c = W.hist[j * B + b];
-        if (run <= nh && nh < run + c) {
-          pb = b;
-          cL = (int)run;
-          cMid = (int)c;
+    // ---- e. pivot bins of ALL nodes in one pass: lane owns 16 consecutive bins, a node owns
+    // Wd = 64/M consecutive lanes
+    const int Wd = 64 >> depth, lw = 6 - depth;
+    const int jl = lane >> lw, rl = lane & (Wd - 1);
+    const int nj = sub_node_size(n_top, depth, jl), nhj = nj >> 1;
+    unsigned int c[16];
+    unsigned int loc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      c[i] = W.hist[lane * 17 + i];
+      loc += c[i];
+    }
+    unsigned int inc = loc;
+    for (int o = 1; o < Wd; o <<= 1) {
+      const unsigned int v = __shfl_up(inc, o, Wd);
+      if (rl >= o) inc += v;
+    }
+    int pb = -1, cL = 0, cMid = 0;
+    {
+      unsigned int a = inc - loc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (c[i] && a <= (unsigned int)nhj && (unsigned int)nhj < a + c[i]) {
+          pb = rl * 16 + i;
+          cL = (int)a;
+          cMid = (int)c[i];
         }
-        run += c;
-      }
-      const unsigned long long own = __ballot(pb >= 0);
-      if (!own) continue;  // phantom slot below a Tip
-      const int src_lane = __ffsll((long long)own) - 1;
-      pb = __shfl(pb, src_lane);
-      cL = __shfl(cL, src_lane);
-      cMid = __shfl(cMid, src_lane);
-      for (int i = 0; i < per; ++i) {
-        const int b = lane * per + i;
-        if (W.hist[j * B + b]) {
-          if (b < pb) lowb = b > lowb ? b : lowb;
-          if (b > pb) highb = b < highb ? b : highb;
-        }
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        const int x = __shfl_xor(lowb, o), y = __shfl_xor(highb, o);
-        lowb = x > lowb ? x : lowb;
-        highb = y < highb ? y : highb;
-      }
-      if (lane == 0) {
-        W.sn[j].pb = pb;
-        W.sn[j].cL = cL;
-        W.sn[j].cMid = cMid;
-        W.sn[j].lowb = lowb;
-        W.sn[j].highb = highb;
+        a += c[i];
       }
     }
-    wsync();
-    WSTAMP();
-    // ---- f. pool the pivot bins ----
-    int tot = 0;
-    if (lane == 0) {
-      for (int j = 0; j < M; ++j) {
-        W.sn[j].midoff = tot;
-        tot += W.sn[j].cMid;
+    const unsigned long long found = __ballot(pb >= 0);
+    const unsigned long long segm = (Wd == 64 ? ~0ULL : ((1ULL << Wd) - 1ULL)) << (jl * Wd);
+    const unsigned long long own = found & segm;
+    const int srcl = own ? __ffsll((long long)own) - 1 : lane;  // phantom slot below a Tip: none
+    pb = __shfl(pb, srcl);
+    cL = __shfl(cL, srcl);
+    cMid = __shfl(cMid, srcl);
+    const int il = nhj > 0 ? nhj - 1 : 0, ih = nhj + 1 < nj ? nhj + 1 : nj - 1;
+    // the margins p'[nh-1] / p'[nh+1] leave the pivot bin only at its edges: only then the
+    // points of the nearest non-empty bins are tracked (max of the left one, min of the right)
+    const bool need_lo = il < cL, need_hi = ih >= cL + cMid;
+    int lowb = -1, highb = B;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int bb = rl * 16 + i;
+      if (c[i]) {
+        if (bb < pb) lowb = bb;
+        if (bb > pb && highb == B) highb = bb;
       }
     }
-    tot = __shfl(tot, 0);
+    for (int o = 1; o < Wd; o <<= 1) {
+      const int x = __shfl_xor(lowb, o), y = __shfl_xor(highb, o);
+      lowb = x > lowb ? x : lowb;
+      highb = y < highb ? y : highb;
+    }
+    // offsets of the pivot bins in the wave's pool: prefix over the nodes
+    const int mine = (rl == 0 && own) ? cMid : 0;
+    int pinc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(pinc, o);
+      if (lane >= o) pinc += v;
+    }
+    const int tot = __shfl(pinc, 63);
+    if (rl == 0) {
+      W.pf[jl] = make_int4(own ? pb : -1, need_lo ? lowb : -2, need_hi ? highb : B + 1, pinc - mine);
+      W.pg[jl] = make_int4(cL, nhj, nj, own ? cMid : 0);
+    }
     if (tot > kWMid) {
       overflow = true;
       break;
     }
     wsync();
+    WSTAMP();
+    // ---- f. pool the pivot bins; every other point descends right away.  The node records
+    // are fetched four points at a time so that the LDS round trips overlap.
 #pragma unroll
-    for (int e = 0; e < kWE; ++e) {
-      if (id[e] < 0 || st[e] < 0) continue;
-      const int j = st[e];
-      const int b = bin_of_e(key[e], j);
-      if (b == W.sn[j].pb) {
-        const int p = W.sn[j].midoff + atomicAdd(&W.midcur[j], 1);
-        W.midkey[p] = (double)key[e];
-        W.midid[p] = id[e];
-      } else if (b == W.sn[j].lowb) {
-        atomicMax(&W.nmaxL[j], ord_of(key[e]));
-      } else if (b == W.sn[j].highb) {
-        atomicMin(&W.nminR[j], ord_of(key[e]));
+    for (int e0 = 0; e0 < kWE; e0 += 4) {
+      int4 pf4[4], pg4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u;
+        const int j = (id[e] >= 0 && st[e] >= 0) ? (st[e] & 0xff) : 0;
+        pf4[u] = W.pf[j];
+        pg4[u] = W.pg[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u;
+        if (id[e] < 0 || st[e] < 0) continue;
+        const int j = st[e] & 0xff, b = st[e] >> 8;
+        if (b == pf4[u].x) {
+          const int p = pf4[u].w + atomicAdd(&W.midcur[j], 1);
+          W.midkey[p] = (double)key[e];
+          W.midid[p] = id[e];
+          W.midnode[p] = j;
+          st[e] = j | (p << 8) | kWPivot;
+          continue;
+        }
+        if (b == pf4[u].y) atomicMax(&W.nmaxL[j], ord_of(key[e]));
+        else if (b == pf4[u].z) atomicMin(&W.nminR[j], ord_of(key[e]));
+        const int side = b > pf4[u].x;
+        const int child = 2 * j + side;
+        const int nc = side ? pg4[u].z - pg4[u].y : pg4[u].y;
+        if (level + 1 >= L || nc <= min_leaf)
+          st[e] = -(((child << (kWRmax - (depth + 1))) << 8) | (level + 1));
+        else
+          st[e] = child;
       }
     }
     wsync();
     WSTAMP();
-    // ---- g. exact rank inside the pivot bin, node outputs, h. descend ----
-#pragma unroll
-    for (int e = 0; e < kWE; ++e) {
-      if (id[e] < 0 || st[e] < 0) continue;
-      const int j = st[e];
-      const SubNode a = W.sn[j];
-      const int b = bin_of_e(key[e], j);
-      int side = b > a.pb;
-      if (b == a.pb) {
+    // ---- g. exact order inside the pivot bins: one lane per pooled point
+    for (int p0 = 0; p0 < tot; p0 += 64) {
+      const int p = p0 + lane;
+      if (p < tot) {
+        const int j = W.midnode[p];
+        const int4 pf = W.pf[j], pg = W.pg[j];
+        const TK kp = (TK)W.midkey[p];
+        const int ip = W.midid[p];
         int rank = 0;
-        for (int q = a.midoff; q < a.midoff + a.cMid; ++q)
-          if (W.midid[q] != id[e] && K.less((TK)W.midkey[q], W.midid[q], key[e], id[e])) ++rank;
-        const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+        for (int q = pf.w; q < pf.w + pg.w; ++q)
+          if (q != p && K.less((TK)W.midkey[q], W.midid[q], kp, ip)) ++rank;
+        const int cLj = pg.x, nh = pg.y, n = pg.z;
+        const int il2 = nh > 0 ? nh - 1 : 0, ih2 = nh + 1 < n ? nh + 1 : n - 1;
         const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
-        if (rank == a.nh - a.cL) {
-          thr[h] = (double)key[e];
-          W.vthr[j] = (double)key[e];
+        if (rank == nh - cLj) {
+          thr[h] = (double)kp;
+          W.vthr[j] = (double)kp;
         }
-        if (rank == il - a.cL) {
-          mglo[h] = (double)key[e];
-          W.vlo[j] = (double)key[e];
+        if (rank == il2 - cLj) {
+          mglo[h] = (double)kp;
+          W.vlo[j] = (double)kp;
         }
-        if (rank == ih - a.cL) mghi[h] = (double)key[e];
-        side = rank >= a.nh - a.cL;
+        if (rank == ih2 - cLj) mghi[h] = (double)kp;
+        W.midside[p] = rank >= nh - cLj;
       }
-      const int child = 2 * j + side;
-      const int nc = side ? a.n - a.nh : a.nh;
-      if (level + 1 >= L || nc <= min_leaf)
-        st[e] = -(((child << (kWRmax - (depth + 1))) << 8) | (level + 1));
-      else
-        st[e] = child;
     }
     wsync();
-    if (lane < M && W.sn[lane].cMid > 0) {
-      const SubNode a = W.sn[lane];
-      const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+    // the owners of the pooled points descend
+#pragma unroll
+    for (int e = 0; e < kWE; ++e) {
+      const bool piv = id[e] >= 0 && st[e] >= 0 && (st[e] & kWPivot);
+      if (!__any(piv)) continue;
+      if (piv) {
+        const int j = st[e] & 0xff, p = (st[e] >> 8) & 0xffff;
+        const int4 pg = W.pg[j];
+        const int side = W.midside[p];
+        const int child = 2 * j + side;
+        const int nc = side ? pg.z - pg.y : pg.y;
+        if (level + 1 >= L || nc <= min_leaf)
+          st[e] = -(((child << (kWRmax - (depth + 1))) << 8) | (level + 1));
+        else
+          st[e] = child;
+      }
+    }
+    if (lane < M && W.pg[lane].w > 0) {
+      const int4 pg = W.pg[lane];
+      const int cLj = pg.x, nh = pg.y, n = pg.z, cM = pg.w;
+      const int il2 = nh > 0 ? nh - 1 : 0, ih2 = nh + 1 < n ? nh + 1 : n - 1;
       const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + lane);
       double vlo = W.vlo[lane];
-      if (il < a.cL) {
+      if (il2 < cLj) {
         vlo = (double)ord_to(W.nmaxL[lane], TK());
         mglo[h] = vlo;
       }
-      if (ih >= a.cL + a.cMid) mghi[h] = (double)ord_to(W.nminR[lane], TK());
-      if (a.nh > 0 && !(vlo < W.vthr[lane])) atomicAdd(tie_count, 1ULL);
+      if (ih2 >= cLj + cM) mghi[h] = (double)ord_to(W.nminR[lane], TK());
+      if (nh > 0 && !(vlo < W.vthr[lane])) atomicAdd(tie_count, 1ULL);
     }
     wsync();
     WSTAMP();
