@@ -592,27 +592,35 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
 // point set is read ceil(C / (16*CBT)) times instead of ceil(C / 32) times.  The hyperplane
 // fragments no longer fit in registers (CBT * D/4 values per lane): they live in LDS, in
 // fragment order (one conflict-free ds_read per MFMA), shared by the 8 waves of the one
-// workgroup a CU holds.  Each wave stages HALF a 16-row tile at a time (16 rows x D/2
-// elements, wave-private LDS region, same register-prefetch pipeline as proj_mfma_fast):
-//   LDS = CBT*D/4*64*sizeof(TC) + 8 * 16*(D/2 + pad)*sizeof(TC)   (f64, CBT 4: 64 + 66 KB)
-// f64: one v_mfma_f64_16x16x4 is 64 cycles, a tile costs CBT*32 of them per wave: at CBT = 4
-// the matrix pipe is ~70 % busy when HBM delivers its 5 TB/s — the kernel sits where the two
-// rooflines cross, which is the point of reading X less often.
+// workgroup a CU holds.  Each wave stages a 1/KS K-slice of a 16-row tile at a time (16 rows x
+// D/KS elements, wave-private LDS region) through two register stages: a slice is requested
+// two MFMA phases before it is needed.
+//   LDS = CBT*D/4*64*sizeof(TC) + 8 * 16*(D/KS + pad)*sizeof(TC)
+//       f64: CBT 4, KS 2: 64 + 66 KB;  CBT 6, KS 4: 96 + 34 KB
+// f64: one v_mfma_f64_16x16x4 is 64 cycles and a tile costs CBT*32 of them per wave: at
+// CBT = 6 the matrix pipe needs 0.31 ms per pass and HBM (1.79 GB) about as long — the kernel
+// sits where the two rooflines cross, which is the point of reading X less often.
 // ---------------------------------------------------------------------------------------
-template <class TIn, class TC, int D, int CBT>
-__global__ __launch_bounds__(512, 1) void proj_mfma_wide(const TIn* __restrict__ X, int64_t n,
+template <class TC, int D, int CBT, int KS, int WPB>
+constexpr size_t wide_smem_bytes() {
+  return ((size_t)CBT * (D / 4) * 64 + (size_t)WPB * 16 * (D / KS + 16 / sizeof(TC))) * sizeof(TC);
+}
+
+template <class TIn, class TC, int D, int CBT, int KS, int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0,
                                                          int ncol, TC* __restrict__ P,
                                                          int64_t ldp, int64_t ntiles) {
-  constexpr int STEPS = D / 4, HSTEPS = STEPS / 2, KH = D / 2;
+  constexpr int STEPS = D / 4, SSTEPS = STEPS / KS, KW = D / KS;
   constexpr int PIECE = 16 / (int)sizeof(TIn);  // elements per 16-B piece
-  constexpr int PPR = KH / PIECE;               // pieces per half row
-  constexpr int NP = 16 * PPR / 64;             // pieces per lane per half tile
-  constexpr int LDW = KH + 16 / (int)sizeof(TC);
-  static_assert((16 * PPR) % 64 == 0, "half tile must be a multiple of 64 pieces");
+  constexpr int PPR = KW / PIECE;               // pieces per row slice
+  constexpr int NP = 16 * PPR / 64;             // pieces per lane per slice
+  constexpr int LDW = KW + 16 / (int)sizeof(TC);
+  static_assert((16 * PPR) % 64 == 0 && NP >= 1, "slice must be a multiple of 64 pieces");
+  static_assert(KS % 2 == 0, "two register stages alternate per slice");
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
   TC* As = reinterpret_cast<TC*>(wide_smem);                   // [CBT][STEPS][64]
-  TC* tiles = As + (size_t)CBT * STEPS * 64;                   // [8][16 * LDW]
+  TC* tiles = As + (size_t)CBT * STEPS * 64;                   // [WPB][16 * LDW]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
@@ -620,25 +628,25 @@ __global__ __launch_bounds__(512, 1) void proj_mfma_wide(const TIn* __restrict__
   typedef typename Mfma<TC>::acc_t acc_t;
   struct alignas(16) Raw { TIn v[PIECE]; };
 
-  for (int i = threadIdx.x; i < CBT * STEPS * 64; i += 512) As[i] = Apad[i];
+  for (int i = threadIdx.x; i < CBT * STEPS * 64; i += WPB * 64) As[i] = Apad[i];
   __syncthreads();
 
-  const int64_t wave_global = (int64_t)blockIdx.x * 8 + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * 8;
+  const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * WPB;
   const int64_t last_row = n - 1;
 
-  Raw stage[NP];
-  auto issue = [&](int64_t t, int half) {
+  Raw stg0[NP], stg1[NP];
+  auto issue = [&](Raw (&stage)[NP], int64_t t, int slice) {
     const int64_t row0 = t * 16;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PPR;
       row = row < last_row ? row : last_row;
-      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + half * KH + (p % PPR) * PIECE);
+      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + slice * KW + (p % PPR) * PIECE);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](const Raw (&stage)[NP]) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int p = i * 64 + lane;
@@ -652,29 +660,34 @@ __global__ __launch_bounds__(512, 1) void proj_mfma_wide(const TIn* __restrict__
   };
 
   int64_t t = wave_global;
-  if (t < ntiles) issue(t, 0);
+  if (t < ntiles) {
+    issue(stg0, t, 0);
+    issue(stg1, t, 1);
+  }
   while (t < ntiles) {
+    const int64_t tn = t + wave_stride;
     acc_t acc[CBT];
 #pragma unroll
     for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
-    commit();          // first half: waits for the staged pieces, writes LDS
-    issue(t, 1);       // second half in flight during the MFMA phase
 #pragma unroll
-    for (int s = 0; s < HSTEPS; ++s) {
-      const TC b = my[m * LDW + 4 * s + q];
+    for (int sl = 0; sl < KS; ++sl) {
+      // slice sl -> LDS, then request the slice two ahead into the stage just freed
+      if (sl % 2 == 0) commit(stg0);
+      else commit(stg1);
+      if (sl + 2 < KS) {
+        if (sl % 2 == 0) issue(stg0, t, sl + 2);
+        else issue(stg1, t, sl + 2);
+      } else if (tn < ntiles) {
+        if (sl % 2 == 0) issue(stg0, tn, sl + 2 - KS);
+        else issue(stg1, tn, sl + 2 - KS);
+      }
 #pragma unroll
-      for (int h = 0; h < CBT; ++h)
-        acc[h] = Mfma<TC>::run(As[(h * STEPS + s) * 64 + lane], b, acc[h]);
-    }
-    commit();
-    const int64_t tn = t + wave_stride;
-    if (tn < ntiles) issue(tn, 0);
+      for (int s = 0; s < SSTEPS; ++s) {
+        const TC b = my[m * LDW + 4 * s + q];
 #pragma unroll
-    for (int s = 0; s < HSTEPS; ++s) {
-      const TC b = my[m * LDW + 4 * s + q];
-#pragma unroll
-      for (int h = 0; h < CBT; ++h)
-        acc[h] = Mfma<TC>::run(As[(h * STEPS + HSTEPS + s) * 64 + lane], b, acc[h]);
+        for (int h = 0; h < CBT; ++h)
+          acc[h] = Mfma<TC>::run(As[(h * STEPS + sl * SSTEPS + s) * 64 + lane], b, acc[h]);
+      }
     }
     const int64_t row = t * 16 + m;  // D col = lane&15 = point
     if (row < n) {
@@ -785,45 +798,65 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
   }
 }
 
+// one wide pass over X for the CBT*16 hyperplanes padded into fragment order at Ab
+template <class TIn, class TC, int D, int CBT, int KS>
+int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int c0, int ncol, const TC* Ab, TC* P,
+                    int64_t ntiles, int64_t blocks) {
+  constexpr int WPB = 8;
+  constexpr size_t smem = wide_smem_bytes<TC, D, CBT, KS, WPB>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    RPT_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB>), dim3((unsigned)blocks),
+                     dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X, ds->n, Ab, c0, ncol, P,
+                     ds->n, ntiles);
+  return RPT_OK;
+}
+
 template <class TIn, class TC>
 int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
                     TC* P) {
   const int64_t n = ds->n;
   const int64_t ntiles = (n + 15) / 16;
   if (ds->d == 128) {  // guard-free pipelined paths
-    constexpr int D = 128, CBW = 4;  // wide passes: 64 hyperplanes per read of X
+    constexpr int D = 128;
+    // wide passes: up to 96 hyperplanes per read of X (CBT 6); a pass that has at most 64 left
+    // uses the CBT 4 shape (the matrix pipe pays for padded columns too)
+    constexpr int WCOLS = 96;
     const bool wide_ok = !getenv("RPT_PROJ_NARROW");
     // wide passes while more than 32 columns remain, the 32-column kernel for a short tail
     int nwide = 0;
     if (wide_ok) {
-      nwide = C / (16 * CBW);
-      if (C - nwide * 16 * CBW > 32) ++nwide;
+      nwide = C / WCOLS;
+      if (C - nwide * WCOLS > 32) ++nwide;
     }
-    const int cw = nwide * 16 * CBW < C ? nwide * 16 * CBW : C;  // columns done by wide passes
+    const int cw = nwide * WCOLS < C ? nwide * WCOLS : C;  // columns done by wide passes
     const int nblk = (C - cw + 31) / 32;
     DevBuf<TC> ApadW, Apad;
     if (nwide) {
-      RPT_TRY(ApadW.alloc((size_t)nwide * CBW * (D / 4) * 64));
-      hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D,
-                         nwide, CBW, 0, ApadW.p);
-      constexpr size_t smem = ((size_t)CBW * (D / 4) * 64 + (size_t)8 * 16 * (D / 2 + 16 / sizeof(TC))) *
-                              sizeof(TC);
-      static bool attr_done = false;
-      if (!attr_done) {
-        RPT_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBW>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-      }
+      RPT_TRY(ApadW.alloc((size_t)nwide * 6 * (D / 4) * 64));
       int64_t blocks = (ntiles + 7) / 8;
       if (blocks > ctx->n_cu) blocks = ctx->n_cu;
+      for (int b = 0; b < nwide; ++b) {  // fragment-order copies of the hyperplanes
+        const int c0 = b * WCOLS;
+        const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
+        hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(16), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
+                           D, 1, ncol > 64 ? 6 : 4, c0, ApadW.p + (size_t)b * 6 * (D / 4) * 64);
+      }
       for (int b = 0; b < nwide; ++b) {
-        const int c0 = b * 16 * CBW;
-        const int ncol = C - c0 < 16 * CBW ? C - c0 : 16 * CBW;
+        const int c0 = b * WCOLS;
+        const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
+        const TC* Ab = ApadW.p + (size_t)b * 6 * (D / 4) * 64;
         ProfScope ps(ctx, RPT_PROF_PROJECT);
-        hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBW>), dim3((unsigned)blocks), dim3(512),
-                           smem, ctx->stream, (const TIn*)ds->X, n,
-                           ApadW.p + (size_t)b * CBW * (D / 4) * 64, c0, ncol, P, n, ntiles);
+        if (ncol > 64) {
+          RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, c0, ncol, Ab, P, ntiles, blocks)));
+        } else {
+          RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, c0, ncol, Ab, P, ntiles, blocks)));
+        }
       }
     }
     if (nblk) {
