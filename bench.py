@@ -28,6 +28,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+# dense FP64 matrix peak: v_mfma_f64_16x16x4_f64 = 2048 flop per 64 cycles per SIMD
+# (32 flop/clk/SIMD, half the f32 16x16x4 rate of the guide's table) x 1024 SIMDs x 2.4 GHz
+MFMA_F64_PEAK_TF = 78.6
 
 
 def synth(n, d, seed, device):
@@ -170,7 +173,8 @@ def main():
 
     def read_prof():
         out = {}
-        for name, which in (("project", 0), ("split", 1), ("knn_plan", 2), ("knn_topk", 3)):
+        for name, which in (("project", 0), ("split", 1), ("knn_plan", 2), ("knn_topk", 3),
+                            ("project_wide", 4)):
             ms, cnt = C.c_double(), C.c_int64()
             _lib.check(L_.rpt_prof_get(ctx._h, which, C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, cnt.value)
@@ -288,11 +292,31 @@ def main():
 
     if rank == 0:
         p_ms, p_n = prof["project"]
-        cols_total = Tl * maxd * args.steps
-        avg_cols = cols_total / max(p_n, 1)
-        bytes_per_launch = N * d * 8 + d * avg_cols * 8 + N * avg_cols * 8
-        avg_ms = p_ms / max(p_n, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        w_ms, w_n = prof["project_wide"]
+        cols_total = Tl * maxd                       # hyperplanes of one build on this rank
+        if w_n > 0:
+            # dominant kernel: proj_mfma_wide.  Passes of up to 96 hyperplanes while more than
+            # 32 remain (project.hip: launch_mfma); the short tail goes to the 32-column kernel
+            nwide = cols_total // 96
+            if cols_total - nwide * 96 > 32:
+                nwide += 1
+            cols = min(nwide * 96, cols_total) / nwide   # real hyperplanes per wide launch
+            kernel = "proj_mfma_wide (MFMA f64 16x16x4, %.1f hyperplanes per pass over X)" % cols
+            avg_ms = w_ms / w_n
+        else:
+            cols = cols_total * args.steps / max(p_n, 1)
+            kernel = "projection batch (%s), %.1f hyperplanes per launch" % (
+                "proj_mfma_fast" if args.mode == "mfma" else "proj_exact_lds", cols)
+            avg_ms = p_ms / max(p_n, 1)
+        # bytes = N*d*s_x + d*T*s_x + N*T*s_p, flops = 2*N*d*T for a batch of T
+        # hyperplanes -- evaluated at the hyperplanes ONE launch really covers (X is read once
+        # per launch, not once per 32 hyperplanes)
+        bytes_per_launch = N * d * 8 + d * cols * 8 + N * cols * 8
+        flops_per_launch = 2.0 * N * d * cols
+        hbm_achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        mfma_achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        hbm_frac = hbm_achieved / HBM_PEAK_GBS
+        mfma_frac = mfma_achieved / MFMA_F64_PEAK_TF if args.mode == "mfma" else 0.0
         # HBM traffic of the same kernel from the PMC passes committed under profiles/
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per MI355X_MICROARCH.md); only
         # valid for the exact configuration it was measured on, otherwise null
@@ -300,11 +324,36 @@ def main():
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             c = pj["config"]
-            kname = "proj_mfma_fast" if args.mode == "mfma" else "proj_exact_lds"
-            if (c["N"], c["d"], c["cols"]) == (N, d, int(round(avg_cols))) and world == 1:
+            kname = ("proj_mfma_wide" if w_n > 0 else
+                     "proj_mfma_fast" if args.mode == "mfma" else "proj_exact_lds")
+            if (c["N"], c["d"]) == (N, d) and world == 1 and \
+                    int(round(pj[kname]["cols"])) == int(round(cols)):
                 traffic = pj[kname]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        if mfma_frac > hbm_frac:
+            roof = {"bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_F64_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": mfma_frac}
+        else:
+            roof = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hbm_frac}
+        roof.update({
+            "kernel": kernel, "traffic": traffic, "avg_launch_ms": avg_ms,
+            "launches": w_n if w_n > 0 else p_n,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_frac},
+            "mfma_f64": {"achieved": mfma_achieved, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": mfma_frac},
+            # the reference formulation projects one tree level (32 hyperplanes) per read of X:
+            # 8(d)'s 1.28 GB per level.  All projection launches of a build against that figure:
+            "survey_8d_per_level": {
+                "bytes_per_forest": maxd * (N * d * 8 + d * Tl * 8 + N * Tl * 8),
+                "projection_ms_per_forest": p_ms / args.steps,
+                "equivalent_GBps": maxd * (N * d * 8 + d * Tl * 8 + N * Tl * 8) /
+                                   (p_ms / args.steps * 1e-3) / 1e9 if p_ms > 0 else 0.0},
+        })
         out = {
             "metric": "forest-build vectors/s (1M x 128 dense, 32 trees); kNN queries/s and "
                       "recall@10 in `knn` / `recall_at_10`",
@@ -323,12 +372,7 @@ def main():
                                    "maxDepth %d, pnz %.4f, k=%d, %d queries; trees sharded %d/GPU, "
                                    "X replicated" % (N, d, T, args.min_leaf, maxd, pnz, k, nq, Tl),
                        "projection_mode": args.mode},
-            "roofline": {"bound": "hbm", "kernel": "projection batch (proj_exact / proj_mfma), "
-                                                   "%.1f hyperplanes per launch" % avg_cols,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": p_n,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "roofline": roof,
             "cpu_baseline": cpu,
             "knn": {"value": nq * args.steps / t_knn, "unit": "queries/s",
                     "ms_per_batch": t_knn / args.steps * 1e3, "semantics": "duplicates kept "

@@ -84,9 +84,10 @@ int32_t rpt_ctx_trim(rpt_ctx* ctx);
 int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
 
 /* ---- kernel timing (bench.py roofline): HIP events recorded on the ctx stream around every
- * launch of a kernel class while enabled.  which: 0 = projection batch kernel (one launch =
- * up to 32 hyperplanes over the whole point set), 1 = split work of one tree level,
- * 2 = query plan (query projections + traversal), 3 = distance/top-k kernel.
+ * launch of a kernel class while enabled.  which: 0 = projection batch kernels (one launch =
+ * one pass over the whole point set for up to 96 hyperplanes), 1 = split work,
+ * 2 = query plan (query projections + traversal), 3 = distance/top-k kernel, 4 = the wide
+ * (> 32 hyperplanes per pass) MFMA projection launches alone (they are also part of class 0).
  * rpt_prof_get synchronises the stream and returns the accumulated ms and launch count. */
 int32_t rpt_prof_enable(rpt_ctx* ctx, int32_t on);
 int32_t rpt_prof_reset(rpt_ctx* ctx);

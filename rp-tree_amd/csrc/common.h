@@ -101,7 +101,7 @@ struct DevBuf {
 
 // kernel classes timed by rpt_prof_* (HIP events on the ctx stream)
 enum { RPT_PROF_PROJECT = 0, RPT_PROF_SPLIT = 1, RPT_PROF_KNN_PLAN = 2, RPT_PROF_KNN_TOPK = 3,
-       RPT_PROF_CLASSES = 4 };
+       RPT_PROF_PROJECT_WIDE = 4, RPT_PROF_CLASSES = 5 };
 
 struct rpt_prof_span {
   hipEvent_t a, b;
@@ -118,8 +118,8 @@ struct rpt_ctx {
   int32_t n_cu = 256;
   bool prof = false;
   std::vector<rpt_prof_span> spans;
-  double prof_ms[RPT_PROF_CLASSES] = {0, 0, 0, 0};
-  int64_t prof_n[RPT_PROF_CLASSES] = {0, 0, 0, 0};
+  double prof_ms[RPT_PROF_CLASSES] = {0, 0, 0, 0, 0};
+  int64_t prof_n[RPT_PROF_CLASSES] = {0, 0, 0, 0, 0};
 };
 
 namespace rpt {
