@@ -1507,6 +1507,14 @@ __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __res
   }
 }
 
+template <class TK>
+struct AGeom {  // per node, one 16-byte LDS read
+  TK lo, sc;
+};
+struct ABins {  // per node, one 8-byte LDS read (bins <= 4096: -2 .. 4097 fit 16 bits)
+  short pb, lowb, highb, pad;
+};
+
 // bin geometry of one node from the min / max of its keys (hist and pick must agree bit for bit)
 template <class TK>
 __device__ inline void stream_geom(unsigned long long mn, unsigned long long mx, int B, TK& lo,
@@ -1536,20 +1544,36 @@ __global__ __launch_bounds__(kStreamThreads) void stream_hist(
     int M, int64_t per, const unsigned long long* __restrict__ cmin,
     const unsigned long long* __restrict__ cmax, unsigned int* __restrict__ part) {
   __shared__ unsigned int hist[kStreamBins / 2];  // two 16-bit counters per word
-  __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
+  __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
   const int t = blockIdx.y;
   const int B = stream_bins(M);
   for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) hist[i] = 0;
-  for (int j = threadIdx.x; j < M; j += kStreamThreads)
-    stream_geom<TK>(cmin[(int64_t)t * M + j], cmax[(int64_t)t * M + j], B, nlo[j], nsc[j]);
+  for (int j = threadIdx.x; j < M; j += kStreamThreads) {
+    AGeom<TK> g;
+    stream_geom<TK>(cmin[(int64_t)t * M + j], cmax[(int64_t)t * M + j], B, g.lo, g.sc);
+    ngeo[j] = g;
+  }
   __syncthreads();
   const TK* Pl = P + ((int64_t)t * L + level) * N;
   const uint16_t* no = node_of + (int64_t)t * N;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
-  for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
-    const int j = no[i];
-    const int e = j * B + stream_bin(Pl[i], nlo[j], nsc[j], B);
+  auto one = [&](int j, TK key) {
+    const AGeom<TK> g = ngeo[j];
+    const int e = j * B + stream_bin(key, g.lo, g.sc, B);
     atomicAdd(&hist[e >> 1], 1u << ((e & 1) * 16));  // per < 65536: no carry between halves
+  };
+  typedef TK key2_t __attribute__((ext_vector_type(2)));
+  if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {  // 16-byte key loads, 4-byte node loads
+    const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)1);
+    for (int64_t i = i0 + 2 * (int64_t)threadIdx.x; i < ie; i += 2 * kStreamThreads) {
+      const unsigned int jj = *reinterpret_cast<const unsigned int*>(no + i);
+      const key2_t kk = *reinterpret_cast<const key2_t*>(Pl + i);
+      one((int)(jj & 0xffffu), kk[0]);
+      one((int)(jj >> 16), kk[1]);
+    }
+    if (threadIdx.x == 0 && ie < i1) one(no[ie], Pl[ie]);
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) one(no[i], Pl[i]);
   }
   __syncthreads();
   unsigned int* gp = part + ((int64_t)t * gridDim.x + blockIdx.x) * (kStreamBins / 2);
@@ -1705,19 +1729,16 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
     int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
     unsigned long long* cmin_next, unsigned long long* cmax_next) {
-  __shared__ TK nlo[kStreamMaxNodes], nsc[kStreamMaxNodes];
-  __shared__ short npb[kStreamMaxNodes], nlowb[kStreamMaxNodes], nhighb[kStreamMaxNodes];
+  __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
+  __shared__ __attribute__((aligned(8))) ABins nbin[kStreamMaxNodes];
   __shared__ int nmidoff[kStreamMaxNodes];
   __shared__ unsigned long long smin[2 * kStreamMaxNodes], smax[2 * kStreamMaxNodes];
   const int t = blockIdx.y;
   const int B = stream_bins(M);
   SNode<TK>* ndt = nd + (int64_t)t * M;
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
-    nlo[j] = ndt[j].lo;
-    nsc[j] = ndt[j].scale;
-    npb[j] = (short)ndt[j].pb;  // bins <= 4096: -2 .. 4097 fit 16 bits
-    nlowb[j] = (short)ndt[j].lowb;
-    nhighb[j] = (short)ndt[j].highb;
+    ngeo[j] = AGeom<TK>{ndt[j].lo, ndt[j].scale};
+    nbin[j] = ABins{(short)ndt[j].pb, (short)ndt[j].lowb, (short)ndt[j].highb, 0};
     nmidoff[j] = ndt[j].midoff;
   }
   for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
@@ -1733,7 +1754,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   // The children's min/max of the NEXT level's key only shape that level's bins (keys outside
   // the range are clamped into the edge bins), so a sample is enough: the first quarter of the
   // block's points — every point while nodes are small.
-  const int64_t isamp = (N >> level) < 8192 ? i1 : i0 + ((i1 - i0 + 3) >> 2);
+  const int64_t isamp = (N >> level) < 1024 ? i1 : (i0 + ((i1 - i0 + 3) >> 2) + 1) & ~(int64_t)1;
   // few nodes: a per-thread running min/max per child avoids hammering one LDS word
   const bool few = M <= 4;
   unsigned long long tmn[8], tmx[8];
@@ -1742,32 +1763,70 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     tmn[c] = ~0ULL;
     tmx[c] = 0ULL;
   }
-  for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
-    const int j = no[i];
-    const TK key = Pl[i];
-    const int b = stream_bin(key, nlo[j], nsc[j], B);
-    const int pb = npb[j];
+  // classify one point: child node index, or -1 when it went to the node's pivot-bin list
+  auto classify = [&](int64_t i, int j, TK key) -> int {
+    const AGeom<TK> g = ngeo[j];
+    const ABins nb = nbin[j];
+    const int b = stream_bin(key, g.lo, g.sc, B);
+    const int pb = nb.pb;
     if (b == pb) {
       const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
       pl[nmidoff[j] + p] = (int32_t)i;
-      continue;
+      return -1;
     }
-    const int child = 2 * j + (b > pb);
-    no[i] = (uint16_t)child;
-    if (b == nlowb[j]) atomicMax(&ndt[j].maxL, ord_of(key));
-    if (b == nhighb[j]) atomicMin(&ndt[j].minR, ord_of(key));
-    if (has_next && i < isamp) {
-      const unsigned long long o = ord_of(Pn[i]);
-      if (few) {
+    if (b == nb.lowb) atomicMax(&ndt[j].maxL, ord_of(key));
+    if (b == nb.highb) atomicMin(&ndt[j].minR, ord_of(key));
+    return 2 * j + (b > pb);
+  };
+  auto sample = [&](int child, TK knext) {
+    const unsigned long long o = ord_of(knext);
+    if (few) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (c == child) {
-            tmn[c] = o < tmn[c] ? o : tmn[c];
-            tmx[c] = o > tmx[c] ? o : tmx[c];
-          }
+      for (int c = 0; c < 8; ++c)
+        if (c == child) {
+          tmn[c] = o < tmn[c] ? o : tmn[c];
+          tmx[c] = o > tmx[c] ? o : tmx[c];
+        }
+    } else {
+      atomicMin(&smin[child], o);
+      atomicMax(&smax[child], o);
+    }
+  };
+  // two consecutive points per thread and step: 16-byte key loads, 4-byte node loads/stores
+  // (the key rows are 16-byte aligned when N is even and the block ranges start on even offsets)
+  typedef TK key2_t __attribute__((ext_vector_type(2)));
+  if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {
+    const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)1);
+    for (int64_t i = i0 + 2 * (int64_t)threadIdx.x; i < ie; i += 2 * kStreamThreads) {
+      const unsigned int jj = *reinterpret_cast<const unsigned int*>(no + i);
+      const key2_t kk = *reinterpret_cast<const key2_t*>(Pl + i);
+      const int c0 = classify(i, (int)(jj & 0xffffu), kk[0]);
+      const int c1 = classify(i + 1, (int)(jj >> 16), kk[1]);
+      if (c0 >= 0 && c1 >= 0) {
+        *reinterpret_cast<unsigned int*>(no + i) = (unsigned int)c0 | ((unsigned int)c1 << 16);
       } else {
-        atomicMin(&smin[child], o);
-        atomicMax(&smax[child], o);
+        if (c0 >= 0) no[i] = (uint16_t)c0;
+        if (c1 >= 0) no[i + 1] = (uint16_t)c1;
+      }
+      if (has_next && i < isamp) {
+        const key2_t kn = *reinterpret_cast<const key2_t*>(Pn + i);
+        if (c0 >= 0) sample(c0, kn[0]);
+        if (c1 >= 0) sample(c1, kn[1]);
+      }
+    }
+    if (threadIdx.x == 0 && ie < i1) {
+      const int c = classify(ie, no[ie], Pl[ie]);
+      if (c >= 0) {
+        no[ie] = (uint16_t)c;
+        if (has_next) sample(c, Pn[ie]);
+      }
+    }
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
+      const int c = classify(i, no[i], Pl[i]);
+      if (c >= 0) {
+        no[i] = (uint16_t)c;
+        if (has_next && i < isamp) sample(c, Pn[i]);
       }
     }
   }
@@ -2364,15 +2423,15 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     const int64_t min_per = getenv("RPT_STREAM_MINPER") ? atoll(getenv("RPT_STREAM_MINPER")) : 32768;
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblk > (N + min_per - 1) / min_per) nblk = (N + min_per - 1) / min_per;
-    if (nblk < (N + 65534) / 65535) nblk = (N + 65534) / 65535;
+    if (nblk < (N + 65533) / 65534) nblk = (N + 65533) / 65534;
     if (nblk < 1) nblk = 1;
-    const int64_t per = (N + nblk - 1) / nblk;
+    const int64_t per = (((N + nblk - 1) / nblk) + 1) & ~(int64_t)1;  // even, <= 65534
     const dim3 sgrid((unsigned)nblk, (unsigned)T);
     // assign pass: no per-block table to flush, fill the chip
     int64_t nblkA = (4 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblkA > (N + 8191) / 8192) nblkA = (N + 8191) / 8192;
     if (nblkA < 1) nblkA = 1;
-    const int64_t perA = (N + nblkA - 1) / nblkA;
+    const int64_t perA = (((N + nblkA - 1) / nblkA) + 1) & ~(int64_t)1;  // even: 16-byte key loads
     const dim3 agrid((unsigned)nblkA, (unsigned)T);
     RPT_TRY(node_of.alloc((size_t)T * N));
     RPT_TRY(part.alloc((size_t)T * nblk * (kStreamBins / 2)));
