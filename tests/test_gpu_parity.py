@@ -58,7 +58,10 @@ def test_project_exact_matches_oracle_inner_sd(rp, ctx, oracle):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 1e-5)])
-@pytest.mark.parametrize("n,d,C", [(1000, 16, 3), (5000, 128, 32), (777, 37, 33), (4099, 200, 17)])
+# d = 128 with more than 32 hyperplanes: the wide (96 / 64 columns per pass) kernels and their tails
+@pytest.mark.parametrize("n,d,C", [(1000, 16, 3), (5000, 128, 32), (777, 37, 33), (4099, 200, 17),
+                                   (3001, 128, 33), (2100, 128, 64), (1999, 128, 100),
+                                   (1500, 128, 230)])
 def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
     rng = np.random.default_rng(n * 3 + d)
     X = rng.standard_normal((n, d)).astype(dtype)
@@ -71,10 +74,10 @@ def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
     assert (err <= tol * scale + 1e-300).all(), float((err / (scale + 1e-300)).max())
 
 
-def test_project_mfma_bf16_input(rp, ctx):
+@pytest.mark.parametrize("n,d,C", [(3000, 256, 32), (2500, 128, 100), (1111, 128, 52)])
+def test_project_mfma_bf16_input(rp, ctx, n, d, C):
     import torch
     rng = np.random.default_rng(5)
-    n, d, C = 3000, 256, 32
     Xf = rng.standard_normal((n, d)).astype(np.float32)
     xb = torch.from_numpy(Xf).to(torch.bfloat16)
     Xr = xb.to(torch.float32).numpy().astype(np.float64)     # exactly representable inputs
