@@ -38,6 +38,8 @@ foreign import ccall safe "rpt_forest_build"        c_forest_build   :: Ptr Ctx 
 foreign import ccall safe "rpt_forest_get_perm"     c_forest_perm    :: Ptr Forest -> Ptr Int32 -> IO Int32
 foreign import ccall safe "rpt_forest_get_nodes"    c_forest_nodes   :: Ptr Forest -> Ptr Double -> Ptr Double -> Ptr Double -> IO Int32
 foreign import ccall safe "rpt_knn_host"            c_knn_host       :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Int32 -> Ptr Int32 -> Ptr Double -> Ptr Int32 -> IO Int32
+-- knnH (RPTree.hs:199-217): two calls, the first with null outputs returns the result size
+foreign import ccall safe "rpt_knnh_host"           c_knnh_host      :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Ptr Int64 -> Ptr Int32 -> Ptr Double -> Int64 -> Ptr Int64 -> IO Int32
 foreign import ccall unsafe "rpt_last_error"        c_last_error     :: IO CString
 foreign import ccall "&rpt_forest_free"             p_forest_free    :: FunPtr (Ptr Forest -> IO ())
 foreign import ccall "&rpt_dataset_free"            p_dataset_free   :: FunPtr (Ptr Dataset -> IO ())

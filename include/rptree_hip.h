@@ -65,6 +65,7 @@ extern "C" {
 /* knn flags */
 #define RPT_KNN_KEEP_DUPLICATES 0 /* the reference: RPTree.hs:174-176 never de-duplicates */
 #define RPT_KNN_DEDUP 1           /* extension: each point id at most once */
+#define RPT_KNN_DEDUP_DISTANCE 2  /* knnPQ (RPTree.hs:181-194): `nub` keeps one entry per DISTANCE */
 
 typedef struct rpt_ctx rpt_ctx;
 typedef struct rpt_dataset rpt_dataset;
@@ -162,6 +163,17 @@ int32_t rpt_split_segments(rpt_ctx* ctx, const double* key_host, int64_t n,
  * Two-call protocol: ids_host = NULL -> only *total is written. */
 int32_t rpt_candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* queries,
                        int64_t* off_host, int32_t* ids_host, int64_t cap, int64_t* total);
+
+/* knnH (RPTree.hs:199-217 over candidatesH :318-342) with distf = metricL2: per query the
+ * buckets of the leaves with the smallest margin priority, taken while the running count stays
+ * <= k (always at least one), the bucket taken last FIRST, every point with its distance — as in
+ * the reference the result is neither sorted by distance nor cut to k.  Equal priorities keep
+ * (tree, DFS) order (the reference's order among ties depends on its heap's shape).
+ * Output is CSR-like: off_host[nq + 1] into ids_host / dist_host.  Two-call protocol:
+ * ids_host = NULL -> only off_host and *total are written. */
+int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                      const rpt_dataset* queries, int32_t k, int64_t* off_host, int32_t* ids_host,
+                      double* dist_host, int64_t cap, int64_t* total);
 
 /* knn (RPTree.hs:168-176) with distf = metricL2 (Internal.hs:318, metricDDL2 :403-406 /
  * true Euclidean distance for CSR data): per query the k best (distance, id), stable in

@@ -59,6 +59,9 @@ def lib():
         L.rpo_knn_dense.restype = C.c_int32
         L.rpo_knn_csr.restype = C.c_int32
         L.rpo_recall_with_dense.restype = C.c_double
+        L.rpo_knn_h_dense.restype = C.c_int64
+        L.rpo_knn_h_csr.restype = C.c_int64
+        L.rpo_candidates_h_dense.restype = C.c_int64
         L.rpo_data_normal_sparse2.restype = C.c_int64
         L.rpo_data_sparse_uniform.restype = C.c_int64
         L.rpo_next_double.restype = C.c_double
@@ -291,6 +294,57 @@ def knn_csr(f, rowptr, col, val, qi, qv, k, dedup=False, true_l2=False):
                           *_fargs(f), *_targs(f), C.c_int32(k), C.c_int32(int(dedup)),
                           C.c_int32(int(true_l2)), _p(ids, _i32p), _p(dist, _f64p))
     return ids[:m].copy(), dist[:m].copy()
+
+
+def knn_pq_dense(f, X, q, k):
+    """RPTree.hs:181-194 knnPQ: like knn, entries of equal distance collapse to one"""
+    return knn_dense(f, X, q, k, dedup=2)
+
+
+def candidates_h_dense(f, q, t):
+    """RPTree.hs:318-342 for tree t -> (priority, perm offset, length) per leaf reached, DFS order"""
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    cap = 1 << min(f.L, 20)
+    prio = np.empty(cap, dtype=np.float64)
+    off = np.empty(cap, dtype=np.int64)
+    ln = np.empty(cap, dtype=np.int64)
+    tt = _targs(f)
+    n = lib().rpo_candidates_h_dense(_p(q, _f64p), C.c_int32(f.d), *_fargs(f), C.c_int64(f.N),
+                                     tt[1], tt[2], tt[3], C.c_int32(t), _p(prio, _f64p),
+                                     _p(off, _i64p), _p(ln, _i64p), C.c_int64(cap))
+    return prio[:n].copy(), off[:n].copy(), ln[:n].copy()
+
+
+def knn_h_dense(f, X, q, k):
+    """RPTree.hs:199-217 knnH with metricL2 -> (ids, dists): whole buckets, unsorted"""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    cap = 4096
+    while True:
+        ids = np.empty(cap, dtype=np.int32)
+        dist = np.empty(cap, dtype=np.float64)
+        m = lib().rpo_knn_h_dense(_p(X, _f64p), C.c_int64(f.N), C.c_int32(f.d), _p(q, _f64p),
+                                  *_fargs(f), *_targs(f), C.c_int32(k), _p(ids, _i32p),
+                                  _p(dist, _f64p), C.c_int64(cap))
+        if m <= cap:
+            return ids[:m].copy(), dist[:m].copy()
+        cap = int(m)
+
+
+def knn_h_csr(f, rowptr, col, val, qi, qv, k, true_l2=False):
+    qi, qv = _sv(qi, qv)
+    cap = 4096
+    while True:
+        ids = np.empty(cap, dtype=np.int32)
+        dist = np.empty(cap, dtype=np.float64)
+        m = lib().rpo_knn_h_csr(_p(rowptr, _i64p), _p(col, _i32p), _p(val, _f64p),
+                                C.c_int64(f.N), C.c_int32(f.d), C.c_int64(len(qi)),
+                                _p(qi, _i32p), _p(qv, _f64p), *_fargs(f), *_targs(f),
+                                C.c_int32(k), C.c_int32(int(true_l2)), _p(ids, _i32p),
+                                _p(dist, _f64p), C.c_int64(cap))
+        if m <= cap:
+            return ids[:m].copy(), dist[:m].copy()
+        cap = int(m)
 
 
 def recall_with_dense(f, X, q, k):

@@ -218,6 +218,79 @@ void tree_candidates(InnerQ innerq, const std::vector<SparseVec>& all, int32_t L
   c.go(0, 0, 0, N);
 }
 
+// RPTree.hs:318-342 `candidatesH` on the flat layout: one (priority, leaf) entry per leaf
+// reached by the same 4-way rule; the priority is the smallest margin distance met on the way
+// down (`pl = p min dl` towards the left child, `pr = p min dr` towards the right one), starting
+// from +infinity.  Entries are listed in DFS order (left before right), trees in key order.
+struct LeafEntry {
+  double prio;
+  int32_t tree;
+  int64_t off, n;
+};
+struct CandH {
+  const double *thr, *mglo, *mghi;
+  int32_t L, minLeaf, tree;
+  const double* projq;
+  std::vector<LeafEntry>* out;
+  void go(int32_t level, int64_t heap, int64_t off, int64_t n, double p) const {
+    if (is_leaf(level, n, L, minLeaf)) {  // :323 Tip -> insertp p xs
+      out->push_back(LeafEntry{p, tree, off, n});
+      return;
+    }
+    const double proj = projq[level];
+    const double dl = std::fabs(mglo[heap] - proj);  // :330
+    const double dr = std::fabs(mghi[heap] - proj);  // :331
+    const double pl = p <= dl ? p : dl;              // :332 p `min` dl
+    const double pr = p <= dr ? p : dr;              // :333
+    const double th = thr[heap];
+    const int64_t nh = n / 2;
+    const int64_t hl = 2 * heap + 1, hr = 2 * heap + 2;
+    if (proj < th && dl > dr) {  // :335-336
+      go(level + 1, hl, off, nh, pl);
+      go(level + 1, hr, off + nh, n - nh, pr);
+    } else if (proj < th) {  // :337
+      go(level + 1, hl, off, nh, pl);
+    } else if (proj > th && dl < dr) {  // :338-339
+      go(level + 1, hl, off, nh, pl);
+      go(level + 1, hr, off + nh, n - nh, pr);
+    } else {  // :340
+      go(level + 1, hr, off + nh, n - nh, pr);
+    }
+  }
+};
+
+template <class InnerQ>
+void forest_leaves_h(InnerQ innerq, const std::vector<SparseVec>& all, int32_t T, int32_t L,
+                     int32_t minLeaf, int64_t N, const double* thr, const double* mglo,
+                     const double* mghi, std::vector<LeafEntry>& out) {
+  const int64_t nodes = ((int64_t)1 << L) - 1;
+  std::vector<double> projq((size_t)L);
+  for (int32_t t = 0; t < T; ++t) {
+    for (int32_t l = 0; l < L; ++l) projq[l] = innerq(all[(size_t)t * L + l]);
+    CandH c{thr + t * nodes, mglo + t * nodes, mghi + t * nodes, L, minLeaf, t, projq.data(), &out};
+    c.go(0, 0, 0, N, std::numeric_limits<double>::infinity());  // :320 infty = 1 / 0
+  }
+}
+
+// RPTree.hs:205-217 `knnH`: leaves are taken in increasing priority while the running count
+// stays <= k — but always at least one —, each new bucket is PREPENDED (`xsh <> acc`), and the
+// result is neither sorted by distance nor cut to k.  Equal priorities: the `heaps` package
+// pops them in an order that depends on its internal shape; here ties keep (tree, DFS) order.
+// Returns the leaves selected, in result order.
+std::vector<LeafEntry> knn_h_select(std::vector<LeafEntry> es, int32_t k) {
+  std::stable_sort(es.begin(), es.end(),
+                   [](const LeafEntry& a, const LeafEntry& b) { return a.prio < b.prio; });
+  std::vector<LeafEntry> acc;
+  int64_t n = 0;
+  for (const LeafEntry& e : es) {
+    const int64_t ntot = e.n + n;
+    if (ntot > k && !acc.empty()) break;
+    acc.insert(acc.begin(), e);
+    n = ntot;
+  }
+  return acc;
+}
+
 struct DistId {
   double dist;
   int32_t id;
@@ -231,7 +304,9 @@ int32_t topk_from(std::vector<DistId>& cs, int32_t k, int32_t dedup, int32_t* ou
   int32_t m = 0;
   std::set<int32_t> seen;
   for (size_t i = 0; i < cs.size() && m < k; ++i) {
-    if (dedup) {
+    if (dedup == 2) {  // knnPQ's `nub`: entries of equal PRIORITY (distance) collapse to one
+      if (i > 0 && cs[i].dist == cs[i - 1].dist) continue;
+    } else if (dedup) {
       if (seen.count(cs[i].id)) continue;
       seen.insert(cs[i].id);
     }
@@ -612,6 +687,77 @@ int32_t rpo_knn_csr(const int64_t* rowptr, const int32_t* col, const double* val
     cs[i] = {dist, c[i]};
   }
   return topk_from(cs, k, dedup, out_ids, out_dist);
+}
+
+// RPTree.hs:199-217 knnH with distf = metricL2 (dense data, dense query)
+int64_t rpo_knn_h_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                        int32_t T, int32_t L, int32_t minLeaf, const int32_t* perm,
+                        const double* thr, const double* mglo, const double* mghi, int32_t k,
+                        int32_t* out_ids, double* out_dist, int64_t cap) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<LeafEntry> es;
+  forest_leaves_h(
+      [&](const SparseVec& r) {
+        return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+      },
+      all, T, L, minLeaf, N, thr, mglo, mghi, es);
+  int64_t m = 0;
+  for (const LeafEntry& e : knn_h_select(es, k))
+    for (int64_t i = 0; i < e.n; ++i, ++m)
+      if (m < cap) {
+        const int32_t id = perm[(int64_t)e.tree * N + e.off + i];
+        out_ids[m] = id;
+        out_dist[m] = rpo_metric_dd(d, X + (int64_t)id * d, q);
+      }
+  return m;
+}
+
+int64_t rpo_knn_h_csr(const int64_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                      int32_t d, int64_t qn, const int32_t* qi, const double* qv, const double* R,
+                      int32_t T, int32_t L, int32_t minLeaf, const int32_t* perm,
+                      const double* thr, const double* mglo, const double* mghi, int32_t k,
+                      int32_t true_l2, int32_t* out_ids, double* out_dist, int64_t cap) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<LeafEntry> es;
+  forest_leaves_h(
+      [&](const SparseVec& r) {
+        return rpo_inner_ss((int64_t)r.idx.size(), r.idx.data(), r.val.data(), qn, qi, qv);
+      },
+      all, T, L, minLeaf, N, thr, mglo, mghi, es);
+  int64_t m = 0;
+  for (const LeafEntry& e : knn_h_select(es, k))
+    for (int64_t i = 0; i < e.n; ++i, ++m)
+      if (m < cap) {
+        const int32_t id = perm[(int64_t)e.tree * N + e.off + i];
+        const int64_t a = rowptr[id], b = rowptr[id + 1];
+        out_ids[m] = id;
+        out_dist[m] = true_l2 ? true_l2_ss(b - a, col + a, val + a, qn, qi, qv)
+                              : rpo_metric_ss(b - a, col + a, val + a, qn, qi, qv);
+      }
+  return m;
+}
+
+// leaf priorities of one tree (candidatesH), DFS order; returns the number of leaves reached
+int64_t rpo_candidates_h_dense(const double* q, int32_t d, const double* R, int32_t T, int32_t L,
+                               int32_t minLeaf, int64_t N, const double* thr, const double* mglo,
+                               const double* mghi, int32_t t, double* prio, int64_t* off,
+                               int64_t* len, int64_t cap) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<LeafEntry> es;
+  const int64_t nodes = ((int64_t)1 << L) - 1;
+  std::vector<double> projq((size_t)L);
+  for (int32_t l = 0; l < L; ++l) {
+    const SparseVec& r = all[(size_t)t * L + l];
+    projq[l] = rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+  }
+  CandH c{thr + t * nodes, mglo + t * nodes, mghi + t * nodes, L, minLeaf, t, projq.data(), &es};
+  c.go(0, 0, 0, N, std::numeric_limits<double>::infinity());
+  for (size_t i = 0; i < es.size() && (int64_t)i < cap; ++i) {
+    prio[i] = es[i].prio;
+    off[i] = es[i].off;
+    len[i] = es[i].n;
+  }
+  return (int64_t)es.size();
 }
 
 // RPTree.hs:259-282

@@ -145,6 +145,30 @@ int32_t rpo_knn_csr(const int64_t* rowptr, const int32_t* col, const double* val
                     const double* mghi, int32_t k, int32_t dedup, int32_t true_l2,
                     int32_t* out_ids, double* out_dist);
 
+/* ---- knnPQ, RPTree.hs:181-194: rpo_knn_dense / rpo_knn_csr with dedup = 2 — `nub` collapses
+ * entries of equal PRIORITY, i.e. equal distance, to one (the first in candidate order here; the
+ * reference's pick among ties depends on the heap's shape). */
+
+/* ---- candidatesH / knnH, RPTree.hs:199-217,318-342 (distf = metricL2) ----
+ * candidates_h: the leaves one tree contributes, DFS order, with their margin priority.
+ * knn_h: buckets of the lowest-priority leaves while the count stays <= k (at least one), the
+ * later bucket first, every point with its distance; NOT sorted, NOT cut to k (as the
+ * reference).  Returns the number of results (may exceed cap: then only cap were written).
+ * Equal priorities keep (tree, DFS) order — the reference's order among ties is unspecified. */
+int64_t rpo_candidates_h_dense(const double* q, int32_t d, const double* R, int32_t T, int32_t L,
+                               int32_t minLeaf, int64_t N, const double* thr, const double* mglo,
+                               const double* mghi, int32_t t, double* prio, int64_t* off,
+                               int64_t* len, int64_t cap);
+int64_t rpo_knn_h_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                        int32_t T, int32_t L, int32_t minLeaf, const int32_t* perm,
+                        const double* thr, const double* mglo, const double* mghi, int32_t k,
+                        int32_t* out_ids, double* out_dist, int64_t cap);
+int64_t rpo_knn_h_csr(const int64_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                      int32_t d, int64_t qn, const int32_t* qi, const double* qv, const double* R,
+                      int32_t T, int32_t L, int32_t minLeaf, const int32_t* perm,
+                      const double* thr, const double* mglo, const double* mghi, int32_t k,
+                      int32_t true_l2, int32_t* out_ids, double* out_dist, int64_t cap);
+
 /* ---- recallWith, RPTree.hs:259-282 (dense data, metricDDL2) ---- */
 double rpo_recall_with_dense(const double* X, int64_t N, int32_t d, const double* q,
                              const double* R, int32_t T, int32_t L, int32_t minLeaf,

@@ -682,6 +682,19 @@ int32_t rpt_candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* queries,
   return candidates(ctx, f, queries, off_host, ids_host, cap, total);
 }
 
+int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
+                      const rpt_dataset* queries, int32_t k, int64_t* off_host, int32_t* ids_host,
+                      double* dist_host, int64_t cap, int64_t* total) {
+  if (ctx) dev_set_stream(ctx->stream);
+  RPT_TRY(check_query(ctx, f, queries));
+  RPT_ARG(data && data->ctx == ctx, "bad data handle");
+  RPT_ARG(data->n == f->n && data->d == f->d, "data shape differs from the forest's");
+  RPT_ARG(data->csr == queries->csr, "data and queries must both be dense or both CSR");
+  RPT_ARG(k >= 1, "k must be >= 1");
+  RPT_ARG(total, "total is NULL");
+  return knn_h(ctx, f, data, queries, k, off_host, ids_host, dist_host, cap, total);
+}
+
 int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                     const rpt_dataset* queries, int32_t k, int32_t flags, int32_t* ids_dev,
                     double* dist_dev, int32_t* count_dev) {
@@ -691,6 +704,7 @@ int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
   RPT_ARG(data->n == f->n && data->d == f->d, "data shape differs from the forest's");
   RPT_ARG(data->csr == queries->csr, "data and queries must both be dense or both CSR");
   RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
+  RPT_ARG(flags >= 0 && flags <= 2, "unknown knn flags");
   RPT_ARG(ids_dev && dist_dev && count_dev, "NULL output");
   return knn_dev(ctx, f, data, queries, k, flags, ids_dev, dist_dev, count_dev);
 }
@@ -702,6 +716,7 @@ int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
   RPT_TRY(check_query(ctx, f, queries));
   RPT_ARG(ids_host && dist_host && count_host, "NULL output");
   RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
+  RPT_ARG(flags >= 0 && flags <= 2, "unknown knn flags");
   int64_t nq = queries->n;
   DevBuf<int32_t> ids, cnt;
   DevBuf<double> dist;

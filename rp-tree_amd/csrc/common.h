@@ -208,5 +208,8 @@ int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_d
                       int32_t* out_ids, double* out_dist, int32_t* out_count);
 int32_t brute_knn(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* q, int32_t k,
                   int32_t* ids_host, double* dist_host);
+int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
+              int32_t k, int64_t* off_host, int32_t* ids_host, double* dist_host, int64_t cap,
+              int64_t* total);
 
 }  // namespace rpt

@@ -17,8 +17,11 @@
 //   expand_kernel : materialises candidate ids for rpt_candidates
 #include <hip/hip_bf16.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
+#include <vector>
 
 #include "common.h"
 
@@ -151,6 +154,84 @@ __global__ void ranges_kernel(const double* __restrict__ thr, const double* __re
   }
 }
 
+// candidatesH (RPTree.hs:318-342): the same descent, every leaf reached carries the smallest
+// margin distance met on the way down (`p min dl` towards the left child, `p min dr` towards
+// the right one, +infinity at the root).  emit(off, n, priority), left to right.
+template <class TK, class Emit>
+__device__ inline void traverse_h(const double* __restrict__ thr, const double* __restrict__ mglo,
+                                  const double* __restrict__ mghi, const TK* __restrict__ pq,
+                                  int64_t pq_stride, int L, int min_leaf, int64_t N, Emit emit) {
+  int s_level[32];
+  unsigned int s_heap[32];
+  int s_off[32], s_n[32];
+  double s_p[32];
+  int sp = 1;
+  s_level[0] = 0;
+  s_heap[0] = 0;
+  s_off[0] = 0;
+  s_n[0] = (int)N;
+  s_p[0] = __longlong_as_double(0x7ff0000000000000LL);  // :320 infty = 1 / 0
+  while (sp > 0) {
+    --sp;
+    int level = s_level[sp];
+    unsigned int heap = s_heap[sp];
+    int off = s_off[sp], n = s_n[sp];
+    double p = s_p[sp];
+    for (;;) {
+      if (level >= L || n <= min_leaf) {  // :323 Tip
+        emit(off, n, p);
+        break;
+      }
+      const double proj = (double)pq[(int64_t)level * pq_stride];
+      const double th = thr[heap];
+      const double dl = fabs(mglo[heap] - proj);  // :330
+      const double dr = fabs(mghi[heap] - proj);  // :331
+      const double pl = p <= dl ? p : dl;         // :332
+      const double pr = p <= dr ? p : dr;         // :333
+      const int nh = n / 2;
+      const bool both = (proj < th && dl > dr) || (proj > th && dl < dr);  // :335-339
+      const bool left = proj < th;
+      if (both) {  // push right, continue left
+        s_level[sp] = level + 1;
+        s_heap[sp] = 2 * heap + 2;
+        s_off[sp] = off + nh;
+        s_n[sp] = n - nh;
+        s_p[sp] = pr;
+        ++sp;
+        heap = 2 * heap + 1;
+        n = nh;
+        p = pl;
+      } else if (left) {
+        heap = 2 * heap + 1;
+        n = nh;
+        p = pl;
+      } else {
+        heap = 2 * heap + 2;
+        off += nh;
+        n = n - nh;
+        p = pr;
+      }
+      ++level;
+    }
+  }
+}
+
+// priorities of the leaf ranges, in the order ranges_kernel lists them
+template <class TK>
+__global__ void ranges_h_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
+                                const double* __restrict__ mghi, int64_t nodes, const TK* Pq,
+                                int64_t nq, int T, int L, int min_leaf, int64_t N,
+                                const int64_t* __restrict__ rng_off /*[nq*T+1]*/,
+                                double* __restrict__ prio) {
+  const int64_t q = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int64_t r = rng_off[q * T + t];
+    traverse_h<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes,
+                   Pq + (int64_t)t * L * nq + q, nq, L, min_leaf, N,
+                   [&](int, int, double p) { prio[r++] = p; });
+  }
+}
+
 // candidate ids for rpt_candidates: one block per (query, tree) range list
 __global__ void expand_kernel(const int32_t* __restrict__ perm, const Range* __restrict__ ranges,
                               const int64_t* __restrict__ rng_off, const int64_t* __restrict__ cand_off,
@@ -193,7 +274,8 @@ __device__ inline void bitonic_entries(Entry* e, int np) {
 
 // Merge step: sort buf[0, np) and keep the best k (optionally unique ids) at the front.
 // Returns the number of valid best entries.  All threads call; `scratch` is int[kBuf].
-__device__ int merge_best(Entry* buf, int filled, int k, bool dedup, int* scratch) {
+// dedup: 0 keep duplicates (knn), 1 each id once, 2 each DISTANCE once (knnPQ's `nub`)
+__device__ int merge_best(Entry* buf, int filled, int k, int dedup, int* scratch) {
   int np = 1;
   while (np < filled) np <<= 1;
   for (int i = filled + threadIdx.x; i < np; i += blockDim.x)
@@ -205,11 +287,15 @@ __device__ int merge_best(Entry* buf, int filled, int k, bool dedup, int* scratc
   // of equal distances before it
   for (int i = threadIdx.x; i < filled; i += blockDim.x) {
     int dup = 0;
-    for (int j = i - 1; j >= 0 && buf[j].dist == buf[i].dist; --j)
-      if (buf[j].id == buf[i].id) {
-        dup = 1;
-        break;
-      }
+    if (dedup == 2) {
+      dup = i > 0 && buf[i - 1].dist == buf[i].dist;
+    } else {
+      for (int j = i - 1; j >= 0 && buf[j].dist == buf[i].dist; --j)
+        if (buf[j].id == buf[i].id) {
+          dup = 1;
+          break;
+        }
+    }
     scratch[i] = dup;
   }
   __syncthreads();
@@ -310,14 +396,14 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
       done += take;
       __syncthreads();
       if (filled == cap) {
-        best = merge_best(buf, filled, k, dedup != 0, scratch);
+        best = merge_best(buf, filled, k, dedup, scratch);
         filled = best;
         __syncthreads();
       }
     }
   }
   if (filled > best || best == 0) {
-    best = merge_best(buf, filled, k, dedup != 0, scratch);
+    best = merge_best(buf, filled, k, dedup, scratch);
     __syncthreads();
   }
   for (int i = threadIdx.x; i < k; i += blockDim.x) {
@@ -535,7 +621,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       __syncthreads();
       if (bi < 0) break;  // candidates exhausted
       bool keep = true;
-      if (dedup && bd == last_d)  // same id => same distance: duplicates are among equal dist
+      if (dedup == 2 && nb > 0 && bd == last_d) keep = false;  // knnPQ: one per distance
+      else if (dedup && bd == last_d)  // same id => same distance: duplicates are among equal dist
         for (int j = nb - 1; j >= 0 && bdist[j] == bd; --j)
           if (bid[j] == cid[bi]) keep = false;
       if (tid == 0) {
@@ -617,14 +704,14 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
       done += take;
       __syncthreads();
       if (filled == cap) {
-        best = merge_best(buf, filled, k, dedup != 0, scratch);
+        best = merge_best(buf, filled, k, dedup, scratch);
         filled = best;
         __syncthreads();
       }
     }
   }
   if (filled > best || best == 0) {
-    best = merge_best(buf, filled, k, dedup != 0, scratch);
+    best = merge_best(buf, filled, k, dedup, scratch);
     __syncthreads();
   }
   for (int i = threadIdx.x; i < k; i += blockDim.x) {
@@ -633,6 +720,85 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
     out_dist[q * k + i] = ok ? buf[i].dist : __longlong_as_double(0x7ff0000000000000LL);
   }
   if (threadIdx.x == 0) out_cnt[q] = best;
+}
+
+// knnH: distances of the points of the selected leaf ranges, written in result order
+// (sel[r].pos = position of the range's first point in the query's result).  One block per
+// query, one wave per point.
+template <class TD>
+__global__ __launch_bounds__(256) void dist_sel_dense_kernel(
+    const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
+    const Range* __restrict__ sel, const int64_t* __restrict__ sel_off,
+    const int64_t* __restrict__ out_off, int32_t* __restrict__ out_ids,
+    double* __restrict__ out_dist) {
+  typedef typename AccOf<TD>::type TA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  TA* qs = reinterpret_cast<TA*>(smem);
+  const int64_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) qs[j] = ld<TD>(Q + q * d + j);
+  __syncthreads();
+  for (int64_t r = sel_off[q]; r < sel_off[q + 1]; ++r) {
+    const Range rg = sel[r];
+    for (int i = wave; i < rg.n; i += 4) {
+      const int id = perm[rg.poff + i];
+      TA s = (TA)0;
+      for (int j = lane; j < d; j += 64) {
+        const TA df = ld<TD>(X + (int64_t)id * d + j) - qs[j];
+        s += df * df;
+      }
+      const TA tot = wave_sum(s);
+      if (lane == 0) {
+        out_ids[out_off[q] + rg.pos + i] = id;
+        out_dist[out_off[q] + rg.pos + i] = (double)sqrt((double)tot);
+      }
+    }
+  }
+}
+
+template <class TD>
+__global__ __launch_bounds__(256) void dist_sel_csr_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const TD* __restrict__ val, int d, const int64_t* __restrict__ qrowptr,
+    const int32_t* __restrict__ qcol, const TD* __restrict__ qval,
+    const int32_t* __restrict__ perm, const Range* __restrict__ sel,
+    const int64_t* __restrict__ sel_off, const int64_t* __restrict__ out_off,
+    int32_t* __restrict__ out_ids, double* __restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* qs = reinterpret_cast<double*>(smem);  // [d] densified query
+  __shared__ double s_qn2;
+  const int64_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) qs[j] = 0.0;
+  __syncthreads();
+  for (int64_t j = qrowptr[q] + threadIdx.x; j < qrowptr[q + 1]; j += blockDim.x)
+    qs[qcol[j]] = (double)qval[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double s = 0;
+    for (int j = lane; j < d; j += 64) s += qs[j] * qs[j];
+    s = wave_sum(s);
+    if (lane == 0) s_qn2 = s;
+  }
+  __syncthreads();
+  const double qn2 = s_qn2;
+  for (int64_t r = sel_off[q]; r < sel_off[q + 1]; ++r) {
+    const Range rg = sel[r];
+    for (int i = wave; i < rg.n; i += 4) {
+      const int id = perm[rg.poff + i];
+      double s = 0;
+      for (int64_t j = rowptr[id] + lane; j < rowptr[id + 1]; j += 64) {
+        const double qj = qs[col[j]];
+        const double df = (double)val[j] - qj;
+        s += df * df - qj * qj;  // same formula as topk_csr_kernel: true Euclidean distance
+      }
+      s = wave_sum(s) + qn2;
+      if (lane == 0) {
+        out_ids[out_off[q] + rg.pos + i] = id;
+        out_dist[out_off[q] + rg.pos + i] = sqrt(s > 0 ? s : 0.0);
+      }
+    }
+  }
 }
 
 // multi-GPU merge: G shard results per query, shard-major [G][nq][k]
@@ -661,7 +827,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ 
   __syncthreads();
   int valid = 0;
   for (int g = 0; g < G; ++g) valid += cnt[(int64_t)g * nq + q];
-  int best = merge_best(buf, total, k, dedup != 0, scratch);
+  int best = merge_best(buf, total, k, dedup, scratch);
   // merge_best counted +inf padding as entries: clamp to the valid ones (dedup can only
   // shrink further; invalid entries have id -1 and sort last)
   __syncthreads();
@@ -800,7 +966,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
   RPT_TRY(make_plan(ctx, f, q, pl));
   ctx->last_candidates = pl.total_cand;
   if (q->n == 0) return RPT_OK;
-  const int dedup = (flags & RPT_KNN_DEDUP) ? 1 : 0;
+  const int dedup = flags & 3;
   if (data->csr) {
     const size_t smem = topk_smem(data->d, 8);
     if (data->dtype == RPT_F64) {
@@ -846,7 +1012,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
                      (size_t)data->d * 8 <= 32 * 1024;
   if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
   const int64_t nq = q->n;
-  const int dedup = (flags & RPT_KNN_DEDUP) ? 1 : 0;
+  const int dedup = flags & 3;
   DevBuf<char> Pq;
   DevBuf<unsigned int> ovf;
   DevBuf<unsigned long long> ctot;
@@ -883,6 +1049,131 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   return RPT_OK;
 }
 
+// knnH (RPTree.hs:199-217): the union of the trees' candidatesH heaps is popped in increasing
+// priority; buckets are taken while the running count stays <= k — but at least one —, each new
+// bucket in FRONT of the ones taken before; the result is every point of those buckets with its
+// distance, neither sorted nor cut to k.  Equal priorities keep (tree, DFS) order (the reference's
+// order among ties depends on the shape of its heap).
+// Device: query projections, traversal with priorities, distances.  Host: the per-query
+// selection over a few dozen (priority, leaf) entries.
+int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
+              int32_t k, int64_t* off_host, int32_t* ids_host, double* dist_host, int64_t cap,
+              int64_t* total) {
+  RPT_ARG(data->dtype == q->dtype && data->csr == q->csr, "data and query must have one layout");
+  const int64_t nq = q->n;
+  const int T = f->T;
+  *total = 0;
+  if (off_host) off_host[0] = 0;
+  if (nq == 0) return RPT_OK;
+  QueryPlan pl;
+  RPT_TRY(make_plan(ctx, f, q, pl));
+  hipStream_t st = ctx->stream;
+  DevBuf<double> prio;
+  RPT_TRY(prio.alloc((size_t)pl.total_rng));
+  const int threads = T <= 64 ? 64 : (T <= 128 ? 128 : 256);
+  if (f->pdtype == RPT_F64)
+    hipLaunchKernelGGL(ranges_h_kernel<double>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                       f->mglo.p, f->mghi.p, f->nodes, (const double*)pl.Pq.p, nq, T, f->L,
+                       f->min_leaf, f->n, pl.rng_off.p, prio.p);
+  else
+    hipLaunchKernelGGL(ranges_h_kernel<float>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                       f->mglo.p, f->mghi.p, f->nodes, (const float*)pl.Pq.p, nq, T, f->L,
+                       f->min_leaf, f->n, pl.rng_off.p, prio.p);
+  RPT_HIP(hipGetLastError());
+  RPT_HIP(stream_sync(st));
+  std::vector<Range> hr((size_t)pl.total_rng);
+  std::vector<double> hp((size_t)pl.total_rng);
+  std::vector<int64_t> hoff((size_t)nq * T + 1);
+  RPT_HIP(hipMemcpy(hr.data(), pl.ranges.p, hr.size() * sizeof(Range), hipMemcpyDeviceToHost));
+  RPT_HIP(hipMemcpy(hp.data(), prio.p, hp.size() * 8, hipMemcpyDeviceToHost));
+  RPT_HIP(hipMemcpy(hoff.data(), pl.rng_off.p, hoff.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<Range> sel;
+  std::vector<int64_t> sel_off((size_t)nq + 1, 0), out_off((size_t)nq + 1, 0);
+  std::vector<int64_t> order, taken;
+  for (int64_t qi = 0; qi < nq; ++qi) {
+    const int64_t r0 = hoff[(size_t)qi * T], r1 = hoff[(size_t)(qi + 1) * T];
+    order.resize((size_t)(r1 - r0));
+    for (int64_t r = r0; r < r1; ++r) order[(size_t)(r - r0)] = r;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int64_t a, int64_t b) { return hp[(size_t)a] < hp[(size_t)b]; });
+    taken.clear();
+    int64_t n = 0;
+    for (int64_t r : order) {  // :209-217
+      const int64_t ntot = hr[(size_t)r].n + n;
+      if (ntot > k && !taken.empty()) break;
+      taken.push_back(r);
+      n = ntot;
+    }
+    int64_t pos = 0;
+    for (size_t i = taken.size(); i-- > 0;) {  // `xsh <> acc`: the bucket taken last comes first
+      Range rg = hr[(size_t)taken[i]];
+      rg.pos = (int32_t)pos;
+      pos += rg.n;
+      sel.push_back(rg);
+    }
+    sel_off[(size_t)qi + 1] = (int64_t)sel.size();
+    out_off[(size_t)qi + 1] = out_off[(size_t)qi] + pos;
+  }
+  *total = out_off[(size_t)nq];
+  if (off_host) std::memcpy(off_host, out_off.data(), out_off.size() * 8);
+  if (!ids_host || !dist_host || *total == 0) return RPT_OK;
+  RPT_ARG(cap >= *total, "result capacity too small");
+  DevBuf<Range> dsel;
+  DevBuf<int64_t> dsel_off, dout_off;
+  DevBuf<int32_t> ids;
+  DevBuf<double> dist;
+  RPT_TRY(dsel.alloc(sel.size()));
+  RPT_TRY(dsel_off.alloc(sel_off.size()));
+  RPT_TRY(dout_off.alloc(out_off.size()));
+  RPT_TRY(ids.alloc((size_t)*total));
+  RPT_TRY(dist.alloc((size_t)*total));
+  RPT_HIP(hipMemcpy(dsel.p, sel.data(), sel.size() * sizeof(Range), hipMemcpyHostToDevice));
+  RPT_HIP(hipMemcpy(dsel_off.p, sel_off.data(), sel_off.size() * 8, hipMemcpyHostToDevice));
+  RPT_HIP(hipMemcpy(dout_off.p, out_off.data(), out_off.size() * 8, hipMemcpyHostToDevice));
+  if (data->csr) {
+    const size_t smem = (size_t)data->d * 8;
+    RPT_ARG(smem <= 150 * 1024, "d too large");
+    if (data->dtype == RPT_F64) {
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)dist_sel_csr_kernel<double>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(dist_sel_csr_kernel<double>, dim3((unsigned)nq), dim3(256), smem, st,
+                         data->rowptr, data->col, (const double*)data->val, data->d, q->rowptr,
+                         q->col, (const double*)q->val, f->perm.p, dsel.p, dsel_off.p, dout_off.p,
+                         ids.p, dist.p);
+    } else {
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)dist_sel_csr_kernel<float>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(dist_sel_csr_kernel<float>, dim3((unsigned)nq), dim3(256), smem, st,
+                         data->rowptr, data->col, (const float*)data->val, data->d, q->rowptr,
+                         q->col, (const float*)q->val, f->perm.p, dsel.p, dsel_off.p, dout_off.p,
+                         ids.p, dist.p);
+    }
+  } else {
+    const size_t smem = (size_t)data->d * (data->dtype == RPT_F64 ? 8 : 4);
+    RPT_ARG(smem <= 150 * 1024, "d too large");
+#define RPT_DIST_SEL(TD)                                                                      \
+  do {                                                                                        \
+    if (smem > 64 * 1024)                                                                     \
+      RPT_HIP(hipFuncSetAttribute((const void*)dist_sel_dense_kernel<TD>,                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));    \
+    hipLaunchKernelGGL(dist_sel_dense_kernel<TD>, dim3((unsigned)nq), dim3(256), smem, st,    \
+                       (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p, dsel.p,       \
+                       dsel_off.p, dout_off.p, ids.p, dist.p);                                \
+  } while (0)
+    if (data->dtype == RPT_F64) RPT_DIST_SEL(double);
+    else if (data->dtype == RPT_F32) RPT_DIST_SEL(float);
+    else RPT_DIST_SEL(__hip_bfloat16);
+#undef RPT_DIST_SEL
+  }
+  RPT_HIP(hipGetLastError());
+  RPT_HIP(stream_sync(st));
+  RPT_HIP(hipMemcpy(ids_host, ids.p, (size_t)*total * 4, hipMemcpyDeviceToHost));
+  RPT_HIP(hipMemcpy(dist_host, dist.p, (size_t)*total * 8, hipMemcpyDeviceToHost));
+  return RPT_OK;
+}
+
 int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
                       const int32_t* count_dev, int32_t G, int64_t nq, int32_t k, int32_t flags,
                       int32_t* out_ids, double* out_dist, int32_t* out_count) {
@@ -894,7 +1185,7 @@ int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_d
     RPT_HIP(hipFuncSetAttribute((const void*)merge_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, ctx->stream, ids_dev,
-                     dist_dev, count_dev, G, nq, k, (flags & RPT_KNN_DEDUP) ? 1 : 0, out_ids,
+                     dist_dev, count_dev, G, nq, k, flags & 3, out_ids,
                      out_dist, out_count);
   RPT_HIP(hipGetLastError());
   return RPT_OK;

@@ -5,6 +5,7 @@
 //
 //   forestBatch / treeBatch   Batch.hs:29-63          knn          RPTree.hs:168-176
 //   candidates                RPTree.hs:289-314        recallWith   RPTree.hs:259-282
+//   knnH / knnPQ              RPTree.hs:181-217,318-342
 //   rpTreeCfg / RPTreeConfig  Conduit.hs:123-141       SVector/DVector/Embed  Internal.hs:56-133
 //   sparse / stdNormal / sample: host-side hyperplane sampling, Batch.hs:59-61, Gen.hs:148-195
 //   (SplitMix64 + Box-Muller restated from the published algorithm: self-consistent, not
@@ -207,6 +208,37 @@ inline std::vector<std::pair<double, int32_t>> knn(const RPForest& tts, int k, c
                      RPT_KNN_KEEP_DUPLICATES, ids.data(), dist.data(), &cnt));
   std::vector<std::pair<double, int32_t>> out;
   for (int i = 0; i < cnt; ++i) out.push_back({dist[(size_t)i], ids[(size_t)i]});
+  return out;
+}
+
+// knnPQ metricL2 k forest q  (RPTree.hs:181-194): like knn, one entry per distance (`nub`)
+inline std::vector<std::pair<double, int32_t>> knnPQ(const RPForest& tts, int k, const DVector& q) {
+  std::vector<DVector> qv{q};
+  Dataset qs(*tts.ctx, qv);
+  std::vector<int32_t> ids((size_t)k);
+  std::vector<double> dist((size_t)k);
+  int32_t cnt = 0;
+  check(rpt_knn_host(tts.ctx->get(), tts.get(), tts.data->get(), qs.get(), k,
+                     RPT_KNN_DEDUP_DISTANCE, ids.data(), dist.data(), &cnt));
+  std::vector<std::pair<double, int32_t>> out;
+  for (int i = 0; i < cnt; ++i) out.push_back({dist[(size_t)i], ids[(size_t)i]});
+  return out;
+}
+
+// knnH metricL2 k forest q  (RPTree.hs:199-217): whole buckets of the leaves with the smallest
+// margin priority, NOT sorted by distance and NOT cut to k (as the reference)
+inline std::vector<std::pair<double, int32_t>> knnH(const RPForest& tts, int k, const DVector& q) {
+  std::vector<DVector> qv{q};
+  Dataset qs(*tts.ctx, qv);
+  int64_t off[2] = {0, 0}, total = 0;
+  check(rpt_knnh_host(tts.ctx->get(), tts.get(), tts.data->get(), qs.get(), k, off, nullptr,
+                      nullptr, 0, &total));
+  std::vector<int32_t> ids((size_t)(total > 0 ? total : 1));
+  std::vector<double> dist((size_t)(total > 0 ? total : 1));
+  check(rpt_knnh_host(tts.ctx->get(), tts.get(), tts.data->get(), qs.get(), k, off, ids.data(),
+                      dist.data(), total, &total));
+  std::vector<std::pair<double, int32_t>> out;
+  for (int64_t i = 0; i < total; ++i) out.push_back({dist[(size_t)i], ids[(size_t)i]});
   return out;
 }
 

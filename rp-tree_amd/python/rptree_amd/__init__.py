@@ -20,7 +20,8 @@ from collections import namedtuple
 import numpy as np
 
 from . import gen
-from ._lib import (RPT_BF16, RPT_F32, RPT_F64, RPT_KNN_DEDUP, RPT_KNN_KEEP_DUPLICATES,
+from ._lib import (RPT_BF16, RPT_F32, RPT_F64, RPT_KNN_DEDUP, RPT_KNN_DEDUP_DISTANCE,
+                   RPT_KNN_KEEP_DUPLICATES,
                    RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA, RPTError, check, lib)
 
 __all__ = [
@@ -29,6 +30,7 @@ __all__ = [
     "candidates", "recallWith", "rpTreeCfg", "RPTreeConfig", "leaves", "levels", "points",
     "treeSize", "leafSizes", "metricL2", "inner", "project", "splitSegments", "topology",
     "bruteKnn", "RPTError", "forest", "tree", "saveForest", "loadForest", "importForest",
+    "knnH", "knnHBatch", "knnPQ", "candidatesBatch",
 ]
 
 _DT = {np.dtype(np.float64): RPT_F64, np.dtype(np.float32): RPT_F32}
@@ -501,13 +503,16 @@ def candidatesBatch(forest, qs):
 
 
 def knnBatch(k, forest, qs, dedup=False):
-    """knn for a batch of queries -> (ids[nq][k], dist[nq][k], count[nq])."""
+    """knn for a batch of queries -> (ids[nq][k], dist[nq][k], count[nq]).
+    dedup: False = the reference's knn (duplicates kept), True = each id once,
+    RPT_KNN_DEDUP_DISTANCE = knnPQ's `nub` (one entry per distance)."""
     ctx = forest.ctx
     qd, nq = _query_dataset(ctx, forest.data, qs)
     ids = np.empty((nq, k), dtype=np.int32)
     dist = np.empty((nq, k), dtype=np.float64)
     cnt = np.empty(nq, dtype=np.int32)
-    flags = RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES
+    flags = (RPT_KNN_DEDUP_DISTANCE if dedup == RPT_KNN_DEDUP_DISTANCE
+             else RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES)
     check(lib().rpt_knn_host(ctx._h, forest._h, forest.data._h, qd._h, int(k), flags, _vp(ids),
                              _vp(dist), _vp(cnt)))
     return ids, dist, cnt
@@ -521,6 +526,42 @@ def knn(distf, k, tts, q, dedup=False):
         raise NotImplementedError("the device path evaluates metricL2 only")
     ids, dist, cnt = knnBatch(k, tts, q, dedup=dedup)
     return [(float(dist[0, i]), int(ids[0, i])) for i in range(int(cnt[0]))]
+
+
+def knnPQ(distf, k, tts, q):
+    """RPTree.hs:181-194: like knn, but the heap's `nub` keeps ONE entry per distance value
+    (the first in candidate order here; the reference's pick among ties depends on the heap)."""
+    if distf is not metricL2:
+        raise NotImplementedError("the device path evaluates metricL2 only")
+    ids, dist, cnt = knnBatch(k, tts, q, dedup=RPT_KNN_DEDUP_DISTANCE)
+    return [(float(dist[0, i]), int(ids[0, i])) for i in range(int(cnt[0]))]
+
+
+def knnHBatch(k, forest, qs):
+    """knnH for a batch of queries -> (off[nq+1], ids, dist): the result of query i is
+    ids[off[i]:off[i+1]] with its distances."""
+    ctx = forest.ctx
+    qd, nq = _query_dataset(ctx, forest.data, qs)
+    total = C.c_int64()
+    off = np.empty(nq + 1, dtype=np.int64)
+    check(lib().rpt_knnh_host(ctx._h, forest._h, forest.data._h, qd._h, int(k), _vp(off), None,
+                              None, 0, C.byref(total)))
+    ids = np.empty(max(total.value, 1), dtype=np.int32)
+    dist = np.empty(max(total.value, 1), dtype=np.float64)
+    check(lib().rpt_knnh_host(ctx._h, forest._h, forest.data._h, qd._h, int(k), _vp(off),
+                              _vp(ids), _vp(dist), total.value, C.byref(total)))
+    return off, ids[:total.value], dist[:total.value]
+
+
+def knnH(distf, k, tts, q):
+    """RPTree.hs:199-217: leaves are visited in increasing margin priority (candidatesH
+    :318-342); whole buckets are taken while the running count stays <= k (at least one), the
+    bucket taken last first.  As in the reference the result is NOT sorted by distance and NOT
+    cut to k: [(distance, point id)]."""
+    if distf is not metricL2:
+        raise NotImplementedError("the device path evaluates metricL2 only")
+    off, ids, dist = knnHBatch(k, tts, q)
+    return [(float(dist[i]), int(ids[i])) for i in range(int(off[0]), int(off[1]))]
 
 
 def bruteKnn(forest_or_data, qs, k, ctx=None):

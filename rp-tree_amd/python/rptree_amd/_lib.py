@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(PKG_ROOT, "librptree_hip.so")
 
 RPT_F64, RPT_F32, RPT_BF16 = 0, 1, 2
 RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA = 0, 1, 2
-RPT_KNN_KEEP_DUPLICATES, RPT_KNN_DEDUP = 0, 1
+RPT_KNN_KEEP_DUPLICATES, RPT_KNN_DEDUP, RPT_KNN_DEDUP_DISTANCE = 0, 1, 2
 
 i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
 p_i32, p_i64, p_f64 = C.POINTER(i32), C.POINTER(i64), C.POINTER(f64)
@@ -49,6 +49,7 @@ SYMBOLS = {
     "rpt_forest_stats": (i32, [vp, p_i64, p_i64]),
     "rpt_split_segments": (i32, [vp, vp, i64, vp, vp, vp, i32, vp]),
     "rpt_candidates": (i32, [vp, vp, vp, vp, vp, i64, p_i64]),
+    "rpt_knnh_host": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i64, p_i64]),
     "rpt_knn_host": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "rpt_knn_dev": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "rpt_knn_last_candidates": (i32, [vp, p_i64]),

@@ -433,3 +433,49 @@ def test_knn_f32_data(rp, ctx, oracle):
     ref = np.sqrt(((X[ids[:, 1]].astype(np.float64) - X[:50].astype(np.float64)) ** 2).sum(1))
     assert np.allclose(dist[:, 1], ref, rtol=1e-5)
     assert (bi[:, 0] == np.arange(50)).all()
+
+
+# ------------------------------------------------------------------ knnH / knnPQ
+def test_knnh_matches_oracle(rp, ctx, small_forest, oracle):
+    """knnH (RPTree.hs:199-217): whole buckets of the lowest-margin-priority leaves, the bucket
+    taken last first, unsorted and not cut to k."""
+    X, f, fo, Q = small_forest
+    for k in (1, 10, 60, 200):
+        off, ids, dist = rp.knnHBatch(k, f, Q[:12])
+        for i in range(12):
+            wi, wd = oracle.knn_h_dense(fo, X, Q[i], k)
+            got = ids[off[i]:off[i + 1]]
+            assert np.array_equal(got, wi), (k, i)
+            assert np.allclose(dist[off[i]:off[i + 1]], wd, rtol=1e-12)
+    hits = rp.knnH(rp.metricL2, 10, f, Q[0])
+    wi, wd = oracle.knn_h_dense(fo, X, Q[0], 10)
+    assert [i for _, i in hits] == wi.tolist()
+
+
+def test_knnh_sparse_matches_oracle(rp, ctx, oracle):
+    n, d = 3000, 30
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.3)
+    R, _ = oracle.forest_hyperplanes(9, 4, 6, 0.5, d)
+    fo = oracle.forest_build_csr(rowptr, col, val, d, R, 25)
+    f = rp.forestBatch(9, 6, 25, 4, 0.5, d, (rowptr, col, val, d), ctx=ctx)
+    assert np.array_equal(f.perm, fo.perm)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 10, d, 0.3)
+    off, ids, dist = rp.knnHBatch(30, f, (qr, qc, qv, d))
+    for i in range(10):
+        a, b = qr[i], qr[i + 1]
+        wi, wd = oracle.knn_h_csr(fo, rowptr, col, val, qc[a:b], qv[a:b], 30, true_l2=True)
+        assert np.array_equal(ids[off[i]:off[i + 1]], wi)
+        assert np.allclose(dist[off[i]:off[i + 1]], wd, rtol=1e-9, atol=1e-12)
+
+
+def test_knnpq_collapses_equal_distances(rp, ctx, small_forest, oracle):
+    """knnPQ (RPTree.hs:181-194): one entry per distance value — the copies of a point that
+    several trees return collapse, and so do distinct points at exactly the same distance."""
+    X, f, fo, Q = small_forest
+    ids, dist, cnt = rp.knnBatch(20, f, Q[:16], dedup=rp.RPT_KNN_DEDUP_DISTANCE)
+    for i in range(16):
+        wi, wd = oracle.knn_pq_dense(fo, X, Q[i], 20)
+        assert np.array_equal(ids[i, :cnt[i]], wi)
+        assert np.all(np.diff(dist[i, :cnt[i]]) > 0)
+    hits = rp.knnPQ(rp.metricL2, 5, f, Q[0])
+    assert [i for _, i in hits] == oracle.knn_pq_dense(fo, X, Q[0], 5)[0].tolist()

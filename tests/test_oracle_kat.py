@@ -158,3 +158,60 @@ def test_candidates_rule(oracle):
     assert oracle.candidates_dense(f, [0.6], 0).tolist() == [2, 3]
     # p = -5: proj < thr, dl=4 < dr=7 -> left only
     assert oracle.candidates_dense(f, [-5.0], 0).tolist() == [0, 1]
+
+
+def test_candidates_h_and_knn_h_rule(oracle):
+    # hand-built 2-level tree over 8 points, 2 per leaf (RPTree.hs:318-342, 199-217)
+    import numpy as np
+    from oracle.oracle import Forest
+    R = np.array([[[1.0], [1.0]]])                       # both levels project on x
+    nan = np.nan
+    f = Forest(8, 1, R, 2, 2, np.arange(8, dtype=np.int32)[None, :],
+               np.array([[0.0, -2.0, 2.0]]), np.array([[-1.0, -3.0, 1.0]]),
+               np.array([[1.0, -1.5, 3.0]]))
+    # q = 0.4: root: proj > thr, dl=1.4 > dr=0.6 -> right only, p = min(inf, 0.6) = 0.6;
+    # node 2 (thr 2, margins 1, 3): proj < thr, dl=.6 < dr=2.6 -> left only, p = min(.6, .6)
+    prio, off, ln = oracle.candidates_h_dense(f, [0.4], 0)
+    assert prio.tolist() == [0.6] and off.tolist() == [4] and ln.tolist() == [2]
+    # q = 0.6: root: proj > thr, dl=1.6 > dr=.4 -> right, p=.4; node 2: dl=.4 < dr=2.4 -> left
+    prio, off, ln = oracle.candidates_h_dense(f, [0.6], 0)
+    assert prio.tolist() == [0.4] and off.tolist() == [4]
+    # q = 0.45: root: proj > thr and dl=1.45 > dr=.55 -> right only
+    # q = -0.2 at root: proj < thr, dl=.8 < dr=1.2 -> left only, p=.8; node 1 (thr -2, margins
+    # -3, -1.5): proj > thr, dl=2.8 > dr=1.3 -> right only: p = min(.8, 1.3) = .8, leaf [2,3]
+    prio, off, ln = oracle.candidates_h_dense(f, [-0.2], 0)
+    assert prio.tolist() == [0.8] and off.tolist() == [2]
+    X = np.arange(8, dtype=np.float64)[:, None] - 3.5
+    ids, dist = oracle.knn_h_dense(f, X, [-0.2], 1)
+    assert ids.tolist() == [2, 3]                        # one whole bucket even though k = 1
+    assert np.allclose(dist, [1.3, 0.3])                 # not sorted by distance
+
+
+def test_knn_h_and_pq_properties(oracle):
+    n, T, min_leaf = 5000, 6, 20
+    X = oracle.data_normal_dense2(3, n, 8)
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, 8)
+    R, _ = oracle.forest_hyperplanes(7, T, L, pnz, 8)
+    f = oracle.forest_build_dense(X, R, min_leaf)
+    topo_leaf = {}
+    for q in X[:5]:
+        leaves = []
+        for t in range(T):
+            prio, off, ln = oracle.candidates_h_dense(f, q, t)
+            leaves += [(p, t, o, l) for p, o, l in zip(prio, off, ln)]
+        leaves.sort(key=lambda e: e[0])                 # stable: (tree, DFS) order among ties
+        for k in (1, 30, 100):
+            ids, dist = oracle.knn_h_dense(f, X, q, k)
+            taken, cnt = [], 0
+            for e in leaves:
+                if cnt + e[3] > k and taken:
+                    break
+                taken.insert(0, e)
+                cnt += e[3]
+            want = np.concatenate([f.perm[t][o:o + l] for _, t, o, l in taken])
+            assert np.array_equal(ids, want)
+            assert np.allclose(dist, np.sqrt(((X[ids] - q) ** 2).sum(1)))
+        i_pq, d_pq = oracle.knn_pq_dense(f, X, q, 8)
+        i_dd, d_dd = oracle.knn_dense(f, X, q, 8, dedup=True)
+        assert (np.diff(d_pq) > 0).all()
+        assert np.array_equal(i_pq, i_dd)               # continuous data: no two points tie
