@@ -119,116 +119,10 @@ __global__ __launch_bounds__(256) void proj_exact(const T* __restrict__ X, int64
 }
 
 // ---------------------------------------------------------------------------------------
-// Fast exact-order path for rows of exactly D elements.  Same arithmetic as proj_exact (one
-// `acc = r*x + acc` per (k, hyperplane), k descending, separate multiply and add) with
-//   * guard-free, fully unrolled staging: the next k-chunk's 16-B pieces are loaded into
-//     registers while the current chunk is accumulated (async-STAGE split); waves never
-//     synchronise with each other (wave-private LDS tile),
-//   * SKIP (off by default): the (k, c) pairs with r == 0 — the terms innerSD never visits
-//     (Internal.hs:375-382); a dense-ified zero adds an exact +-0 that never changes the
-//     accumulator — can be skipped with wave-uniform scalar branches on a per-k bit mask.
-//     Measured as a loss: hipcc sinks the scalar load of r into every taken branch, so each
-//     executed term waits on the scalar cache; the dense form hoists 4 s_load_dwordx16 per k.
-// Work item = (64-row tile, k-chunk); chunks of a tile are visited last to first.
-// ---------------------------------------------------------------------------------------
-template <class T>
-__global__ void mask_R_kernel(const T* __restrict__ Rt, int d, int CB, int nblk,
-                              uint32_t* __restrict__ masks /*[nblk][d]*/) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nblk * d) return;
-  const T* r = Rt + (int64_t)i * CB;
-  uint32_t m = 0;
-  for (int c = 0; c < CB; ++c) m |= (r[c] != (T)0 ? 1u : 0u) << c;
-  masks[i] = m;
-}
-
-template <class T, int D, int CB, int KC, bool SKIP>
-__global__ __launch_bounds__(256, 2) void proj_exact_fast(const T* __restrict__ X, int64_t n,
-                                                          const T* __restrict__ Rt /*[D][CB]*/,
-                                                          const uint32_t* __restrict__ masks,
-                                                          T* __restrict__ P, int64_t ldp,
-                                                          int ncol, int64_t ntiles) {
-  static_assert(CB == 32, "one mask bit per hyperplane");
-  constexpr int PIECE = 16 / (int)sizeof(T);
-  constexpr int PPR = KC / PIECE;              // pieces per row per chunk
-  constexpr int NP = kWave * PPR / 64;         // pieces per lane per chunk
-  constexpr int NCH = D / KC;
-  constexpr int LDW = KC + PIECE;              // row stride keeps 16-B alignment
-  __shared__ __attribute__((aligned(16))) T tile[4][kWave * LDW];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  T* my = tile[wave];
-  typedef typename Vec16<T>::type Raw;
-  const int64_t last_row = n - 1;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * 4;
-
-  Raw stage[NP];
-  auto issue = [&](int64_t t, int ch) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int p = i * 64 + lane;
-      int64_t row = t * kWave + p / PPR;
-      row = row < last_row ? row : last_row;
-      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + ch * KC + (p % PPR) * PIECE);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int p = i * 64 + lane;
-      *reinterpret_cast<Raw*>(my + (p / PPR) * LDW + (p % PPR) * PIECE) = stage[i];
-    }
-  };
-
-  T acc[CB];
-#pragma unroll
-  for (int c = 0; c < CB; ++c) acc[c] = (T)0;
-
-  int64_t t = wave_global;
-  int ch = NCH - 1;
-  if (t < ntiles) issue(t, ch);
-  while (t < ntiles) {
-    commit();
-    // next work item
-    int64_t tn = t;
-    int chn = ch - 1;
-    if (chn < 0) {
-      chn = NCH - 1;
-      tn = t + wave_stride;
-    }
-    if (tn < ntiles) issue(tn, chn);
-    // accumulate this chunk, k descending
-    const T* rrow = Rt + (int64_t)ch * KC * CB;
-    const uint32_t* mrow = masks + ch * KC;
-    for (int k = KC - 1; k >= 0; --k) {
-      const T x = my[lane * LDW + k];
-      const T* rk = rrow + k * CB;      // wave-uniform -> scalar loads
-      const uint32_t mk = SKIP ? mrow[k] : 0u;  // wave-uniform
-#pragma unroll
-      for (int c = 0; c < CB; ++c)
-        if (!SKIP || (mk & (1u << c))) acc[c] = add_rn(mul_rn(rk[c], x), acc[c]);
-    }
-    if (ch == 0) {
-      const int64_t row = t * kWave + lane;
-      if (row < n) {
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
-          if (c < ncol) P[(int64_t)c * ldp + row] = acc[c];
-      }
-#pragma unroll
-      for (int c = 0; c < CB; ++c) acc[c] = (T)0;
-    }
-    t = tn;
-    ch = chn;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Exact-order kernel, LDS-broadcast form (rows of exactly D elements).  proj_exact_fast is
-// bounded by the scalar cache: 32 hyperplane values per k arrive through four serialized
-// s_load_dwordx16.  Here a wave owns 128 rows (two per lane) and walks k-chunks of KC from the
-// last to the first; the chunk of X ([128][KC]) and the chunk of hyperplanes ([KC][32]) are
+// Exact-order kernel, LDS-broadcast form (rows of exactly D elements).  (Reading the 32
+// hyperplane values of a k through wave-uniform scalar loads, as proj_exact does, is bounded by
+// the scalar cache: four serialized s_load_dwordx16 per k — measured 1.1 ms per launch at C2.)
+// Here a wave owns 128 rows (two per lane) and walks k-chunks of KC from the last to the first; the chunk of X ([128][KC]) and the chunk of hyperplanes ([KC][32]) are
 // staged in a wave-private LDS slab (next chunk prefetched into registers meanwhile); per k the
 // 32 hyperplane values are read with eight uniform-address ds_read_b128 (LDS broadcast) and
 // each feeds two rows: acc = r*x + acc, separate multiply and add, k descending — the
@@ -913,42 +807,28 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
   constexpr int CB = 32;
   const int nblk = (C + CB - 1) / CB;
   DevBuf<T> Rt;
-  DevBuf<uint32_t> masks;
   RPT_TRY(Rt.alloc((size_t)nblk * d * CB));
   hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
-  const bool fast = d == 128;
-  if (fast) {
-    RPT_TRY(masks.alloc((size_t)nblk * d));
-    hipLaunchKernelGGL(mask_R_kernel<T>, dim3((unsigned)((nblk * d + 255) / 256)), dim3(256), 0,
-                       ctx->stream, Rt.p, d, CB, nblk, masks.p);
-  }
-  const int64_t ntiles = (n + 63) / 64;
-  int64_t fblocks = (ntiles + 3) / 4;
-  if (fblocks > (int64_t)ctx->n_cu * 2) fblocks = (int64_t)ctx->n_cu * 2;
   const int64_t blocks = (n + 255) / 256;
   for (int b = 0; b < nblk; ++b) {
     const int c0 = b * CB;
     const int ncol = C - c0 < CB ? C - c0 : CB;
     ProfScope ps(ctx, RPT_PROF_PROJECT);
-    if (fast && !getenv("RPT_EXACT_SGPR")) {
+    if (d == 128) {
       const int64_t nt128 = (n + 127) / 128;
       int64_t lb = (nt128 + 3) / 4;
       if (lb > (int64_t)ctx->n_cu * 2) lb = (int64_t)ctx->n_cu * 2;
       hipLaunchKernelGGL((proj_exact_lds<T, 128, 8>), dim3((unsigned)lb), dim3(256), 0, ctx->stream,
                          (const T*)ds->X, n, Rt.p + (size_t)b * d * CB, P + (int64_t)c0 * n, n, ncol,
                          nt128);
-    } else if (fast)
-      hipLaunchKernelGGL((proj_exact_fast<T, 128, CB, 32, false>), dim3((unsigned)fblocks), dim3(256), 0,
-                         ctx->stream, (const T*)ds->X, n, Rt.p + (size_t)b * d * CB,
-                         masks.p + (size_t)b * d, P + (int64_t)c0 * n, n, ncol, ntiles);
-    else
+    } else {
       hipLaunchKernelGGL((proj_exact<T, CB, 32>), dim3((unsigned)blocks), dim3(256), 0,
                          ctx->stream, (const T*)ds->X, n, d, Rt.p + (size_t)b * d * CB,
                          P + (int64_t)c0 * n, n, ncol);
+    }
   }
   RPT_HIP(hipGetLastError());
-  RPT_HIP(stream_sync(ctx->stream));  // Rt is freed on return
-  return RPT_OK;
+  return RPT_OK;  // Rt returns to the stream-ordered allocator
 }
 
 template <class T>
@@ -961,7 +841,7 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
   RPT_TRY(Rt.alloc((size_t)nblk * d * CB));
   hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
   const size_t tile = (size_t)d * CB * sizeof(T);
-  const bool lds_path = tile <= 128 * 1024 && !getenv("RPT_CSR_L2");
+  const bool lds_path = tile <= 128 * 1024;  // else the hyperplane tile is read through L2
   if (lds_path && tile > 64 * 1024)
     RPT_HIP(hipFuncSetAttribute((const void*)proj_csr_lds<T>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile));
@@ -980,8 +860,7 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
                          P + (int64_t)c0 * n, n, ncol);
   }
   RPT_HIP(hipGetLastError());
-  RPT_HIP(stream_sync(ctx->stream));
-  return RPT_OK;
+  return RPT_OK;  // Rt returns to the stream-ordered allocator
 }
 
 }  // namespace
