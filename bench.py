@@ -225,6 +225,10 @@ def main():
     for t in range(nt_cmp):
         flips += int((leaf_index(pa[t]) != leaf_index(pb[t])).sum())
     leaf_flip_rate = flips / float(nt_cmp * N)
+    # exact-order build of the first trees, kept for the full-size comparison with the oracle
+    ex_forest = alt if alt_name == "exact" else forest
+    ex_perm = np.array(ex_forest.perm[:3])
+    ex_thr = np.array(ex_forest.thr[:3])
     alt.close()
 
     tt = torch.tensor([t_build, t_knn], dtype=torch.float64, device="cpu" if one_gpu else dev)
@@ -266,9 +270,14 @@ def main():
         Xh = X.cpu().numpy()
         nt = 3 if N >= 500_000 else min(T, 8)
         t0 = time.perf_counter()
-        orc.forest_build_dense(Xh, R[:nt], args.min_leaf)
+        f_cpu = orc.forest_build_dense(Xh, R[:nt], args.min_leaf)
         t_cpu = time.perf_counter() - t0
         cpu_build = N / (t_cpu / nt * T)
+        # full-size parity: the oracle's trees against the exact-order device build, bit for bit
+        ncmp = min(nt, len(ex_perm))
+        same_trees = sum(int(np.array_equal(f_cpu.perm[t], ex_perm[t]) and
+                             np.array_equal(f_cpu.thr[t], ex_thr[t], equal_nan=True))
+                         for t in range(ncmp))
         # queries: the oracle's knn over the FULL forest (the device-built flat arrays; they
         # are identical to the oracle's in exact mode) for a sample of queries
         fo = orc.Forest(N, d, R, maxd, args.min_leaf, forest.perm, forest.thr, forest.mglo,
@@ -288,7 +297,8 @@ def main():
                          "on the same 1M x 128 data, scaled to %d trees; knn: %d queries over the "
                          "full forest" % (nt, T, T, nqs),
                "knn_queries_per_s": nqs / t_cpuq,
-               "knn_ids_identical_to_gpu": "%d/%d" % (same, nqs)}
+               "knn_ids_identical_to_gpu": "%d/%d" % (same, nqs),
+               "trees_identical_to_gpu_exact_mode": "%d/%d" % (same_trees, ncmp)}
 
     if rank == 0:
         p_ms, p_n = prof["project"]

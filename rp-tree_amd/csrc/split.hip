@@ -734,8 +734,8 @@ __global__ __launch_bounds__(kSubThreads) void subtree_kernel(
 // in the wave's registers (16 points per lane) and a wave-private LDS slab, so a CU runs many
 // independent subtrees at once and their latencies overlap.
 // Output: every point is scattered to the slot range of its terminal node — a leaf (final
-// perm F, UNORDERED, with the key of the leaf's parent level in Kleaf) or a node still active
-// after kWRmax levels (nxt).  leaf_sort_kernel then orders every leaf bucket.
+// perm F; the bucket is written in its final order, phase h) or a node still active after
+// kWRmax levels (nxt).
 // A wave that meets a pivot bin larger than its LDS slab flags the node and writes nothing;
 // the host re-runs those nodes with subtree_kernel.
 // grid = ceil(S*T/4) blocks of 256 threads.
@@ -747,6 +747,7 @@ constexpr int kWHist = 1024;      // histogram entries per wave
 constexpr int kWMid = 192;        // pivot-bin pool per wave
 
 constexpr int kWPivot = 1 << 30;  // st flag: the point sits in its node's pivot-bin pool
+constexpr int kWHasPos = 1 << 28;  // st flag: bits 18..27 hold the point's position in its node
 
 struct WSlab {
   unsigned int hist[kWHist + 64];  // skewed: bin idx lives at idx + (idx >> 4)
@@ -756,18 +757,24 @@ struct WSlab {
   int midcur[16];
   double midkey[kWMid];
   int midid[kWMid];
-  int midnode[kWMid], midside[kWMid];
+  unsigned char midnode[kWMid], midside[kWMid];
   int toff[32], tcur[32];
   double vthr[16], vlo[16];
+  // the points of nodes whose children are leaves, in (node, bin) order: 30-bit monotone image
+  // of the key (bin << 20 | position inside the bin)
+  unsigned int code[kWCap];
+  int noff[16];  // offset of every node of the level inside the wave's segment
+  int nunord[16];  // node holds bin-mates with equal key images: its leaves stay unordered
 };
 
 template <class TK>
-__global__ __launch_bounds__(256) void wsub_kernel(
+__global__ __launch_bounds__(256, 3) void wsub_kernel(
     const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
-    TK* __restrict__ Kleaf, int64_t N, const TK* __restrict__ P, int L, int T, int level0,
-    int min_leaf, const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
+    int64_t N, const TK* __restrict__ P, int L, int T, int level0, int min_leaf,
+    const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
     int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
-    unsigned int* ovf_count, const unsigned int* __restrict__ abort, unsigned long long* dbg) {
+    unsigned int* ovf_count, unsigned int* unord_flags, unsigned int* unord_count,
+    const unsigned int* __restrict__ abort, unsigned long long* dbg) {
   __shared__ WSlab slabs[4];
   int dbgi = 0;
 #define WSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) dbg[dbgi++] = clock64(); } while (0)
@@ -785,7 +792,9 @@ __global__ __launch_bounds__(256) void wsub_kernel(
 
   int id[kWE];
   TK key[kWE];   // key of the current level; frozen at the level a point retires
-  int st[kWE];   // active: node index (>= 0); retired: -(((left-aligned path) << 8) | leaf level)
+  // active: node index (>= 0); retired: -(ordered << 23 | rank in leaf << 13 |
+  // left-aligned path << 8 | leaf level)
+  int st[kWE];
 #pragma unroll
   for (int e = 0; e < kWE; ++e) {
     const int pos = e * 64 + lane;
@@ -795,6 +804,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
   }
   int depth = 0;
   bool overflow = false;
+  bool unord = false;  // some leaf could not be ordered from the key images alone
   WSTAMP();
   for (; depth < kWRmax; ++depth) {
     const int level = level0 + depth;
@@ -840,6 +850,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       W.nmaxL[lane] = 0ULL;
       W.nminR[lane] = ~0ULL;
       W.midcur[lane] = 0;
+      W.nunord[lane] = 0;
     }
     wsync();
     WSTAMP();
@@ -887,6 +898,14 @@ __global__ __launch_bounds__(256) void wsub_kernel(
         a += c[i];
       }
     }
+    {  // the node-relative exclusive prefix replaces the count of every bin (phase h)
+      unsigned int a = inc - loc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        W.hist[lane * 17 + i] = a;
+        a += c[i];
+      }
+    }
     const unsigned long long found = __ballot(pb >= 0);
     const unsigned long long segm = (Wd == 64 ? ~0ULL : ((1ULL << Wd) - 1ULL)) << (jl * Wd);
     const unsigned long long own = found & segm;
@@ -923,6 +942,17 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     if (rl == 0) {
       W.pf[jl] = make_int4(own ? pb : -1, need_lo ? lowb : -2, need_hi ? highb : B + 1, pinc - mine);
       W.pg[jl] = make_int4(cL, nhj, nj, own ? cMid : 0);
+      int off = 0, n = n_top;
+      for (int bb = depth - 1; bb >= 0; --bb) {
+        const int h = n >> 1;
+        if ((jl >> bb) & 1) {
+          off += h;
+          n -= h;
+        } else {
+          n = h;
+        }
+      }
+      W.noff[jl] = off;
     }
     if (tot > kWMid) {
       overflow = true;
@@ -930,6 +960,72 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     }
     wsync();
     WSTAMP();
+    // ---- h. nodes whose children are leaves: position of every point inside its node, so that
+    // the leaf buckets leave this kernel in their final order.  Counting sort by bin (the
+    // histogram now holds the bins' exclusive prefixes), then the few bin-mates are ordered by
+    // a 30-bit monotone image of the key kept in LDS.  Two mates with the SAME image (or real
+    // ties) cannot be ordered from it: the node is flagged and leaf_sort_kernel orders its
+    // leaves afterwards (rare).
+    // (st of an active point from here on: node | bin << 8 | position << 18 | kWHasPos)
+    bool any_leaf = false;
+    for (int j = 0; j < M; ++j) {
+      const int4 pgj = W.pg[j];
+      any_leaf = any_leaf || (pgj.w > 0 && (level + 1 >= L || pgj.y <= min_leaf ||
+                                            pgj.z - pgj.y <= min_leaf));
+    }
+    if (any_leaf) {
+      auto image = [&](TK k) -> unsigned int {
+        const TK fq = (k - lo) * scale;
+        if (!(fq > (TK)0)) return 0u;
+        if (fq >= (TK)B) return ((unsigned int)B << 20) - 1u;
+        return (unsigned int)(fq * (TK)1048576);
+      };
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0) {
+          const int j = st[e] & 0xff, b = (st[e] >> 8) & 0x3ff;
+          const int4 pgj = W.pg[j];
+          if (level + 1 >= L || pgj.y <= min_leaf || pgj.z - pgj.y <= min_leaf) {
+            const int idx = j * B + b;
+            const int gp = W.noff[j] + (int)atomicAdd(&W.hist[idx + (idx >> 4)], 1u);
+            W.code[gp] = image(key[e]);
+            st[e] |= (gp << 18) | kWHasPos;
+          }
+        }
+      wsync();
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0 && (st[e] & kWHasPos)) {
+          const int j = st[e] & 0xff, gp = (st[e] >> 18) & 0x3ff;
+          const unsigned int b = (unsigned int)((st[e] >> 8) & 0x3ff);
+          const int lo_j = W.noff[j], hi_j = lo_j + W.pg[j].z;
+          const unsigned int mine_w = image(key[e]);
+          int nleft = 0, less = 0;
+          for (int qq = gp - 1; qq >= lo_j; --qq) {
+            const unsigned int w = W.code[qq];
+            if ((w >> 20) != b) break;
+            ++nleft;
+            less += w < mine_w;
+            if (w == mine_w) W.nunord[j] = 1;
+          }
+          for (int qq = gp + 1; qq < hi_j; ++qq) {
+            const unsigned int w = W.code[qq];
+            if ((w >> 20) != b) break;
+            less += w < mine_w;
+            if (w == mine_w) W.nunord[j] = 1;
+          }
+          st[e] = (st[e] & ~(0x3ff << 18)) | ((gp - lo_j - nleft + less) << 18);
+        }
+      wsync();
+      // a node with equal images keeps its points unordered (positions by arrival): both the
+      // image order and the exact pivot ranks would have to agree, and only real keys can tell
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0 && (st[e] & kWHasPos) && W.nunord[st[e] & 0xff]) {
+          st[e] &= ~(kWHasPos | (0x3ff << 18));
+          unord = true;
+        }
+    }
     // ---- f. pool the pivot bins; every other point descends right away.  The node records
     // are fetched four points at a time so that the LDS round trips overlap.
 #pragma unroll
@@ -946,13 +1042,14 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       for (int u = 0; u < 4; ++u) {
         const int e = e0 + u;
         if (id[e] < 0 || st[e] < 0) continue;
-        const int j = st[e] & 0xff, b = st[e] >> 8;
+        const int j = st[e] & 0xff, b = (st[e] >> 8) & 0x3ff;
+        const int hp = st[e] & (kWHasPos | (0x3ff << 18));  // position in the node, if known
         if (b == pf4[u].x) {
           const int p = pf4[u].w + atomicAdd(&W.midcur[j], 1);
           W.midkey[p] = (double)key[e];
           W.midid[p] = id[e];
-          W.midnode[p] = j;
-          st[e] = j | (p << 8) | kWPivot;
+          W.midnode[p] = (unsigned char)j;
+          st[e] = j | (p << 8) | hp | kWPivot;
           continue;
         }
         if (b == pf4[u].y) atomicMax(&W.nmaxL[j], ord_of(key[e]));
@@ -960,10 +1057,14 @@ __global__ __launch_bounds__(256) void wsub_kernel(
         const int side = b > pf4[u].x;
         const int child = 2 * j + side;
         const int nc = side ? pg4[u].z - pg4[u].y : pg4[u].y;
-        if (level + 1 >= L || nc <= min_leaf)
-          st[e] = -(((child << (kWRmax - (depth + 1))) << 8) | (level + 1));
-        else
+        if (level + 1 >= L || nc <= min_leaf) {
+          int code = ((child << (kWRmax - (depth + 1))) << 8) | (level + 1);
+          const int pos = (hp >> 18) & 0x3ff;
+          if (hp & kWHasPos) code |= (1 << 23) | ((side ? pos - pg4[u].y : pos) << 13);
+          st[e] = -code;
+        } else {
           st[e] = child;
+        }
       }
     }
     wsync();
@@ -991,7 +1092,7 @@ __global__ __launch_bounds__(256) void wsub_kernel(
           W.vlo[j] = (double)kp;
         }
         if (rank == ih2 - cLj) mghi[h] = (double)kp;
-        W.midside[p] = rank >= nh - cLj;
+        W.midside[p] = (unsigned char)(rank >= nh - cLj);
       }
     }
     wsync();
@@ -1001,15 +1102,20 @@ __global__ __launch_bounds__(256) void wsub_kernel(
       const bool piv = id[e] >= 0 && st[e] >= 0 && (st[e] & kWPivot);
       if (!__any(piv)) continue;
       if (piv) {
-        const int j = st[e] & 0xff, p = (st[e] >> 8) & 0xffff;
+        const int j = st[e] & 0xff, p = (st[e] >> 8) & 0x3ff;
+        const int hp = st[e] & (kWHasPos | (0x3ff << 18));
         const int4 pg = W.pg[j];
         const int side = W.midside[p];
         const int child = 2 * j + side;
         const int nc = side ? pg.z - pg.y : pg.y;
-        if (level + 1 >= L || nc <= min_leaf)
-          st[e] = -(((child << (kWRmax - (depth + 1))) << 8) | (level + 1));
-        else
+        if (level + 1 >= L || nc <= min_leaf) {
+          int code = ((child << (kWRmax - (depth + 1))) << 8) | (level + 1);
+          const int pos = (hp >> 18) & 0x3ff;
+          if (hp & kWHasPos) code |= (1 << 23) | ((side ? pos - pg.y : pos) << 13);
+          st[e] = -code;
+        } else {
           st[e] = child;
+        }
       }
     }
     if (lane < M && W.pg[lane].w > 0) {
@@ -1035,6 +1141,10 @@ __global__ __launch_bounds__(256) void wsub_kernel(
     }
     return;
   }
+  if (__any(unord) && lane == 0) {
+    unord_flags[si] = 1u;
+    atomicAdd(unord_count, 1u);
+  }
 
   WSTAMP();
   // ---- scatter every point to the slot range of its terminal node ----
@@ -1057,16 +1167,16 @@ __global__ __launch_bounds__(256) void wsub_kernel(
   wsync();
   int32_t* of = F + (int64_t)t * N + sg.off;
   int32_t* on = nxt + (int64_t)t * N + sg.off;
-  TK* kl = Kleaf + (int64_t)t * N + sg.off;
 #pragma unroll
   for (int e = 0; e < kWE; ++e) {
     if (id[e] < 0) continue;
     const bool done = st[e] < 0;
-    const int v = done ? ((-st[e]) >> 8) : (st[e] << (kWRmax - depth));
-    const int slot = W.toff[v] + atomicAdd(&W.tcur[v], 1);
+    const int code = -st[e];
+    const int v = done ? ((code >> 8) & 31) : (st[e] << (kWRmax - depth));
+    const bool ordered = done && ((code >> 23) & 1);
+    const int slot = W.toff[v] + (ordered ? ((code >> 13) & 1023) : atomicAdd(&W.tcur[v], 1));
     if (done) {
       of[slot] = id[e];
-      kl[slot] = key[e];
     } else {
       on[slot] = id[e];
     }
@@ -1075,38 +1185,30 @@ __global__ __launch_bounds__(256) void wsub_kernel(
 #undef WSTAMP
 }
 
-// order one leaf bucket per wave: (key of the parent's level, earlier levels, id).  The bucket
-// (<= 128 points, two per lane) is sorted by a bitonic network over lane shuffles.
-// segs: leaf segments (identical for every tree); seg_info = leaf level | (index of the
-// wsub_kernel node that produced the leaf << 6): leaves of a node that kernel flagged as
-// overflowed are skipped (the host re-runs those nodes), key level = leaf level - 1.
-// grid = ceil(S*T/4) blocks of 256 threads.
+// order one leaf bucket per wave by (key of the parent's level, earlier levels, id) — the exact
+// sort for the leaves wsub_kernel could not order from its key images (equal images, real ties).
+// The bucket (<= 128 points, two per lane) is sorted by a bitonic network over lane shuffles;
+// keys are gathered by id.  segs: leaf segments (identical for every tree); seg_level: the leaf's
+// level, key level = leaf level - 1.  grid = ceil(S*T/4) blocks of 256 threads.
 template <class TK>
-__global__ __launch_bounds__(256) void leaf_sort_kernel(int32_t* __restrict__ F,
-                                                        const TK* __restrict__ Kleaf, int64_t N,
+__global__ __launch_bounds__(256) void leaf_sort_kernel(int32_t* __restrict__ F, int64_t N,
                                                         const TK* __restrict__ P, int L, int T,
                                                         const Seg* __restrict__ segs, int S,
-                                                        const int* __restrict__ seg_info,
-                                                        const unsigned int* __restrict__ ovf_flags,
-                                                        const unsigned int* __restrict__ abort) {
+                                                        const int* __restrict__ seg_level) {
   const int lane = threadIdx.x & 63;
   const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wg >= (int64_t)S * T) return;
-  if (abort && *abort) return;
   const int si = (int)(wg % S), t = (int)(wg / S);
   const Seg sg = segs[si];
   const int tn = sg.n;
   if (tn <= 1) return;
-  const int info = seg_info[si];
-  if (ovf_flags[info >> 6]) return;
-  Keys<TK> K{P + (int64_t)t * L * N, N, (info & 63) - 1, nullptr};
+  Keys<TK> K{P + (int64_t)t * L * N, N, seg_level[si] - 1, nullptr};
   int32_t* f = F + (int64_t)t * N + sg.off;
-  const TK* kk = Kleaf + (int64_t)t * N + sg.off;
   const bool v0 = lane < tn, v1 = lane + 64 < tn;
-  TK k0 = v0 ? kk[lane] : pos_inf<TK>();
   int i0 = v0 ? f[lane] : kPad;
-  TK k1 = v1 ? kk[lane + 64] : pos_inf<TK>();
   int i1 = v1 ? f[lane + 64] : kPad;
+  TK k0 = v0 ? K.key(i0) : pos_inf<TK>();
+  TK k1 = v1 ? K.key(i1) : pos_inf<TK>();
   if (tn <= 64) {
     TK ka[1] = {k0};
     int ia[1] = {i0};
@@ -2335,7 +2437,6 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   DevBuf<unsigned long long> counters;  // [0] tie nodes, [1] (uint) big-mid count
   DevBuf<GSeg> dglist;
   DevBuf<unsigned int> ovf;
-  DevBuf<TK> Kleaf;
   DevBuf<Seg> dsegs3;
   DevBuf<int> dlv;
   RPT_TRY(counters.alloc(2));
@@ -2555,7 +2656,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   }
   HT("stream to_perm + free");
   if (stream_unchecked) {
-    // only wsub_kernel / leaf_sort_kernel honour the abort flag: anything else waits for it
+    // only wsub_kernel honours the abort flag: anything else waits for it
     bool all_wave = getenv("RPT_NO_WSUB") == nullptr;
     for (const PNode& pn : pending[(size_t)streamed]) all_wave = all_wave && pn.seg.n <= kWCap;
     if (!all_wave) {
@@ -2586,9 +2687,65 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   struct Deferred {
     int level = 0, b = 0;
     std::vector<Seg> nodes;
-    DevBuf<unsigned int> ovf;  // [0] count, [1 + i] flag of node i
+    // [0] overflow count, [1 + i] overflow flag of node i (pivot bins larger than the wave's
+    // pool: run again by subtree_kernel); [S + 1] count, [S + 2 + i] flag of nodes holding
+    // leaves the wave could not order from the key images (leaf sort pass afterwards)
+    DevBuf<unsigned int> flags;
   };
   std::list<Deferred> deferred;
+
+  // order the leaf buckets below the flagged nodes of one wsub_kernel launch (exact keys)
+  auto sort_leaves_below = [&](const std::vector<Seg>& tops, int level) -> int32_t {
+    std::vector<Seg> small_l;
+    std::vector<int> small_lv;
+    std::vector<std::pair<Seg, int>> mid_l;
+    std::function<void(const Seg&, int, int)> walk = [&](const Seg& sgm, int lv, int dp) {
+      if (is_leaf(lv, sgm.n, L, f->min_leaf)) {
+        if (sgm.n > 1) {
+          if (sgm.n <= 128) {
+            small_l.push_back(Seg{sgm.off, sgm.n, -1});
+            small_lv.push_back(lv);
+          } else {
+            mid_l.push_back({Seg{sgm.off, sgm.n, -1}, lv});
+          }
+        }
+        return;
+      }
+      if (dp == kWRmax) return;  // still a split node: stays pending
+      const int nh = sgm.n / 2;
+      walk(Seg{sgm.off, nh, 2 * sgm.heap + 1}, lv + 1, dp + 1);
+      walk(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, lv + 1, dp + 1);
+    };
+    for (const Seg& tp : tops) walk(tp, level, 0);
+    if (!small_l.empty()) {
+      RPT_TRY(upload(small_l, dsegs3));
+      RPT_TRY(dlv.ensure(small_lv.size()));
+      RPT_TRY(upload_async(ctx, dlv.p, small_lv.data(), small_lv.size() * 4));
+      const unsigned SL = (unsigned)small_l.size();
+      hipLaunchKernelGGL(leaf_sort_kernel<TK>, dim3((unsigned)(((int64_t)SL * T + 3) / 4)),
+                         dim3(256), 0, st, F, N, P, L, T, dsegs3.p, (int)SL, dlv.p);
+    }
+    while (!mid_l.empty()) {  // buckets of 129..kSmallCap points: block-level LDS sort per level
+      const int lv = mid_l.back().second;
+      std::vector<Seg> grp;
+      for (auto it = mid_l.begin(); it != mid_l.end();)
+        if (it->second == lv) {
+          grp.push_back(it->first);
+          it = mid_l.erase(it);
+        } else {
+          ++it;
+        }
+      RPT_TRY(upload(grp, dsegs3));
+      int nm = 0;
+      for (const Seg& sgm : grp) nm = sgm.n > nm ? sgm.n : nm;
+      const size_t sm2 = (size_t)next_pow2(nm) * (sizeof(TK) + 4);
+      hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)grp.size(), T), dim3(256), sm2, st,
+                         F, F, N, P, L, lv - 1, dsegs3.p, (const int32_t*)nullptr, f->thr.p,
+                         f->mglo.p, f->mghi.p, f->nodes, tie_count);
+    }
+    RPT_HIP(hipGetLastError());
+    return RPT_OK;
+  };
 
   for (int level = 0; level < Lused; ++level) {
     for (int b = 0; b < 2; ++b) {
@@ -2611,114 +2768,52 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         Deferred& df = deferred.back();
         df.level = level;
         df.b = b;
-        RPT_TRY(df.ovf.alloc((size_t)S + 1));
-        RPT_HIP(hipMemsetAsync(df.ovf.p, 0, ((size_t)S + 1) * 4, st));
-        RPT_TRY(Kleaf.ensure((size_t)T * N));
+        RPT_TRY(df.flags.alloc(2 * ((size_t)S + 1)));
+        RPT_HIP(hipMemsetAsync(df.flags.p, 0, 2 * ((size_t)S + 1) * 4, st));
+        unsigned int* ovf_cnt = df.flags.p;
+        unsigned int* unord_cnt = df.flags.p + S + 1;
         hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
-                           st, cur, nxt, F, Kleaf.p, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
-                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, df.ovf.p + 1,
-                           df.ovf.p, (const unsigned int*)sflags.p, dbgbuf);
-        // leaves created by the wave kernel still need their order; nodes it left active stay
-        // pending
-        std::vector<Seg> wl_small, rest;
-        std::vector<int> wl_small_info;  // leaf level | (index of the wsub node << 6)
-        std::vector<std::pair<Seg, int>> wl_mid_lv;
-        std::function<void(const Seg&, int, int, int)> walk = [&](const Seg& sgm, int lv, int dp,
-                                                                  int top) {
-          if (is_leaf(lv, sgm.n, L, f->min_leaf)) {
-            if (sgm.n > 1) {
-              if (sgm.n <= 128) {
-                wl_small.push_back(Seg{sgm.off, sgm.n, -1});
-                wl_small_info.push_back(lv | (top << 6));
-              } else {
-                wl_mid_lv.push_back({Seg{sgm.off, sgm.n, -1}, lv});
-              }
-            }
-            return;
-          }
-          if (dp == kWRmax) {
-            rest.push_back(sgm);
-            return;
-          }
-          const int nh = sgm.n / 2;
-          walk(Seg{sgm.off, nh, 2 * sgm.heap + 1}, lv + 1, dp + 1, top);
-          walk(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, lv + 1, dp + 1, top);
-        };
-        for (size_t i = 0; i < wsmall.size(); ++i) walk(wsmall[i], level, 0, (int)i);
-        // The overflow flags are only needed on the host when something other than
-        // leaf_sort_kernel (which skips flagged nodes itself) consumes this launch's output;
-        // otherwise they are looked at once, at the end of the build.
-        const bool defer = rest.empty() && wl_mid_lv.empty() && S < (1u << 25);
-        std::vector<Seg> redo;
-        if (!defer) {
-          unsigned int novf = 0;
-          RPT_HIP(hipMemcpyAsync(&novf, df.ovf.p, 4, hipMemcpyDeviceToHost, st));
+                           st, cur, nxt, F, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
+                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, ovf_cnt + 1,
+                           ovf_cnt, unord_cnt + 1, unord_cnt, (const unsigned int*)sflags.p, dbgbuf);
+        // nodes the wave kernel left active (deeper than kWRmax levels) stay pending
+        std::vector<Seg> rest;
+        for (const Seg& sgm : wsmall) descend(sgm, level, 0, kWRmax, rest);
+        // The flags matter on the host only when something consumes this launch's active
+        // nodes; otherwise they are looked at once, at the end of the build.
+        const bool defer = rest.empty();
+        if (defer) {
+          df.nodes = wsmall;
+        } else {
+          unsigned int cnt[2] = {0, 0};
+          RPT_HIP(hipMemcpyAsync(&cnt[0], ovf_cnt, 4, hipMemcpyDeviceToHost, st));
+          RPT_HIP(hipMemcpyAsync(&cnt[1], unord_cnt, 4, hipMemcpyDeviceToHost, st));
           RPT_HIP(ctx_sync(ctx));
           bool aborted = false;
           RPT_TRY(stream_aborted(&aborted));
           if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
-          std::vector<unsigned int> fl((size_t)S, 0u);
-          if (novf) {  // pivot bin / leaf larger than a wave slab: block-level kernel for those
-            RPT_HIP(hipMemcpy(fl.data(), df.ovf.p + 1, (size_t)S * 4, hipMemcpyDeviceToHost));
-            for (unsigned i = 0; i < S; ++i)
-              if (fl[i]) redo.push_back(wsmall[i]);
-            auto drop = [&](const Seg& x) {  // inside a node that is run again
+          std::vector<Seg> redo, unordered;
+          if (cnt[0] || cnt[1]) {
+            std::vector<unsigned int> fl(2 * ((size_t)S + 1));
+            RPT_HIP(hipMemcpy(fl.data(), df.flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+            for (unsigned i = 0; i < S; ++i) {
+              if (fl[1 + i]) redo.push_back(wsmall[i]);
+              else if (fl[S + 2 + i]) unordered.push_back(wsmall[i]);
+            }
+          }
+          if (!redo.empty()) {  // run again by the block-level kernel: drop their descendants
+            auto drop = [&](const Seg& x) {
               for (const Seg& r : redo)
                 if (x.off >= r.off && x.off < r.off + r.n) return true;
               return false;
             };
             rest.erase(std::remove_if(rest.begin(), rest.end(), drop), rest.end());
-            wl_mid_lv.erase(std::remove_if(wl_mid_lv.begin(), wl_mid_lv.end(),
-                                           [&](const std::pair<Seg, int>& x) { return drop(x.first); }),
-                            wl_mid_lv.end());
+            for (const Seg& r : redo) bsmall.push_back(r);
           }
-          deferred.pop_back();  // settled here (leaf_sort_kernel below still reads the flags:
-                                // the buffer returns to the allocator, which keeps it intact
-                                // until the next synchronisation)
-        } else {
-          df.nodes = wsmall;
+          if (!unordered.empty()) RPT_TRY(sort_leaves_below(unordered, level));
+          deferred.pop_back();
+          for (const Seg& sgm : rest) pending[(size_t)level + kWRmax].push_back(PNode{sgm, 1 - b});
         }
-        const unsigned int* ovf_flags = defer ? df.ovf.p + 1 : nullptr;
-        DevBuf<unsigned int> settled;  // flags of a settled launch, kept for leaf_sort_kernel
-        if (!defer) {
-          RPT_TRY(settled.alloc((size_t)S));
-          std::vector<unsigned int> fl((size_t)S, 0u);
-          for (const Seg& r : redo)
-            for (unsigned i = 0; i < S; ++i)
-              if (wsmall[i].off == r.off) fl[i] = 1u;
-          RPT_TRY(upload_async(ctx, settled.p, fl.data(), (size_t)S * 4));
-          ovf_flags = settled.p;
-        }
-        for (const Seg& sgm : rest) pending[(size_t)level + kWRmax].push_back(PNode{sgm, 1 - b});
-        if (!wl_small.empty()) {
-          RPT_TRY(upload(wl_small, dsegs3));
-          RPT_TRY(dlv.ensure(wl_small_info.size()));
-          RPT_TRY(upload_async(ctx, dlv.p, wl_small_info.data(), wl_small_info.size() * 4));
-          const unsigned SL = (unsigned)wl_small.size();
-          hipLaunchKernelGGL(leaf_sort_kernel<TK>, dim3((unsigned)(((int64_t)SL * T + 3) / 4)),
-                             dim3(256), 0, st, F, Kleaf.p, N, P, L, T, dsegs3.p, (int)SL, dlv.p,
-                             ovf_flags, (const unsigned int*)sflags.p);
-        }
-        // buckets of 129..kSmallCap points: the block-level LDS sort, grouped by key level
-        while (!wl_mid_lv.empty()) {
-          const int lv = wl_mid_lv.back().second;
-          std::vector<Seg> grp;
-          for (auto it = wl_mid_lv.begin(); it != wl_mid_lv.end();)
-            if (it->second == lv) {
-              grp.push_back(it->first);
-              it = wl_mid_lv.erase(it);
-            } else {
-              ++it;
-            }
-          RPT_TRY(upload(grp, dsegs3));
-          int nm = 0;
-          for (const Seg& sgm : grp) nm = sgm.n > nm ? sgm.n : nm;
-          const size_t sm2 = (size_t)next_pow2(nm) * (sizeof(TK) + 4);
-          hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)grp.size(), T), dim3(256), sm2,
-                             st, F, F, N, P, L, lv - 1, dsegs3.p, (const int32_t*)nullptr,
-                             f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count);
-        }
-        for (const Seg& r : redo) bsmall.push_back(r);
       }
       if (!bsmall.empty()) {  // whole subtrees in LDS, kRmax levels per launch
         RPT_TRY(upload(bsmall, dsegs));
@@ -2841,45 +2936,56 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   // ---- the one synchronisation point of the common path ----
   {
     const size_t nd = deferred.size();
-    unsigned long long* hres = reinterpret_cast<unsigned long long*>(pin_alloc(ctx, (2 + nd) * 8));
+    unsigned long long* hres =
+        reinterpret_cast<unsigned long long*>(pin_alloc(ctx, (2 + 2 * nd) * 8));
     std::vector<unsigned long long> hfallback;
     if (!hres) {
-      hfallback.resize(2 + nd);
+      hfallback.resize(2 + 2 * nd);
       hres = hfallback.data();
     }
-    for (size_t i = 0; i < 2 + nd; ++i) hres[i] = 0;
+    for (size_t i = 0; i < 2 + 2 * nd; ++i) hres[i] = 0;
     RPT_HIP(hipMemcpyAsync(&hres[0], tie_count, 8, hipMemcpyDeviceToHost, st));
     RPT_HIP(hipMemcpyAsync(&hres[1], sflags.p, 4, hipMemcpyDeviceToHost, st));
     size_t k = 2;
-    for (Deferred& df : deferred)
-      RPT_HIP(hipMemcpyAsync(&hres[k++], df.ovf.p, 4, hipMemcpyDeviceToHost, st));
+    for (Deferred& df : deferred) {
+      const size_t S = df.nodes.size();
+      RPT_HIP(hipMemcpyAsync(&hres[k++], df.flags.p, 4, hipMemcpyDeviceToHost, st));
+      RPT_HIP(hipMemcpyAsync(&hres[k++], df.flags.p + S + 1, 4, hipMemcpyDeviceToHost, st));
+    }
     RPT_HIP(stream_sync(st));
     const unsigned long long ties0 = hres[0];
     const bool aborted = stream_unchecked && (unsigned int)hres[1] != 0;
-    std::vector<unsigned int> novf(nd);
-    for (size_t i = 0; i < nd; ++i) novf[i] = (unsigned int)hres[2 + i];
+    std::vector<unsigned int> cnts(2 * nd);
+    for (size_t i = 0; i < 2 * nd; ++i) cnts[i] = (unsigned int)hres[2 + i];
     ctx->pin_off = 0;
     if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
     f->tie_nodes = (int64_t)ties0;
     bool redone = false;
     k = 0;
     for (Deferred& df : deferred) {
-      if (novf[k++] == 0) continue;
-      // pivot bin / leaf larger than a wave slab: those nodes again with the block-level kernel
-      // (a deferred launch covers the rest of its subtrees: kRmax > kWRmax)
+      const unsigned int novf = cnts[k++], nunord = cnts[k++];
+      if (novf == 0 && nunord == 0) continue;
       const size_t S = df.nodes.size();
-      std::vector<unsigned int> fl(S);
-      RPT_HIP(hipMemcpy(fl.data(), df.ovf.p + 1, S * 4, hipMemcpyDeviceToHost));
-      std::vector<Seg> redo;
-      for (size_t i = 0; i < S; ++i)
-        if (fl[i]) redo.push_back(df.nodes[i]);
-      if (redo.empty()) continue;
+      std::vector<unsigned int> fl(2 * (S + 1));
+      RPT_HIP(hipMemcpy(fl.data(), df.flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<Seg> redo, unordered;
+      for (size_t i = 0; i < S; ++i) {
+        if (fl[1 + i]) redo.push_back(df.nodes[i]);
+        else if (fl[S + 2 + i]) unordered.push_back(df.nodes[i]);
+      }
       ProfScope ps(ctx, RPT_PROF_SPLIT);
-      RPT_TRY(upload(redo, dsegs));
-      hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)redo.size(), T), dim3(kSubThreads), 0,
-                         st, bufs[df.b], bufs[1 - df.b], F, N, P, L, df.level, f->min_leaf, dsegs.p,
-                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
-      RPT_HIP(hipGetLastError());
+      if (!redo.empty()) {
+        // pivot bins larger than a wave's pool: those nodes again with the block-level kernel
+        // (a deferred launch covers the rest of its subtrees: kRmax > kWRmax)
+        RPT_TRY(upload(redo, dsegs));
+        hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)redo.size(), T), dim3(kSubThreads), 0,
+                           st, bufs[df.b], bufs[1 - df.b], F, N, P, L, df.level, f->min_leaf,
+                           dsegs.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
+        RPT_HIP(hipGetLastError());
+      }
+      // equal key images / real ties inside a bin: the leaf buckets below get the exact sort
+      if (!unordered.empty()) RPT_TRY(sort_leaves_below(unordered, df.level));
+      f->unordered_nodes += (int64_t)unordered.size();
       redone = true;
     }
     if (redone) {

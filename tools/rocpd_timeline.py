@@ -19,11 +19,15 @@ def short(n):
 idx = [i for i, r in enumerate(rows) if "stream_minmax0" in r[0]]
 i0 = idx[which]
 j = i0
-while j > 0 and "leaf_sort" not in rows[j][0]:
+while j > 0 and "wsub_kernel" not in rows[j][0]:
     j -= 1
+while j + 1 < i0 and "leaf_sort" in rows[j + 1][0]:
+    j += 1
 s = j + 1
 e = i0
-while "leaf_sort" not in rows[e][0]:
+while "wsub_kernel" not in rows[e][0]:
+    e += 1
+while e + 1 < len(rows) and "leaf_sort" in rows[e + 1][0]:
     e += 1
 t0 = rows[s][1]
 prev = None
