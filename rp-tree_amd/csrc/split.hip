@@ -1579,7 +1579,11 @@ __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __res
                                                                  unsigned long long* cmax) {
   const int t = blockIdx.y;
   const TK* Pl = P + (int64_t)t * L * N;
-  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
+  const int64_t i0 = (int64_t)blockIdx.x * per;
+  int64_t i1 = i0 + per < N ? i0 + per : N;
+  // the range only shapes the root's bins (keys outside clamp to the edge bins): an eighth of
+  // every block's points is plenty when there are many
+  if (N >= 65536) i1 = i0 + ((i1 - i0 + 7) >> 3);
   unsigned long long mn = ~0ULL, mx = 0ULL;
   for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
     const unsigned long long o = ord_of(Pl[i]);
@@ -1630,6 +1634,9 @@ __device__ inline void stream_geom(unsigned long long mn, unsigned long long mx,
   }
 }
 
+// Uniform bins over the node's [min, max].  (Measured: folding 2B cells into B bins with a finer
+// centre halves the pivot bins of bell-shaped keys but the two-cluster C2 data puts medians into
+// the coarse tails — 0.40 -> 0.74 ms of stream_mid; any monotone map would keep the split exact.)
 template <class TK>
 __device__ inline int stream_bin(TK key, TK lo, TK scale, int B) {
   int b = (int)((key - lo) * scale);
