@@ -1837,7 +1837,7 @@ template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
     int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
-    unsigned long long* cmin_next, unsigned long long* cmax_next) {
+    TK* __restrict__ poolkey, unsigned long long* cmin_next, unsigned long long* cmax_next) {
   __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
   __shared__ __attribute__((aligned(8))) ABins nbin[kStreamMaxNodes];
   __shared__ int nmidoff[kStreamMaxNodes];
@@ -1859,6 +1859,8 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   const TK* Pn = has_next ? Pl + N : Pl;
   uint16_t* no = node_of + (int64_t)t * N;
   int32_t* pl = pool + (int64_t)t * N;
+  TK* pk = poolkey + (int64_t)t * N;  // the pivot-bin lists carry the key: stream_mid reads it
+                                      // coalesced instead of gathering it by id
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
   // The children's min/max of the NEXT level's key only shape that level's bins (keys outside
   // the range are clamped into the edge bins), so a sample is enough: the first quarter of the
@@ -1881,6 +1883,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     if (b == pb) {
       const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
       pl[nmidoff[j] + p] = (int32_t)i;
+      pk[nmidoff[j] + p] = key;
       return -1;
     }
     if (b == nb.lowb) atomicMax(&ndt[j].maxL, ord_of(key));
@@ -1975,6 +1978,7 @@ struct MidArgs {
   int L, level, M, has_next;
   const SNode<TK>* nd;
   const int32_t* pool;
+  const TK* poolkey;
   unsigned long long *cmin_next, *cmax_next;
   int64_t heap0, nodes;
   double *thr, *mglo, *mghi;
@@ -1988,6 +1992,7 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
   const int64_t N = A.N;
   Keys<TK> K{A.P + (int64_t)t * A.L * N, N, A.level, nullptr};
   const int32_t* m = A.pool + (int64_t)t * N + a.midoff;
+  const TK* mk = A.poolkey + (int64_t)t * N + a.midoff;
   // at most 128 points: two per lane (the 4-register instantiation of wave_bitonic proved
   // codegen-sensitive on ROCm 7.2 and is not used; larger bins take the block-level path)
   TK k[2];
@@ -1996,7 +2001,7 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
   for (int r = 0; r < 2; ++r) {
     const int i = r * 64 + lane;
     id[r] = i < cMid ? m[i] : kPad;
-    k[r] = i < cMid ? K.key(id[r]) : pos_inf<TK>();
+    k[r] = i < cMid ? mk[i] : pos_inf<TK>();
   }
   if (cMid <= 64) {
     TK k1[1] = {k[0]};
@@ -2012,6 +2017,9 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
   const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
   const int n = a.n, nh = a.nh;
+  // the children's range of the next level's key comes from stream_assign's sample; the
+  // pivot-bin points only add to it when they are a large part of the node (ties)
+  const bool feed_next = A.has_next && cMid * 4 >= n;
   const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
   TK vthr = (TK)0, vlo = (TK)0, vhi = (TK)0;
   int have = 0;
@@ -2021,7 +2029,7 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
     if (i < cMid) {
       const int side = i >= kk;
       no[id[r]] = (uint16_t)(2 * j + side);
-      if (A.has_next) {
+      if (feed_next) {
         const unsigned long long o = ord_of(Pn[id[r]]);
         mn[side] = o < mn[side] ? o : mn[side];
         mx[side] = o > mx[side] ? o : mx[side];
@@ -2040,7 +2048,7 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
       }
     }
   }
-  if (A.has_next) {
+  if (feed_next) {
     for (int sd = 0; sd < 2; ++sd) {
       unsigned long long x = mn[sd], y = mx[sd];
       for (int o = 32; o > 0; o >>= 1) {
@@ -2081,11 +2089,11 @@ __device__ inline void mid_lds_path(const MidArgs<TK>& A, const SNode<TK>& a, in
   int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
   Keys<TK> K{A.P + (int64_t)t * A.L * N, N, A.level, nullptr};
   const int32_t* m = A.pool + (int64_t)t * N + a.midoff;
+  const TK* mk = A.poolkey + (int64_t)t * N + a.midoff;
   for (int i = tid; i < np; i += nthr) {
     if (i < cMid) {
-      const int id = m[i];
-      sid[i] = id;
-      skey[i] = K.key(id);
+      sid[i] = m[i];
+      skey[i] = mk[i];
     } else {
       sid[i] = kPad;
       skey[i] = pos_inf<TK>();
@@ -2098,16 +2106,17 @@ __device__ inline void mid_lds_path(const MidArgs<TK>& A, const SNode<TK>& a, in
   uint16_t* no = A.node_of + (int64_t)t * N;
   const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
+  const bool feed_next = A.has_next && cMid * 4 >= a.n;  // see mid_wave_path
   for (int i = tid; i < cMid; i += nthr) {
     const int side = i >= kk;
     no[sid[i]] = (uint16_t)(2 * j + side);
-    if (A.has_next) {
+    if (feed_next) {
       const unsigned long long o = ord_of(Pn[sid[i]]);
       mn[side] = o < mn[side] ? o : mn[side];
       mx[side] = o > mx[side] ? o : mx[side];
     }
   }
-  if (A.has_next) {
+  if (feed_next) {
     for (int sd = 0; sd < 2; ++sd) {
       unsigned long long x = mn[sd], y = mx[sd];
       for (int o = 32; o > 0; o >>= 1) {
@@ -2555,6 +2564,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
                        cmax);
     HT("stream alloc+minmax0");
     int32_t* pool = bufB.p;  // the ping-pong buffers are idle while nothing moves
+    DevBuf<TK> poolkey;      // keys of the pivot-bin lists, same indexing as pool
+    RPT_TRY(poolkey.alloc((size_t)T * N));
     const int wave_max = getenv("RPT_NO_WMID") ? 0 : 128;
     {
       ProfScope ps(ctx, RPT_PROF_SPLIT);
@@ -2581,11 +2592,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         }
 #undef RPT_PICK
         hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, node_of.p, N,
-                           L, level, M, perA, has_next, snodes.p, pool, cminN, cmaxN);
+                           L, level, M, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
         const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
         const int npb = M >= 16 ? 4 : 1;
         MidArgs<TK> ma{P,     node_of.p, N,     L,        level,    M,
-                       has_next, snodes.p, pool, cminN, cmaxN, (int64_t)M - 1, f->nodes,
+                       has_next, snodes.p, pool, poolkey.p, cminN, cmaxN, (int64_t)M - 1, f->nodes,
                        f->thr.p, f->mglo.p, f->mghi.p, tie_count};
         hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)((M + npb - 1) / npb), (unsigned)T),
                            dim3(256), smem, st, ma, npb, wave_max);

@@ -8,7 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # rp-tree_amd/
-LIB_PATH = os.path.join(PKG_ROOT, "librptree_hip.so")
+# RPTREE_HIP_LIB: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RPTREE_HIP_LIB") or os.path.join(PKG_ROOT, "librptree_hip.so")
 
 RPT_F64, RPT_F32, RPT_BF16 = 0, 1, 2
 RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA = 0, 1, 2
