@@ -2175,26 +2175,32 @@ __global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, 
   }
 }
 
-// counting sort of the points by node -> perm segments.  A block ranks ALL its points
-// (< 65536) in one round, so every node receives one contiguous run per block (~per/M points:
-// a few hundred bytes) instead of 16-byte crumbs.  Does nothing once *abort is set (a pivot
-// bin outgrew LDS: the host rebuilds with the general path).  grid = (nblk, T)
+// counting sort of the points by node -> perm segments, staged through LDS: a block sorts
+// chunks of kPermChunk points by node in LDS and copies them out in sorted order, so a wave
+// writes a handful of contiguous runs instead of 64 scattered 4-byte stores (measured: the
+// direct scatter wrote 955 MB of HBM traffic for 128 MB of permutation).  Does nothing once
+// *abort is set (a pivot bin outgrew LDS: the host rebuilds with the general path).
+// grid = (nblk, T)
+constexpr int kPermChunk = 8192;
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
     const uint16_t* __restrict__ node_of, int64_t N, int levels, int64_t per,
     unsigned int* __restrict__ gcur, int32_t* __restrict__ perm,
     const unsigned int* __restrict__ abort) {
-  constexpr int EPT = 64;  // per <= 65535 = 64 * 1024 - 1
-  __shared__ unsigned int cnt[2 * kStreamMaxNodes], base[2 * kStreamMaxNodes];
-  __shared__ int64_t noff[2 * kStreamMaxNodes];
+  constexpr int EPT = kPermChunk / kStreamThreads;  // points per thread per chunk
+  __shared__ unsigned int cnt[2 * kStreamMaxNodes];  // counts, then the chunk-local prefixes
+  __shared__ int gb[2 * kStreamMaxNodes], noff[2 * kStreamMaxNodes];
+  __shared__ int sid[kPermChunk];
+  __shared__ unsigned short sj[kPermChunk];
+  __shared__ unsigned int wsum[kStreamThreads / 64];  // 72 KB in all: two blocks per CU
   if (*abort) return;
   const int t = blockIdx.y;
   const int M = 1 << levels;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint16_t* no = node_of + (int64_t)t * N;
   int32_t* pm = perm + (int64_t)t * N;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < N ? i0 + per : N;
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
-    cnt[j] = 0;
     int64_t off = 0, n = N;
     for (int b = levels - 1; b >= 0; --b) {
       const int64_t nh = n >> 1;
@@ -2205,30 +2211,57 @@ __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
         n = nh;
       }
     }
-    noff[j] = off;
+    noff[j] = (int)off;
   }
-  __syncthreads();
-  unsigned int pk[EPT];  // (node << 16) | rank inside this block
+  for (int64_t c0 = i0; c0 < i1; c0 += kPermChunk) {
+    const int cn = (int)(i1 - c0 < kPermChunk ? i1 - c0 : kPermChunk);
+    for (int j = threadIdx.x; j < M; j += kStreamThreads) cnt[j] = 0;
+    __syncthreads();
+    unsigned int pk[EPT];  // (node << 16) | rank inside this chunk
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int64_t i = i0 + e * kStreamThreads + threadIdx.x;
-    pk[e] = 0xffffffffu;
-    if (i < i1) {
-      const unsigned int j = no[i];
-      pk[e] = (j << 16) | atomicAdd(&cnt[j], 1u);
+    for (int e = 0; e < EPT; ++e) {
+      const int k = e * kStreamThreads + threadIdx.x;
+      pk[e] = 0xffffffffu;
+      if (k < cn) {
+        const unsigned int j = no[c0 + k];
+        pk[e] = (j << 16) | atomicAdd(&cnt[j], 1u);
+      }
     }
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < M; j += kStreamThreads)
-    base[j] = cnt[j] ? atomicAdd(&gcur[(int64_t)t * M + j], cnt[j]) : 0u;
-  __syncthreads();
+    __syncthreads();
+    // exclusive prefix of cnt over the nodes (M <= 2 * kStreamMaxNodes: two per thread)
+    unsigned int v0 = 0, v1 = 0;
+    const int j0 = 2 * threadIdx.x, j1 = j0 + 1;
+    if (j0 < M) v0 = cnt[j0];
+    if (j1 < M) v1 = cnt[j1];
+    unsigned int inc = v0 + v1;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int pre = inc - (v0 + v1);
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (j0 < M) {  // gb: where the chunk's first point of the node goes, minus its chunk slot
+      cnt[j0] = pre;
+      gb[j0] = v0 ? noff[j0] + (int)atomicAdd(&gcur[(int64_t)t * M + j0], v0) - (int)pre : 0;
+    }
+    if (j1 < M) {
+      cnt[j1] = pre + v0;
+      gb[j1] = v1 ? noff[j1] + (int)atomicAdd(&gcur[(int64_t)t * M + j1], v1) - (int)(pre + v0) : 0;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int64_t i = i0 + e * kStreamThreads + threadIdx.x;
-    if (pk[e] != 0xffffffffu) {
-      const unsigned int j = pk[e] >> 16;
-      pm[noff[j] + base[j] + (pk[e] & 0xffffu)] = (int32_t)i;
-    }
+    for (int e = 0; e < EPT; ++e)
+      if (pk[e] != 0xffffffffu) {
+        const unsigned int j = pk[e] >> 16, r = pk[e] & 0xffffu;
+        const int sl = (int)(cnt[j] + r);
+        sid[sl] = (int)(c0 + e * kStreamThreads + threadIdx.x);
+        sj[sl] = (unsigned short)j;
+      }
+    __syncthreads();
+    for (int k = threadIdx.x; k < cn; k += kStreamThreads) pm[gb[sj[k]] + k] = sid[k];
+    __syncthreads();
   }
 }
 
