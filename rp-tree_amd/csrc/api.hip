@@ -279,6 +279,10 @@ static void prof_resolve(rpt_ctx* ctx) {
         hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
       ctx->prof_ms[sp.which] += (double)ms;
       ctx->prof_n[sp.which] += 1;
+      if (sp.which == RPT_PROF_PROJECT_WIDE) {  // the wide launches are projection launches too
+        ctx->prof_ms[RPT_PROF_PROJECT] += (double)ms;
+        ctx->prof_n[RPT_PROF_PROJECT] += 1;
+      }
     }
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);

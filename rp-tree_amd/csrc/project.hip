@@ -745,8 +745,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
         const int c0 = b * WCOLS;
         const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
         const TC* Ab = ApadW.p + (size_t)b * 6 * (D / 4) * 64;
-        ProfScope ps(ctx, RPT_PROF_PROJECT);
-        ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
+        ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);  // resolved into class 0 as well
         if (ncol > 64) {
           RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, c0, ncol, Ab, P, ntiles, blocks)));
         } else {

@@ -2426,24 +2426,18 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   hipStream_t st = ctx->stream;
   f->mode = mode;
 
-  // ---- topology: split nodes and leaves per level ----
-  std::vector<Node> topo;
-  enumerate_topology(N, L, f->min_leaf, topo);
+  // deepest level that still splits a node: the largest node of level l has ceil(N / 2^l) points
   int Lused = 0;
-  for (const Node& nd : topo)
-    if (!nd.leaf && nd.level + 1 > Lused) Lused = nd.level + 1;
-  std::vector<std::vector<Seg>> splits((size_t)Lused), leaves((size_t)Lused + 1);
-  for (const Node& nd : topo) {
-    Seg s{nd.off, (int32_t)nd.n, nd.leaf ? -1 : (int32_t)nd.heap};
-    if (nd.leaf) leaves[(size_t)nd.level].push_back(s);
-    else splits[(size_t)nd.level].push_back(s);
+  {
+    int64_t n = N;
+    for (int l = 0; l < L; ++l) {
+      if (n > (int64_t)f->min_leaf) Lused = l + 1;
+      n -= n / 2;
+    }
   }
-  // DFS order is not offset order per level; both are fine (segments are disjoint)
-
-  if ((int64_t)T * f->nodes > 0)
+  if ((int64_t)T * f->nodes > 0) {
     hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, f->thr.p,
                        (int64_t)T * f->nodes, std::numeric_limits<double>::quiet_NaN());
-  if ((int64_t)T * f->nodes > 0) {
     hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, f->mglo.p,
                        (int64_t)T * f->nodes, std::numeric_limits<double>::quiet_NaN());
     hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, f->mghi.p,
@@ -2456,7 +2450,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     return RPT_OK;
   }
 
-  // ---- projection batch: all (tree, level) hyperplanes, X read ceil(T*L/32) times ----
+  // ---- projection batch: all (tree, level) hyperplanes; enqueued first, the host prepares the
+  // split while the device projects ----
   RPT_TRY(f->proj.alloc((size_t)T * L * N * sizeof(TK)));
   TK* P = reinterpret_cast<TK*>(f->proj.p);
   if (Lused == L) {
@@ -2466,6 +2461,17 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       RPT_TRY(project_columns(ctx, ds, f->R.p + (int64_t)t * L * f->d, Lused, mode,
                               P + (int64_t)t * L * N));
   }
+
+  // ---- topology: split nodes and leaves per level ----
+  std::vector<Node> topo;
+  enumerate_topology(N, L, f->min_leaf, topo);
+  std::vector<std::vector<Seg>> splits((size_t)Lused), leaves((size_t)Lused + 1);
+  for (const Node& nd : topo) {
+    Seg s{nd.off, (int32_t)nd.n, nd.leaf ? -1 : (int32_t)nd.heap};
+    if (nd.leaf) leaves[(size_t)nd.level].push_back(s);
+    else splits[(size_t)nd.level].push_back(s);
+  }
+  // DFS order is not offset order per level; both are fine (segments are disjoint)
 
   HT("projection");
   // ---- work buffers ----
