@@ -171,7 +171,7 @@ struct rpt_forest {
   rpt::DevBuf<double> thr, mglo, mghi;  // [T][nodes]
   rpt::DevBuf<char> proj;               // [T][L][N] in pdtype
   rpt::DevBuf<double> R;                // [T][L][d] hyperplanes (device copy)
-  int64_t tie_nodes = 0, big_mid_nodes = 0, unordered_nodes = 0;
+  int64_t tie_nodes = 0, big_mid_nodes = 0;
 };
 
 namespace rpt {

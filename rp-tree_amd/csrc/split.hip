@@ -764,7 +764,6 @@ struct WSlab {
   // of the key (bin << 20 | position inside the bin)
   unsigned int code[kWCap];
   int noff[16];  // offset of every node of the level inside the wave's segment
-  int nunord[16];  // node holds bin-mates with equal key images: its leaves stay unordered
 };
 
 template <class TK>
@@ -773,8 +772,7 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
     int64_t N, const TK* __restrict__ P, int L, int T, int level0, int min_leaf,
     const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
     int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
-    unsigned int* ovf_count, unsigned int* unord_flags, unsigned int* unord_count,
-    const unsigned int* __restrict__ abort, unsigned long long* dbg) {
+    unsigned int* ovf_count, const unsigned int* __restrict__ abort, unsigned long long* dbg) {
   __shared__ WSlab slabs[4];
   int dbgi = 0;
 #define WSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) dbg[dbgi++] = clock64(); } while (0)
@@ -804,7 +802,6 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
   }
   int depth = 0;
   bool overflow = false;
-  bool unord = false;  // some leaf could not be ordered from the key images alone
   WSTAMP();
   for (; depth < kWRmax; ++depth) {
     const int level = level0 + depth;
@@ -850,7 +847,6 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
       W.nmaxL[lane] = 0ULL;
       W.nminR[lane] = ~0ULL;
       W.midcur[lane] = 0;
-      W.nunord[lane] = 0;
     }
     wsync();
     WSTAMP();
@@ -960,12 +956,11 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
     }
     wsync();
     WSTAMP();
-    // ---- h. nodes whose children are leaves: position of every point inside its node, so that
-    // the leaf buckets leave this kernel in their final order.  Counting sort by bin (the
+    // ---- h. nodes whose children are leaves: exact position of every point inside its node, so
+    // that the leaf buckets leave this kernel in their final order.  Counting sort by bin (the
     // histogram now holds the bins' exclusive prefixes), then the few bin-mates are ordered by
-    // a 30-bit monotone image of the key kept in LDS.  Two mates with the SAME image (or real
-    // ties) cannot be ordered from it: the node is flagged and leaf_sort_kernel orders its
-    // leaves afterwards (rare).
+    // a 30-bit monotone image of the key kept in LDS; mates with the SAME image (about one pair
+    // per 10^5 points, and every real tie) compare their real keys, fetched by id.
     // (st of an active point from here on: node | bin << 8 | position << 18 | kWHasPos)
     bool any_leaf = false;
     for (int j = 0; j < M; ++j) {
@@ -993,6 +988,12 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
           }
         }
       wsync();
+      // the histogram has done its job: it now lists the ids in slot order (for the exact compare)
+#pragma unroll
+      for (int e = 0; e < kWE; ++e)
+        if (id[e] >= 0 && st[e] >= 0 && (st[e] & kWHasPos))
+          W.hist[(st[e] >> 18) & 0x3ff] = (unsigned int)id[e];
+      wsync();
 #pragma unroll
       for (int e = 0; e < kWE; ++e)
         if (id[e] >= 0 && st[e] >= 0 && (st[e] & kWHasPos)) {
@@ -1005,25 +1006,24 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
             const unsigned int w = W.code[qq];
             if ((w >> 20) != b) break;
             ++nleft;
-            less += w < mine_w;
-            if (w == mine_w) W.nunord[j] = 1;
+            if (w == mine_w) {
+              const int mate = (int)W.hist[qq];
+              less += K.less(K.key(mate), mate, key[e], id[e]);
+            } else {
+              less += w < mine_w;
+            }
           }
           for (int qq = gp + 1; qq < hi_j; ++qq) {
             const unsigned int w = W.code[qq];
             if ((w >> 20) != b) break;
-            less += w < mine_w;
-            if (w == mine_w) W.nunord[j] = 1;
+            if (w == mine_w) {
+              const int mate = (int)W.hist[qq];
+              less += K.less(K.key(mate), mate, key[e], id[e]);
+            } else {
+              less += w < mine_w;
+            }
           }
           st[e] = (st[e] & ~(0x3ff << 18)) | ((gp - lo_j - nleft + less) << 18);
-        }
-      wsync();
-      // a node with equal images keeps its points unordered (positions by arrival): both the
-      // image order and the exact pivot ranks would have to agree, and only real keys can tell
-#pragma unroll
-      for (int e = 0; e < kWE; ++e)
-        if (id[e] >= 0 && st[e] >= 0 && (st[e] & kWHasPos) && W.nunord[st[e] & 0xff]) {
-          st[e] &= ~(kWHasPos | (0x3ff << 18));
-          unord = true;
         }
     }
     // ---- f. pool the pivot bins; every other point descends right away.  The node records
@@ -1141,10 +1141,6 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
     }
     return;
   }
-  if (__any(unord) && lane == 0) {
-    unord_flags[si] = 1u;
-    atomicAdd(unord_count, 1u);
-  }
 
   WSTAMP();
   // ---- scatter every point to the slot range of its terminal node ----
@@ -1183,47 +1179,6 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
   }
   WSTAMP();
 #undef WSTAMP
-}
-
-// order one leaf bucket per wave by (key of the parent's level, earlier levels, id) — the exact
-// sort for the leaves wsub_kernel could not order from its key images (equal images, real ties).
-// The bucket (<= 128 points, two per lane) is sorted by a bitonic network over lane shuffles;
-// keys are gathered by id.  segs: leaf segments (identical for every tree); seg_level: the leaf's
-// level, key level = leaf level - 1.  grid = ceil(S*T/4) blocks of 256 threads.
-template <class TK>
-__global__ __launch_bounds__(256) void leaf_sort_kernel(int32_t* __restrict__ F, int64_t N,
-                                                        const TK* __restrict__ P, int L, int T,
-                                                        const Seg* __restrict__ segs, int S,
-                                                        const int* __restrict__ seg_level) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wg >= (int64_t)S * T) return;
-  const int si = (int)(wg % S), t = (int)(wg / S);
-  const Seg sg = segs[si];
-  const int tn = sg.n;
-  if (tn <= 1) return;
-  Keys<TK> K{P + (int64_t)t * L * N, N, seg_level[si] - 1, nullptr};
-  int32_t* f = F + (int64_t)t * N + sg.off;
-  const bool v0 = lane < tn, v1 = lane + 64 < tn;
-  int i0 = v0 ? f[lane] : kPad;
-  int i1 = v1 ? f[lane + 64] : kPad;
-  TK k0 = v0 ? K.key(i0) : pos_inf<TK>();
-  TK k1 = v1 ? K.key(i1) : pos_inf<TK>();
-  if (tn <= 64) {
-    TK ka[1] = {k0};
-    int ia[1] = {i0};
-    wave_bitonic<TK, 1>(ka, ia, K);
-    k0 = ka[0];
-    i0 = ia[0];
-  } else {
-    TK ka[2] = {k0, k1};
-    int ia[2] = {i0, i1};
-    wave_bitonic<TK, 2>(ka, ia, K);
-    i0 = ia[0];
-    i1 = ia[1];
-  }
-  if (v0) f[lane] = i0;
-  if (v1) f[lane + 64] = i1;
 }
 
 // copy segments src -> dst unchanged (leaves that are already in final order). grid=(S,T)
@@ -2492,8 +2447,6 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   DevBuf<unsigned long long> counters;  // [0] tie nodes, [1] (uint) big-mid count
   DevBuf<GSeg> dglist;
   DevBuf<unsigned int> ovf;
-  DevBuf<Seg> dsegs3;
-  DevBuf<int> dlv;
   RPT_TRY(counters.alloc(2));
   RPT_HIP(hipMemsetAsync(counters.p, 0, 16, st));
   bool have_big = false;
@@ -2744,65 +2697,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   struct Deferred {
     int level = 0, b = 0;
     std::vector<Seg> nodes;
-    // [0] overflow count, [1 + i] overflow flag of node i (pivot bins larger than the wave's
-    // pool: run again by subtree_kernel); [S + 1] count, [S + 2 + i] flag of nodes holding
-    // leaves the wave could not order from the key images (leaf sort pass afterwards)
+    // [0] count, [1 + i] flag of node i: pivot bins larger than the wave's pool (heavy ties):
+    // those nodes are run again by subtree_kernel
     DevBuf<unsigned int> flags;
   };
   std::list<Deferred> deferred;
-
-  // order the leaf buckets below the flagged nodes of one wsub_kernel launch (exact keys)
-  auto sort_leaves_below = [&](const std::vector<Seg>& tops, int level) -> int32_t {
-    std::vector<Seg> small_l;
-    std::vector<int> small_lv;
-    std::vector<std::pair<Seg, int>> mid_l;
-    std::function<void(const Seg&, int, int)> walk = [&](const Seg& sgm, int lv, int dp) {
-      if (is_leaf(lv, sgm.n, L, f->min_leaf)) {
-        if (sgm.n > 1) {
-          if (sgm.n <= 128) {
-            small_l.push_back(Seg{sgm.off, sgm.n, -1});
-            small_lv.push_back(lv);
-          } else {
-            mid_l.push_back({Seg{sgm.off, sgm.n, -1}, lv});
-          }
-        }
-        return;
-      }
-      if (dp == kWRmax) return;  // still a split node: stays pending
-      const int nh = sgm.n / 2;
-      walk(Seg{sgm.off, nh, 2 * sgm.heap + 1}, lv + 1, dp + 1);
-      walk(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, lv + 1, dp + 1);
-    };
-    for (const Seg& tp : tops) walk(tp, level, 0);
-    if (!small_l.empty()) {
-      RPT_TRY(upload(small_l, dsegs3));
-      RPT_TRY(dlv.ensure(small_lv.size()));
-      RPT_TRY(upload_async(ctx, dlv.p, small_lv.data(), small_lv.size() * 4));
-      const unsigned SL = (unsigned)small_l.size();
-      hipLaunchKernelGGL(leaf_sort_kernel<TK>, dim3((unsigned)(((int64_t)SL * T + 3) / 4)),
-                         dim3(256), 0, st, F, N, P, L, T, dsegs3.p, (int)SL, dlv.p);
-    }
-    while (!mid_l.empty()) {  // buckets of 129..kSmallCap points: block-level LDS sort per level
-      const int lv = mid_l.back().second;
-      std::vector<Seg> grp;
-      for (auto it = mid_l.begin(); it != mid_l.end();)
-        if (it->second == lv) {
-          grp.push_back(it->first);
-          it = mid_l.erase(it);
-        } else {
-          ++it;
-        }
-      RPT_TRY(upload(grp, dsegs3));
-      int nm = 0;
-      for (const Seg& sgm : grp) nm = sgm.n > nm ? sgm.n : nm;
-      const size_t sm2 = (size_t)next_pow2(nm) * (sizeof(TK) + 4);
-      hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)grp.size(), T), dim3(256), sm2, st,
-                         F, F, N, P, L, lv - 1, dsegs3.p, (const int32_t*)nullptr, f->thr.p,
-                         f->mglo.p, f->mghi.p, f->nodes, tie_count);
-    }
-    RPT_HIP(hipGetLastError());
-    return RPT_OK;
-  };
 
   for (int level = 0; level < Lused; ++level) {
     for (int b = 0; b < 2; ++b) {
@@ -2825,40 +2724,33 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         Deferred& df = deferred.back();
         df.level = level;
         df.b = b;
-        RPT_TRY(df.flags.alloc(2 * ((size_t)S + 1)));
-        RPT_HIP(hipMemsetAsync(df.flags.p, 0, 2 * ((size_t)S + 1) * 4, st));
-        unsigned int* ovf_cnt = df.flags.p;
-        unsigned int* unord_cnt = df.flags.p + S + 1;
+        RPT_TRY(df.flags.alloc((size_t)S + 1));
+        RPT_HIP(hipMemsetAsync(df.flags.p, 0, ((size_t)S + 1) * 4, st));
         hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
                            st, cur, nxt, F, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
-                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, ovf_cnt + 1,
-                           ovf_cnt, unord_cnt + 1, unord_cnt, (const unsigned int*)sflags.p, dbgbuf);
+                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, df.flags.p + 1,
+                           df.flags.p, (const unsigned int*)sflags.p, dbgbuf);
         // nodes the wave kernel left active (deeper than kWRmax levels) stay pending
         std::vector<Seg> rest;
         for (const Seg& sgm : wsmall) descend(sgm, level, 0, kWRmax, rest);
-        // The flags matter on the host only when something consumes this launch's active
-        // nodes; otherwise they are looked at once, at the end of the build.
+        // The overflow flags matter on the host only when something consumes this launch's
+        // active nodes; otherwise they are looked at once, at the end of the build.
         const bool defer = rest.empty();
         if (defer) {
           df.nodes = wsmall;
         } else {
-          unsigned int cnt[2] = {0, 0};
-          RPT_HIP(hipMemcpyAsync(&cnt[0], ovf_cnt, 4, hipMemcpyDeviceToHost, st));
-          RPT_HIP(hipMemcpyAsync(&cnt[1], unord_cnt, 4, hipMemcpyDeviceToHost, st));
+          unsigned int novf = 0;
+          RPT_HIP(hipMemcpyAsync(&novf, df.flags.p, 4, hipMemcpyDeviceToHost, st));
           RPT_HIP(ctx_sync(ctx));
           bool aborted = false;
           RPT_TRY(stream_aborted(&aborted));
           if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
-          std::vector<Seg> redo, unordered;
-          if (cnt[0] || cnt[1]) {
-            std::vector<unsigned int> fl(2 * ((size_t)S + 1));
+          if (novf) {  // run again by the block-level kernel: drop their descendants
+            std::vector<unsigned int> fl((size_t)S + 1);
             RPT_HIP(hipMemcpy(fl.data(), df.flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
-            for (unsigned i = 0; i < S; ++i) {
+            std::vector<Seg> redo;
+            for (unsigned i = 0; i < S; ++i)
               if (fl[1 + i]) redo.push_back(wsmall[i]);
-              else if (fl[S + 2 + i]) unordered.push_back(wsmall[i]);
-            }
-          }
-          if (!redo.empty()) {  // run again by the block-level kernel: drop their descendants
             auto drop = [&](const Seg& x) {
               for (const Seg& r : redo)
                 if (x.off >= r.off && x.off < r.off + r.n) return true;
@@ -2867,7 +2759,6 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
             rest.erase(std::remove_if(rest.begin(), rest.end(), drop), rest.end());
             for (const Seg& r : redo) bsmall.push_back(r);
           }
-          if (!unordered.empty()) RPT_TRY(sort_leaves_below(unordered, level));
           deferred.pop_back();
           for (const Seg& sgm : rest) pending[(size_t)level + kWRmax].push_back(PNode{sgm, 1 - b});
         }
@@ -2993,56 +2884,45 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   // ---- the one synchronisation point of the common path ----
   {
     const size_t nd = deferred.size();
-    unsigned long long* hres =
-        reinterpret_cast<unsigned long long*>(pin_alloc(ctx, (2 + 2 * nd) * 8));
+    unsigned long long* hres = reinterpret_cast<unsigned long long*>(pin_alloc(ctx, (2 + nd) * 8));
     std::vector<unsigned long long> hfallback;
     if (!hres) {
-      hfallback.resize(2 + 2 * nd);
+      hfallback.resize(2 + nd);
       hres = hfallback.data();
     }
-    for (size_t i = 0; i < 2 + 2 * nd; ++i) hres[i] = 0;
+    for (size_t i = 0; i < 2 + nd; ++i) hres[i] = 0;
     RPT_HIP(hipMemcpyAsync(&hres[0], tie_count, 8, hipMemcpyDeviceToHost, st));
     RPT_HIP(hipMemcpyAsync(&hres[1], sflags.p, 4, hipMemcpyDeviceToHost, st));
     size_t k = 2;
-    for (Deferred& df : deferred) {
-      const size_t S = df.nodes.size();
+    for (Deferred& df : deferred)
       RPT_HIP(hipMemcpyAsync(&hres[k++], df.flags.p, 4, hipMemcpyDeviceToHost, st));
-      RPT_HIP(hipMemcpyAsync(&hres[k++], df.flags.p + S + 1, 4, hipMemcpyDeviceToHost, st));
-    }
     RPT_HIP(stream_sync(st));
     const unsigned long long ties0 = hres[0];
     const bool aborted = stream_unchecked && (unsigned int)hres[1] != 0;
-    std::vector<unsigned int> cnts(2 * nd);
-    for (size_t i = 0; i < 2 * nd; ++i) cnts[i] = (unsigned int)hres[2 + i];
+    std::vector<unsigned int> novf(nd);
+    for (size_t i = 0; i < nd; ++i) novf[i] = (unsigned int)hres[2 + i];
     ctx->pin_off = 0;
     if (aborted) return build_forest_t<TK>(ctx, ds, f, mode, true);
     f->tie_nodes = (int64_t)ties0;
     bool redone = false;
     k = 0;
     for (Deferred& df : deferred) {
-      const unsigned int novf = cnts[k++], nunord = cnts[k++];
-      if (novf == 0 && nunord == 0) continue;
+      if (novf[k++] == 0) continue;
+      // pivot bins larger than a wave's pool: those nodes again with the block-level kernel
+      // (a deferred launch covers the rest of its subtrees: kRmax > kWRmax)
       const size_t S = df.nodes.size();
-      std::vector<unsigned int> fl(2 * (S + 1));
+      std::vector<unsigned int> fl(S + 1);
       RPT_HIP(hipMemcpy(fl.data(), df.flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
-      std::vector<Seg> redo, unordered;
-      for (size_t i = 0; i < S; ++i) {
+      std::vector<Seg> redo;
+      for (size_t i = 0; i < S; ++i)
         if (fl[1 + i]) redo.push_back(df.nodes[i]);
-        else if (fl[S + 2 + i]) unordered.push_back(df.nodes[i]);
-      }
+      if (redo.empty()) continue;
       ProfScope ps(ctx, RPT_PROF_SPLIT);
-      if (!redo.empty()) {
-        // pivot bins larger than a wave's pool: those nodes again with the block-level kernel
-        // (a deferred launch covers the rest of its subtrees: kRmax > kWRmax)
-        RPT_TRY(upload(redo, dsegs));
-        hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)redo.size(), T), dim3(kSubThreads), 0,
-                           st, bufs[df.b], bufs[1 - df.b], F, N, P, L, df.level, f->min_leaf,
-                           dsegs.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
-        RPT_HIP(hipGetLastError());
-      }
-      // equal key images / real ties inside a bin: the leaf buckets below get the exact sort
-      if (!unordered.empty()) RPT_TRY(sort_leaves_below(unordered, df.level));
-      f->unordered_nodes += (int64_t)unordered.size();
+      RPT_TRY(upload(redo, dsegs));
+      hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)redo.size(), T), dim3(kSubThreads), 0,
+                         st, bufs[df.b], bufs[1 - df.b], F, N, P, L, df.level, f->min_leaf, dsegs.p,
+                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
+      RPT_HIP(hipGetLastError());
       redone = true;
     }
     if (redone) {
