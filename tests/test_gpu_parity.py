@@ -479,3 +479,21 @@ def test_knnpq_collapses_equal_distances(rp, ctx, small_forest, oracle):
         assert np.all(np.diff(dist[i, :cnt[i]]) > 0)
     hits = rp.knnPQ(rp.metricL2, 5, f, Q[0])
     assert [i for _, i in hits] == oracle.knn_pq_dense(fo, X, Q[0], 5)[0].tolist()
+
+
+@pytest.mark.parametrize("n,min_leaf", [(60000, 1), (9000, 3), (2500, 1)])
+def test_deep_trees_down_to_single_points(rp, ctx, oracle, n, min_leaf):
+    """Trees split until the leaves hold one or two points: more levels below the streaming
+    phase than one wave-kernel launch covers (its still-active nodes go through a second
+    launch), leaves of every small size."""
+    d, T = 6, 2
+    X = oracle.data_normal_dense2(n, n, d)
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    R, _ = oracle.forest_hyperplanes(17, T, L, 1.0, d)
+    fo = oracle.forest_build_dense(X, R, min_leaf)
+    f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R)
+    assert_forest_equal(f, fo)
+    ids, dist, cnt = rp.knnBatch(3, f, X[:20])
+    for i in range(20):
+        wi, wd = oracle.knn_dense(fo, X, X[i], 3)
+        assert np.array_equal(ids[i, :cnt[i]], wi)
