@@ -384,7 +384,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_mfma(const TIn* __restrict__ 
 // ---------------------------------------------------------------------------------------
 template <class TC>
 __global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, int nblk, int cbt,
-                             int col0, TC* __restrict__ Apad /*[nblk][cbt][D/4][64]*/) {
+                             int col0, int k0, TC* __restrict__ Apad /*[nblk][cbt][D/4][64]*/) {
   const int steps = D / 4;
   const int64_t total = (int64_t)nblk * cbt * steps * 64;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -394,7 +394,7 @@ __global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, 
     const int h = (int)((i / (64 * (int64_t)steps)) % cbt);
     const int blk = (int)(i / (64 * (int64_t)steps * cbt));
     const int col = col0 + blk * 16 * cbt + h * 16 + (lane & 15);
-    const int k = 4 * s + (lane >> 4);
+    const int k = k0 + 4 * s + (lane >> 4);
     Apad[i] = (col < C && k < d) ? (TC)R[(int64_t)col * d + k] : (TC)0;
   }
 }
@@ -403,7 +403,9 @@ template <class TIn, class TC, int D, int CBT>
 __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0,
                                                          int ncol, TC* __restrict__ P,
-                                                         int64_t ldp, int64_t ntiles) {
+                                                         int64_t ldp, int64_t ntiles,
+                                                         int64_t ldx /* row stride of X */,
+                                                         int accumulate /* P += instead of = */) {
   constexpr int STEPS = D / 4;
   constexpr int PIECE = 16 / (int)sizeof(TIn);            // elements per 16-B piece
   constexpr int PIECES_PER_ROW = D / PIECE;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PIECES_PER_ROW;
       row = row < last_row ? row : last_row;
-      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + (p % PIECES_PER_ROW) * PIECE);
+      stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
     }
   };
   auto commit = [&]() {
@@ -458,16 +460,25 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
     commit();                                   // waits for the staged pieces, writes LDS
     const int64_t tn = t + wave_stride;
     if (tn < ntiles) issue(tn);                 // in flight during the MFMA phase
+    const int64_t row = t * 16 + m;             // D col = lane&15 = point
     acc_t acc[CBT];
 #pragma unroll
     for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
+    if (accumulate && row < n) {  // a later K chunk of rows longer than D: continue the sum
+#pragma unroll
+      for (int h = 0; h < CBT; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
+          if (col < ncol) acc[h][r] = P[(int64_t)(c0 + col) * ldp + row];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       const TC b = my[m * LDW + 4 * s + q];
 #pragma unroll
       for (int h = 0; h < CBT; ++h) acc[h] = Mfma<TC>::run(a[h][s], b, acc[h]);
     }
-    const int64_t row = t * 16 + m;             // D col = lane&15 = point
     if (row < n) {
 #pragma unroll
       for (int h = 0; h < CBT; ++h)
@@ -504,7 +515,9 @@ template <class TIn, class TC, int D, int CBT, int KS, int WPB>
 __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0,
                                                          int ncol, TC* __restrict__ P,
-                                                         int64_t ldp, int64_t ntiles) {
+                                                         int64_t ldp, int64_t ntiles,
+                                                         int64_t ldx /* row stride of X */,
+                                                         int accumulate /* P += instead of = */) {
   constexpr int STEPS = D / 4, SSTEPS = STEPS / KS, KW = D / KS;
   constexpr int PIECE = 16 / (int)sizeof(TIn);  // elements per 16-B piece
   constexpr int PPR = KW / PIECE;               // pieces per row slice
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PPR;
       row = row < last_row ? row : last_row;
-      stage[i] = *reinterpret_cast<const Raw*>(X + row * D + slice * KW + (p % PPR) * PIECE);
+      stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + slice * KW + (p % PPR) * PIECE);
     }
   };
   auto commit = [&](const Raw (&stage)[NP]) {
@@ -560,9 +573,19 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
   }
   while (t < ntiles) {
     const int64_t tn = t + wave_stride;
+    const int64_t row = t * 16 + m;  // D col = lane&15 = point
     acc_t acc[CBT];
 #pragma unroll
     for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
+    if (accumulate && row < n) {  // a later K chunk of rows longer than D: continue the sum
+#pragma unroll
+      for (int h = 0; h < CBT; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
+          if (col < ncol) acc[h][r] = P[(int64_t)(c0 + col) * ldp + row];
+        }
+    }
 #pragma unroll
     for (int sl = 0; sl < KS; ++sl) {
       // slice sl -> LDS, then request the slice two ahead into the stage just freed
@@ -583,7 +606,6 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
           acc[h] = Mfma<TC>::run(As[(h * STEPS + sl * SSTEPS + s) * 64 + lane], b, acc[h]);
       }
     }
-    const int64_t row = t * 16 + m;  // D col = lane&15 = point
     if (row < n) {
 #pragma unroll
       for (int h = 0; h < CBT; ++h)
@@ -692,10 +714,11 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
   }
 }
 
-// one wide pass over X for the CBT*16 hyperplanes padded into fragment order at Ab
+// one wide pass over a 128-element K chunk of X (columns [k0, k0 + D) of every row) for the
+// CBT*16 hyperplanes padded into fragment order at Ab
 template <class TIn, class TC, int D, int CBT, int KS>
-int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int c0, int ncol, const TC* Ab, TC* P,
-                    int64_t ntiles, int64_t blocks) {
+int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int accumulate, int c0, int ncol,
+                    const TC* Ab, TC* P, int64_t ntiles, int64_t blocks) {
   constexpr int WPB = 8;
   constexpr size_t smem = wide_smem_bytes<TC, D, CBT, KS, WPB>();
   static bool attr_done = false;
@@ -706,8 +729,8 @@ int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int c0, int ncol, const
     attr_done = true;
   }
   hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB>), dim3((unsigned)blocks),
-                     dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X, ds->n, Ab, c0, ncol, P,
-                     ds->n, ntiles);
+                     dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X + k0, ds->n, Ab, c0, ncol,
+                     P, ds->n, ntiles, (int64_t)ds->d, accumulate);
   return RPT_OK;
 }
 
@@ -716,8 +739,12 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                     TC* P) {
   const int64_t n = ds->n;
   const int64_t ntiles = (n + 15) / 16;
-  if (ds->d == 128) {  // guard-free pipelined paths
+  if (ds->d % 128 == 0 && ds->d >= 128) {  // guard-free pipelined paths
     constexpr int D = 128;
+    // Rows longer than 128 elements are projected one 128-element K chunk at a time: every
+    // chunk is a pass of the same kernels over columns [k0, k0 + 128) of X (row stride d), the
+    // chunks after the first continue the sums in P.
+    const int nkc = ds->d / D;
     // wide passes: up to 96 hyperplanes per read of X (CBT 6); a pass that has at most 64 left
     // uses the CBT 4 shape (the matrix pipe pays for padded columns too)
     constexpr int WCOLS = 96;
@@ -731,47 +758,56 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
     const int cw = nwide * WCOLS < C ? nwide * WCOLS : C;  // columns done by wide passes
     const int nblk = (C - cw + 31) / 32;
     DevBuf<TC> ApadW, Apad;
-    if (nwide) {
-      RPT_TRY(ApadW.alloc((size_t)nwide * 6 * (D / 4) * 64));
-      int64_t blocks = (ntiles + 7) / 8;
-      if (blocks > ctx->n_cu) blocks = ctx->n_cu;
-      for (int b = 0; b < nwide; ++b) {  // fragment-order copies of the hyperplanes
-        const int c0 = b * WCOLS;
-        const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
-        hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(16), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
-                           D, 1, ncol > 64 ? 6 : 4, c0, ApadW.p + (size_t)b * 6 * (D / 4) * 64);
-      }
+    const size_t wfrag = (size_t)6 * (D / 4) * 64, nfrag = (size_t)2 * (D / 4) * 64;
+    if (nwide) RPT_TRY(ApadW.alloc((size_t)nwide * nkc * wfrag));
+    if (nblk) RPT_TRY(Apad.alloc((size_t)nblk * nkc * nfrag));
+    // fragment-order copies of the hyperplanes, one per (column pass, K chunk)
+    for (int kc = 0; kc < nkc; ++kc) {
       for (int b = 0; b < nwide; ++b) {
         const int c0 = b * WCOLS;
         const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
-        const TC* Ab = ApadW.p + (size_t)b * 6 * (D / 4) * 64;
-        ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);  // resolved into class 0 as well
-        if (ncol > 64) {
-          RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, c0, ncol, Ab, P, ntiles, blocks)));
-        } else {
-          RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, c0, ncol, Ab, P, ntiles, blocks)));
-        }
+        hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(16), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
+                           D, 1, ncol > 64 ? 6 : 4, c0, kc * D,
+                           ApadW.p + ((size_t)kc * nwide + b) * wfrag);
       }
+      if (nblk)
+        hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
+                           D, nblk, 2, cw, kc * D, Apad.p + (size_t)kc * nblk * nfrag);
     }
-    if (nblk) {
-      RPT_TRY(Apad.alloc((size_t)nblk * 2 * (D / 4) * 64));
-      hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D,
-                         nblk, 2, cw, Apad.p);
-    }
+    int64_t wblocks = (ntiles + 7) / 8;
+    if (wblocks > ctx->n_cu) wblocks = ctx->n_cu;
     int64_t blocks = (ntiles + 3) / 4;
     const int64_t cap = (int64_t)ctx->n_cu * 2;
     if (blocks > cap) blocks = cap;
-    for (int b = 0; b < nblk; ++b) {
-      const int c0 = cw + b * 32;
-      const int ncol = C - c0 < 32 ? C - c0 : 32;
-      const TC* Ab = Apad.p + (size_t)b * 2 * (D / 4) * 64;
-      ProfScope ps(ctx, RPT_PROF_PROJECT);
-      if (ncol > 16)
-        hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
-                           ctx->stream, (const TIn*)ds->X, n, Ab, c0, ncol, P, n, ntiles);
-      else
-        hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
-                           ctx->stream, (const TIn*)ds->X, n, Ab, c0, ncol, P, n, ntiles);
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int k0 = kc * D, accumulate = kc > 0;
+      for (int b = 0; b < nwide; ++b) {
+        const int c0 = b * WCOLS;
+        const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
+        const TC* Ab = ApadW.p + ((size_t)kc * nwide + b) * wfrag;
+        ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);  // resolved into class 0 as well
+        if (ncol > 64) {
+          RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, k0, accumulate, c0, ncol, Ab, P, ntiles,
+                                                 wblocks)));
+        } else {
+          RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, k0, accumulate, c0, ncol, Ab, P, ntiles,
+                                                 wblocks)));
+        }
+      }
+      for (int b = 0; b < nblk; ++b) {
+        const int c0 = cw + b * 32;
+        const int ncol = C - c0 < 32 ? C - c0 : 32;
+        const TC* Ab = Apad.p + ((size_t)kc * nblk + b) * nfrag;
+        ProfScope ps(ctx, RPT_PROF_PROJECT);
+        if (ncol > 16)
+          hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
+                             ctx->stream, (const TIn*)ds->X + k0, n, Ab, c0, ncol, P, n, ntiles,
+                             (int64_t)ds->d, accumulate);
+        else
+          hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
+                             ctx->stream, (const TIn*)ds->X + k0, n, Ab, c0, ncol, P, n, ntiles,
+                             (int64_t)ds->d, accumulate);
+      }
     }
     RPT_HIP(hipGetLastError());
     return RPT_OK;  // the pad buffers return to the allocator, which recycles them only after

@@ -61,7 +61,9 @@ def test_project_exact_matches_oracle_inner_sd(rp, ctx, oracle):
 # d = 128 with more than 32 hyperplanes: the wide (96 / 64 columns per pass) kernels and their tails
 @pytest.mark.parametrize("n,d,C", [(1000, 16, 3), (5000, 128, 32), (777, 37, 33), (4099, 200, 17),
                                    (3001, 128, 33), (2100, 128, 64), (1999, 128, 100),
-                                   (1500, 128, 230)])
+                                   (1500, 128, 230),
+                                   # rows of k * 128 elements: one pass per 128-element K chunk
+                                   (2000, 256, 100), (1500, 384, 40), (900, 512, 20)])
 def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
     rng = np.random.default_rng(n * 3 + d)
     X = rng.standard_normal((n, d)).astype(dtype)
