@@ -405,7 +405,9 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
                                                          int ncol, TC* __restrict__ P,
                                                          int64_t ldp, int64_t ntiles,
                                                          int64_t ldx /* row stride of X */,
-                                                         int accumulate /* P += instead of = */) {
+                                                         int accumulate /* P += instead of = */,
+                                                         int kvalid /* elements of the K chunk that
+                                                                       exist (the rest reads as 0) */) {
   constexpr int STEPS = D / 4;
   constexpr int PIECE = 16 / (int)sizeof(TIn);            // elements per 16-B piece
   constexpr int PIECES_PER_ROW = D / PIECE;
@@ -438,7 +440,10 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PIECES_PER_ROW;
       row = row < last_row ? row : last_row;
-      stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
+      if ((p % PIECES_PER_ROW) * PIECE < kvalid)
+        stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
+      else
+        stage[i] = Raw{};  // past the end of a short row: kvalid is a multiple of PIECE
     }
   };
   auto commit = [&]() {
@@ -517,7 +522,9 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
                                                          int ncol, TC* __restrict__ P,
                                                          int64_t ldp, int64_t ntiles,
                                                          int64_t ldx /* row stride of X */,
-                                                         int accumulate /* P += instead of = */) {
+                                                         int accumulate /* P += instead of = */,
+                                                         int kvalid /* elements of the K chunk that
+                                                                       exist (the rest reads as 0) */) {
   constexpr int STEPS = D / 4, SSTEPS = STEPS / KS, KW = D / KS;
   constexpr int PIECE = 16 / (int)sizeof(TIn);  // elements per 16-B piece
   constexpr int PPR = KW / PIECE;               // pieces per row slice
@@ -550,7 +557,10 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PPR;
       row = row < last_row ? row : last_row;
-      stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + slice * KW + (p % PPR) * PIECE);
+      if (slice * KW + (p % PPR) * PIECE < kvalid)
+        stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + slice * KW + (p % PPR) * PIECE);
+      else
+        stage[i] = Raw{};  // past the end of a short row: kvalid is a multiple of PIECE
     }
   };
   auto commit = [&](const Raw (&stage)[NP]) {
@@ -598,12 +608,14 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
         if (sl % 2 == 0) issue(stg0, tn, sl + 2 - KS);
         else issue(stg1, tn, sl + 2 - KS);
       }
+      if (sl * KW < kvalid) {  // a slice beyond a short row holds zeros only
 #pragma unroll
-      for (int s = 0; s < SSTEPS; ++s) {
-        const TC b = my[m * LDW + 4 * s + q];
+        for (int s = 0; s < SSTEPS; ++s) {
+          const TC b = my[m * LDW + 4 * s + q];
 #pragma unroll
-        for (int h = 0; h < CBT; ++h)
-          acc[h] = Mfma<TC>::run(As[(h * STEPS + sl * SSTEPS + s) * 64 + lane], b, acc[h]);
+          for (int h = 0; h < CBT; ++h)
+            acc[h] = Mfma<TC>::run(As[(h * STEPS + sl * SSTEPS + s) * 64 + lane], b, acc[h]);
+        }
       }
     }
     if (row < n) {
@@ -717,8 +729,8 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
 // one wide pass over a 128-element K chunk of X (columns [k0, k0 + D) of every row) for the
 // CBT*16 hyperplanes padded into fragment order at Ab
 template <class TIn, class TC, int D, int CBT, int KS>
-int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int accumulate, int c0, int ncol,
-                    const TC* Ab, TC* P, int64_t ntiles, int64_t blocks) {
+int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int kvalid, int accumulate, int c0,
+                    int ncol, const TC* Ab, TC* P, int64_t ntiles, int64_t blocks) {
   constexpr int WPB = 8;
   constexpr size_t smem = wide_smem_bytes<TC, D, CBT, KS, WPB>();
   static bool attr_done = false;
@@ -730,7 +742,7 @@ int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int accumulate,
   }
   hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB>), dim3((unsigned)blocks),
                      dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X + k0, ds->n, Ab, c0, ncol,
-                     P, ds->n, ntiles, (int64_t)ds->d, accumulate);
+                     P, ds->n, ntiles, (int64_t)ds->d, accumulate, kvalid);
   return RPT_OK;
 }
 
@@ -739,12 +751,14 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                     TC* P) {
   const int64_t n = ds->n;
   const int64_t ntiles = (n + 15) / 16;
-  if (ds->d % 128 == 0 && ds->d >= 128) {  // guard-free pipelined paths
+  constexpr int kPiece = 16 / (int)sizeof(TIn);
+  if (ds->d % kPiece == 0) {  // rows are 16-byte aligned: the pipelined kernels
     constexpr int D = 128;
-    // Rows longer than 128 elements are projected one 128-element K chunk at a time: every
-    // chunk is a pass of the same kernels over columns [k0, k0 + 128) of X (row stride d), the
-    // chunks after the first continue the sums in P.
-    const int nkc = ds->d / D;
+    // Rows are projected one 128-element K chunk at a time: every chunk is a pass of the same
+    // kernels over columns [k0, k0 + 128) of X (row stride d), the chunks after the first
+    // continue the sums in P; a last chunk shorter than 128 reads as zero past the row's end
+    // (and the wide kernel skips its empty K slices).
+    const int nkc = (ds->d + D - 1) / D;
     // wide passes: up to 96 hyperplanes per read of X (CBT 6); a pass that has at most 64 left
     // uses the CBT 4 shape (the matrix pipe pays for padded columns too)
     constexpr int WCOLS = 96;
@@ -781,17 +795,18 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
     if (blocks > cap) blocks = cap;
     for (int kc = 0; kc < nkc; ++kc) {
       const int k0 = kc * D, accumulate = kc > 0;
+      const int kvalid = ds->d - k0 < D ? ds->d - k0 : D;
       for (int b = 0; b < nwide; ++b) {
         const int c0 = b * WCOLS;
         const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
         const TC* Ab = ApadW.p + ((size_t)kc * nwide + b) * wfrag;
         ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);  // resolved into class 0 as well
         if (ncol > 64) {
-          RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, k0, accumulate, c0, ncol, Ab, P, ntiles,
-                                                 wblocks)));
+          RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, k0, kvalid, accumulate, c0, ncol, Ab, P,
+                                                 ntiles, wblocks)));
         } else {
-          RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, k0, accumulate, c0, ncol, Ab, P, ntiles,
-                                                 wblocks)));
+          RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, k0, kvalid, accumulate, c0, ncol, Ab, P,
+                                                 ntiles, wblocks)));
         }
       }
       for (int b = 0; b < nblk; ++b) {
@@ -802,11 +817,11 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
         if (ncol > 16)
           hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
                              ctx->stream, (const TIn*)ds->X + k0, n, Ab, c0, ncol, P, n, ntiles,
-                             (int64_t)ds->d, accumulate);
+                             (int64_t)ds->d, accumulate, kvalid);
         else
           hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
                              ctx->stream, (const TIn*)ds->X + k0, n, Ab, c0, ncol, P, n, ntiles,
-                             (int64_t)ds->d, accumulate);
+                             (int64_t)ds->d, accumulate, kvalid);
       }
     }
     RPT_HIP(hipGetLastError());

@@ -63,7 +63,9 @@ def test_project_exact_matches_oracle_inner_sd(rp, ctx, oracle):
                                    (3001, 128, 33), (2100, 128, 64), (1999, 128, 100),
                                    (1500, 128, 230),
                                    # rows of k * 128 elements: one pass per 128-element K chunk
-                                   (2000, 256, 100), (1500, 384, 40), (900, 512, 20)])
+                                   (2000, 256, 100), (1500, 384, 40), (900, 512, 20),
+                                   # 16-byte aligned rows of any length: short last chunk
+                                   (3000, 64, 70), (1200, 784, 50), (2222, 100, 33)])
 def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
     rng = np.random.default_rng(n * 3 + d)
     X = rng.standard_normal((n, d)).astype(dtype)
