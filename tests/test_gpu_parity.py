@@ -501,3 +501,16 @@ def test_deep_trees_down_to_single_points(rp, ctx, oracle, n, min_leaf):
     for i in range(20):
         wi, wd = oracle.knn_dense(fo, X, X[i], 3)
         assert np.array_equal(ids[i, :cnt[i]], wi)
+
+
+def test_random_shapes_short_sweep(rp, ctx):
+    """15 seconds of tools/fuzz_parity.py: random (points, dimension, trees, minLeaf, depth, data
+    kind) forests, device vs oracle, bit for bit."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                        "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(15.0, 20261003, ctx=ctx, verbose=False) > 20
