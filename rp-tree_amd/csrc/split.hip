@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kSubThreads) void subtree_kernel(
     const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
     int64_t N, const TK* __restrict__ P, int L, int level0, int min_leaf,
     const Seg* __restrict__ segs, double* thr, double* mglo, double* mghi, int64_t nodes,
-    unsigned long long* tie_count, unsigned long long* dbg) {
+    unsigned long long* tie_count, unsigned long long* dbg, int rmax /* levels to run, <= kRmax */) {
   __shared__ __attribute__((aligned(16))) TK skey[kSmallCap];
   __shared__ int sid[kSmallCap];
   __shared__ unsigned int sx[kSmallCap];          // histogram during the levels, path at the end
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kSubThreads) void subtree_kernel(
   }
 
   int depth = 0;
-  for (; depth < kRmax; ++depth) {
+  for (; depth < rmax; ++depth) {
     const int level = level0 + depth;
     if (level >= L) break;
     // any element still active?
@@ -1521,9 +1521,13 @@ struct SNode {  // per (tree, node) of the current streaming level
   unsigned long long maxL, minR;
 };
 
-__host__ __device__ inline int stream_bins(int M) {
+// value bins per node of a streaming level: the 32768 LDS counters are split over the M nodes.
+// Nodes of up to ~2M points keep at most 4096 bins (one stream_pick block scans them); larger
+// nodes take every bin they can get, or a pivot bin would outgrow the LDS sort (kSmallCap)
+// and force the whole build onto the general path.
+inline int stream_bins(int M, int64_t node_points, int64_t big_node) {
   const int b = kStreamBins / M;
-  return b > 4096 ? 4096 : b;
+  return (b > 4096 && node_points <= big_node) ? 4096 : b;
 }
 
 // min / max of one level's keys over the whole tree (root geometry). grid = (nblk, T)
@@ -1572,8 +1576,8 @@ template <class TK>
 struct AGeom {  // per node, one 16-byte LDS read
   TK lo, sc;
 };
-struct ABins {  // per node, one 8-byte LDS read (bins <= 4096: -2 .. 4097 fit 16 bits)
-  short pb, lowb, highb, pad;
+struct ABins {  // per node, one 16-byte LDS read
+  int pb, lowb, highb, pad;
 };
 
 // bin geometry of one node from the min / max of its keys (hist and pick must agree bit for bit)
@@ -1605,12 +1609,11 @@ __device__ inline int stream_bin(TK key, TK lo, TK scale, int B) {
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_hist(
     const TK* __restrict__ P, const uint16_t* __restrict__ node_of, int64_t N, int L, int level,
-    int M, int64_t per, const unsigned long long* __restrict__ cmin,
+    int M, int B, int64_t per, const unsigned long long* __restrict__ cmin,
     const unsigned long long* __restrict__ cmax, unsigned int* __restrict__ part) {
   __shared__ unsigned int hist[kStreamBins / 2];  // two 16-bit counters per word
   __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
   const int t = blockIdx.y;
-  const int B = stream_bins(M);
   for (int i = threadIdx.x; i < (M * B) / 2; i += kStreamThreads) hist[i] = 0;
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
     AGeom<TK> g;
@@ -1788,21 +1791,145 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
   }
 }
 
+// ---- stream_pick for nodes with more than 4096 bins (the first levels of very large point
+// sets): the partials are summed into totals[t][M * B] first, then one block per (tree, node)
+// scans them, every thread owning B / 256 consecutive bins.
+__global__ __launch_bounds__(256) void stream_pick_sum(int MB2 /* M * B / 2 */, int nblk,
+                                                       const unsigned int* __restrict__ part,
+                                                       unsigned int* __restrict__ totals) {
+  const int i = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  if (i >= MB2) return;
+  const unsigned int* p = part + (int64_t)t * nblk * (kStreamBins / 2) + i;
+  unsigned int lo = 0, hi = 0;
+#pragma unroll 4
+  for (int b = 0; b < nblk; ++b) {
+    const unsigned int w = p[(int64_t)b * (kStreamBins / 2)];
+    lo += w & 0xffffu;
+    hi += w >> 16;
+  }
+  totals[(int64_t)t * kStreamBins + 2 * i] = lo;
+  totals[(int64_t)t * kStreamBins + 2 * i + 1] = hi;
+}
+
+template <class TK>
+__global__ __launch_bounds__(256) void stream_pick_big(int64_t N, int level, int M, int B,
+                                                       const unsigned int* __restrict__ totals,
+                                                       const unsigned long long* __restrict__ cmin,
+                                                       const unsigned long long* __restrict__ cmax,
+                                                       SNode<TK>* __restrict__ nd,
+                                                       unsigned int* __restrict__ poolcur,
+                                                       unsigned long long* __restrict__ cmin_next,
+                                                       unsigned long long* __restrict__ cmax_next,
+                                                       unsigned int* __restrict__ bigmid) {
+  __shared__ unsigned int wtot[4];
+  __shared__ int s_owner, s_pb, s_cL, s_cMid, s_low, s_high;
+  const int j = blockIdx.x, t = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int bpt = B / 256;  // 32 .. 128 consecutive bins per thread
+  const unsigned int* h = totals + (int64_t)t * kStreamBins + (int64_t)j * B;
+  int64_t n = N;
+  for (int b = level - 1; b >= 0; --b) {
+    const int64_t hh = n >> 1;
+    n = ((j >> b) & 1) ? n - hh : hh;
+  }
+  const unsigned int nh = (unsigned int)(n >> 1);
+  unsigned int tot = 0;
+  int firstne = B, lastne = -1;  // non-empty bins of this thread's range
+  for (int q = 0; q < bpt; ++q) {
+    const unsigned int c = h[threadIdx.x * bpt + q];
+    tot += c;
+    if (c) {
+      if (firstne == B) firstne = threadIdx.x * bpt + q;
+      lastne = threadIdx.x * bpt + q;
+    }
+  }
+  unsigned int inc = tot;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (threadIdx.x == 0) {
+    s_owner = -1;
+    s_pb = -1;
+    s_cL = 0;
+    s_cMid = 0;
+    s_low = -1;
+    s_high = B;
+  }
+  if (lane == 63) wtot[wv] = inc;
+  __syncthreads();
+  unsigned int run = inc - tot;
+  for (int w = 0; w < wv; ++w) run += wtot[w];
+  if (run <= nh && nh < run + tot) {  // exactly one thread
+    unsigned int a = run;
+    for (int q = 0; q < bpt; ++q) {
+      const unsigned int c = h[threadIdx.x * bpt + q];
+      if (a <= nh && nh < a + c) {
+        s_pb = threadIdx.x * bpt + q;
+        s_cL = (int)a;
+        s_cMid = (int)c;
+      }
+      a += c;
+    }
+    s_owner = (int)threadIdx.x;
+  }
+  __syncthreads();
+  const int pb = s_pb, cL = s_cL, cMid = s_cMid, owner = s_owner;
+  const int il = nh > 0 ? (int)nh - 1 : 0, ih = (int)nh + 1 < (int)n ? (int)nh + 1 : (int)n - 1;
+  const bool need_lo = il < cL, need_hi = ih >= cL + cMid;
+  if (owner >= 0 && (need_lo || need_hi)) {
+    if ((int)threadIdx.x < owner && lastne >= 0) atomicMax(&s_low, lastne);
+    if ((int)threadIdx.x > owner && firstne < B) atomicMin(&s_high, firstne);
+    if ((int)threadIdx.x == owner) {
+      int lowb = -1, highb = B;
+      for (int q = 0; q < bpt; ++q) {
+        const int b = threadIdx.x * bpt + q;
+        if (h[b]) {
+          if (b < pb) lowb = b;
+          if (b > pb && highb == B) highb = b;
+        }
+      }
+      if (lowb >= 0) atomicMax(&s_low, lowb);
+      if (highb < B) atomicMin(&s_high, highb);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    SNode<TK> a;
+    stream_geom<TK>(cmin[(int64_t)t * M + j], cmax[(int64_t)t * M + j], B, a.lo, a.scale);
+    a.n = (int)n;
+    a.nh = (int)nh;
+    a.pb = pb;
+    a.cL = cL;
+    a.cMid = cMid;
+    a.lowb = need_lo ? s_low : -2;
+    a.highb = need_hi ? s_high : B + 1;
+    a.midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
+    a.midcur = 0;
+    a.maxL = 0ULL;
+    a.minR = ~0ULL;
+    nd[(int64_t)t * M + j] = a;
+    cmin_next[(int64_t)t * 2 * M + 2 * j] = ~0ULL;
+    cmin_next[(int64_t)t * 2 * M + 2 * j + 1] = ~0ULL;
+    cmax_next[(int64_t)t * 2 * M + 2 * j] = 0ULL;
+    cmax_next[(int64_t)t * 2 * M + 2 * j + 1] = 0ULL;
+    if (cMid > kSmallCap) atomicAdd(bigmid, 1u);
+  }
+}
+
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
-    int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
+    int B, int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
     TK* __restrict__ poolkey, unsigned long long* cmin_next, unsigned long long* cmax_next) {
   __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
-  __shared__ __attribute__((aligned(8))) ABins nbin[kStreamMaxNodes];
+  __shared__ __attribute__((aligned(16))) ABins nbin[kStreamMaxNodes];
   __shared__ int nmidoff[kStreamMaxNodes];
   __shared__ unsigned long long smin[2 * kStreamMaxNodes], smax[2 * kStreamMaxNodes];
   const int t = blockIdx.y;
-  const int B = stream_bins(M);
   SNode<TK>* ndt = nd + (int64_t)t * M;
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
     ngeo[j] = AGeom<TK>{ndt[j].lo, ndt[j].scale};
-    nbin[j] = ABins{(short)ndt[j].pb, (short)ndt[j].lowb, (short)ndt[j].highb, 0};
+    nbin[j] = ABins{ndt[j].pb, ndt[j].lowb, ndt[j].highb, 0};
     nmidoff[j] = ndt[j].midoff;
   }
   for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
@@ -2524,7 +2651,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   int streamed = 0;  // levels completed by the streaming path
   if (Lstream > 0) {
     DevBuf<uint16_t> node_of;
-    DevBuf<unsigned int> part, poolcur, gcur;
+    DevBuf<unsigned int> part, poolcur, gcur, totals;
     DevBuf<SNode<TK>> snodes;
     DevBuf<unsigned long long> mm[4];  // cmin/cmax ping-pong
     // histogram pass: every block leaves a 64 KB partial that stream_pick reads back, so keep
@@ -2559,20 +2686,24 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     DevBuf<TK> poolkey;      // keys of the pivot-bin lists, same indexing as pool
     RPT_TRY(poolkey.alloc((size_t)T * N));
     const int wave_max = getenv("RPT_NO_WMID") ? 0 : 128;
+    // nodes above this size get more than 4096 bins (RPT_STREAM_BIG_NODE: test hook)
+    const int64_t big_node = getenv("RPT_STREAM_BIG_NODE") ? atoll(getenv("RPT_STREAM_BIG_NODE"))
+                                                           : ((int64_t)1 << 21);
     {
       ProfScope ps(ctx, RPT_PROF_SPLIT);
       for (int level = 0; level < Lstream; ++level) {
         const int M = 1 << level;
         const int has_next = level + 1 < Lstream ? 1 : 0;
+        const int B = stream_bins(M, N >> level, big_node);
         hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
-                           level, M, per, cmin, cmax, part.p);
+                           level, M, B, per, cmin, cmax, part.p);
         unsigned int* pc = poolcur.p + (size_t)level * T;
 #define RPT_PICK(BPT, G)                                                                       \
   hipLaunchKernelGGL((stream_pick<TK, BPT, G>), dim3((unsigned)((M + 256 / G - 1) / (256 / G)), \
                                                       (unsigned)T),                            \
                      dim3(256), 0, st, N, level, M, (int)nblk, part.p, cmin, cmax, snodes.p, pc, \
                      cminN, cmaxN, sflags.p)
-        switch (stream_bins(M)) {
+        switch (B) {
           case 4096: RPT_PICK(16, 256); break;
           case 2048: RPT_PICK(8, 256); break;
           case 1024: RPT_PICK(8, 128); break;
@@ -2580,11 +2711,19 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           case 256: RPT_PICK(8, 32); break;
           case 128: RPT_PICK(8, 16); break;
           case 64: RPT_PICK(8, 8); break;
-          default: RPT_PICK(8, 4); break;  // 32 bins: 1024 nodes
+          case 32: RPT_PICK(8, 4); break;  // 1024 nodes
+          default: {  // > 4096 bins per node (very large nodes): sum the partials, then scan
+            RPT_TRY(totals.ensure((size_t)T * kStreamBins));
+            hipLaunchKernelGGL(stream_pick_sum, dim3((unsigned)((M * B / 2 + 255) / 256), (unsigned)T),
+                               dim3(256), 0, st, M * B / 2, (int)nblk, part.p, totals.p);
+            hipLaunchKernelGGL(stream_pick_big<TK>, dim3((unsigned)M, (unsigned)T), dim3(256), 0, st,
+                               N, level, M, B, totals.p, cmin, cmax, snodes.p, pc, cminN, cmaxN,
+                               sflags.p);
+          }
         }
 #undef RPT_PICK
         hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, node_of.p, N,
-                           L, level, M, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
+                           L, level, M, B, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
         const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
         const int npb = M >= 16 ? 4 : 1;
         MidArgs<TK> ma{P,     node_of.p, N,     L,        level,    M,
@@ -2763,15 +2902,34 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           for (const Seg& sgm : rest) pending[(size_t)level + kWRmax].push_back(PNode{sgm, 1 - b});
         }
       }
-      if (!bsmall.empty()) {  // whole subtrees in LDS, kRmax levels per launch
-        RPT_TRY(upload(bsmall, dsegs));
-        hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)bsmall.size(), T), dim3(kSubThreads),
-                           0, st, cur, nxt, F, N, P, L, level, f->min_leaf, dsegs.p, f->thr.p,
-                           f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
-        if (level + kRmax < Lused) {
-          std::vector<Seg> rest;
-          for (const Seg& sgm : bsmall) descend(sgm, level, 0, kRmax, rest);
-          for (const Seg& sgm : rest) pending[(size_t)level + kRmax].push_back(PNode{sgm, 1 - b});
+      if (!bsmall.empty()) {
+        // whole subtrees in LDS.  Nodes above the wave kernel's size run only the levels that
+        // bring them under it (the wave kernel is the faster one); nodes that kernel handed
+        // back (pool overflow: heavy ties) run kRmax levels, which finishes their subtrees.
+        std::vector<Seg> grp[2];  // [0] above kWCap, [1] handed back
+        for (const Seg& sgm : bsmall) grp[(sgm.n <= kWCap && !no_wsub) ? 1 : 0].push_back(sgm);
+        for (int gi = 0; gi < 2; ++gi) {
+          if (grp[gi].empty()) continue;
+          int r = kRmax;
+          if (gi == 0 && !no_wsub) {
+            int nmax = 0;
+            for (const Seg& sgm : grp[gi]) nmax = sgm.n > nmax ? sgm.n : nmax;
+            r = 0;
+            while (nmax > kWCap) {  // the larger child of n points has n - n/2
+              nmax -= nmax / 2;
+              ++r;
+            }
+          }
+          RPT_TRY(upload(grp[gi], gi == 0 ? dsegs : dsegs2));
+          hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)grp[gi].size(), T),
+                             dim3(kSubThreads), 0, st, cur, nxt, F, N, P, L, level, f->min_leaf,
+                             (gi == 0 ? dsegs : dsegs2).p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
+                             tie_count, dbgbuf, r);
+          if (level + r < Lused) {
+            std::vector<Seg> rest;
+            for (const Seg& sgm : grp[gi]) descend(sgm, level, 0, r, rest);
+            for (const Seg& sgm : rest) pending[(size_t)level + r].push_back(PNode{sgm, 1 - b});
+          }
         }
       }
       if (!big.empty()) {
@@ -2921,7 +3079,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       RPT_TRY(upload(redo, dsegs));
       hipLaunchKernelGGL(subtree_kernel<TK>, dim3((unsigned)redo.size(), T), dim3(kSubThreads), 0,
                          st, bufs[df.b], bufs[1 - df.b], F, N, P, L, df.level, f->min_leaf, dsegs.p,
-                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf);
+                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, dbgbuf, kRmax);
       RPT_HIP(hipGetLastError());
       redone = true;
     }

@@ -514,3 +514,17 @@ def test_random_shapes_short_sweep(rp, ctx):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(15.0, 20261003, ctx=ctx, verbose=False) > 20
+
+
+def test_more_than_4096_bins_per_node(rp, ctx, oracle, monkeypatch):
+    """Very large nodes get up to 32768 value bins on the first streaming levels (two-stage
+    pick); RPT_STREAM_BIG_NODE lowers the node size that triggers it."""
+    monkeypatch.setenv("RPT_STREAM_BIG_NODE", "1000")
+    n, d, T, min_leaf = 70000, 5, 3, 30
+    X = oracle.data_normal_dense2(99, n, d)
+    X[:5000] = np.round(X[:5000])                      # some ties as well
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    R, _ = oracle.forest_hyperplanes(5, T, L, 1.0, d)
+    fo = oracle.forest_build_dense(X, R, min_leaf)
+    f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R)
+    assert_forest_equal(f, fo)
