@@ -305,13 +305,22 @@ def main():
         w_ms, w_n = prof["project_wide"]
         cols_total = Tl * maxd                       # hyperplanes of one build on this rank
         if w_n > 0:
-            # dominant kernel: proj_mfma_wide.  Passes of up to 96 hyperplanes while more than
-            # 32 remain (project.hip: launch_mfma); the short tail goes to the 32-column kernel
-            nwide = cols_total // 96
-            if cols_total - nwide * 96 > 32:
-                nwide += 1
-            cols = min(nwide * 96, cols_total) / nwide   # real hyperplanes per wide launch
-            kernel = "proj_mfma_wide (MFMA f64 16x16x4, %.1f hyperplanes per pass over X)" % cols
+            # dominant kernel: proj_mfma_wide.  Column passes as planned by project.hip
+            # (launch_mfma): 96 hyperplanes per read of X, the rest in the smallest shape that
+            # holds it, a tail of <= 32 folded into the last full pass (128 columns)
+            wide = []
+            left = cols_total
+            while left > 0:
+                take = left if left <= 128 else 96
+                if left <= 32:
+                    take = 0                     # the 32-column kernel, not a wide launch
+                    left = 0
+                else:
+                    wide.append(take)
+                    left -= take
+            cols = sum(wide) / len(wide)         # real hyperplanes per wide launch (average)
+            kernel = "proj_mfma_wide (MFMA f64 16x16x4, passes of %s hyperplanes over X)" % (
+                "+".join(str(c) for c in wide))
             avg_ms = w_ms / w_n
         else:
             cols = cols_total * args.steps / max(p_n, 1)

@@ -23,6 +23,7 @@
 #include <hip/hip_bf16.h>
 
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -759,73 +760,101 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
     // continue the sums in P; a last chunk shorter than 128 reads as zero past the row's end
     // (and the wide kernel skips its empty K slices).
     const int nkc = (ds->d + D - 1) / D;
-    // wide passes: up to 96 hyperplanes per read of X (CBT 6); a pass that has at most 64 left
-    // uses the CBT 4 shape (the matrix pipe pays for padded columns too)
-    constexpr int WCOLS = 96;
-    const bool wide_ok = !getenv("RPT_PROJ_NARROW");
-    // wide passes while more than 32 columns remain, the 32-column kernel for a short tail
-    int nwide = 0;
-    if (wide_ok) {
-      nwide = C / WCOLS;
-      if (C - nwide * WCOLS > 32) ++nwide;
-    }
-    const int cw = nwide * WCOLS < C ? nwide * WCOLS : C;  // columns done by wide passes
-    const int nblk = (C - cw + 31) / 32;
-    DevBuf<TC> ApadW, Apad;
-    const size_t wfrag = (size_t)6 * (D / 4) * 64, nfrag = (size_t)2 * (D / 4) * 64;
-    if (nwide) RPT_TRY(ApadW.alloc((size_t)nwide * nkc * wfrag));
-    if (nblk) RPT_TRY(Apad.alloc((size_t)nblk * nkc * nfrag));
-    // fragment-order copies of the hyperplanes, one per (column pass, K chunk)
-    for (int kc = 0; kc < nkc; ++kc) {
-      for (int b = 0; b < nwide; ++b) {
-        const int c0 = b * WCOLS;
-        const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
-        hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(16), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
-                           D, 1, ncol > 64 ? 6 : 4, c0, kc * D,
-                           ApadW.p + ((size_t)kc * nwide + b) * wfrag);
+    // Column passes.  Full passes take 96 hyperplanes per read of X (6 column tiles: the point
+    // where the f64 matrix pipe and HBM take about as long).  What is left goes to the smallest
+    // shape that holds it (the matrix pipe pays for padded columns too): <= 32 columns the
+    // register-resident 32-column kernel, <= 64 four tiles, else six — except that a tail of at
+    // most 32 columns after a full pass is folded into that pass (8 tiles, 128 columns: cheaper
+    // than one more read of X).
+    struct Pass {
+      int c0, ncol, tiles;  // tiles == 0: the 32-column kernel
+    };
+    std::vector<Pass> passes;
+    constexpr int KS8 = sizeof(TC) == 8 ? 8 : 4;  // 8 tiles of 8-byte fragments are 128 KB of LDS
+    {
+      const bool wide_ok = !getenv("RPT_PROJ_NARROW");
+      int c0 = 0;
+      while (c0 < C) {
+        const int left = C - c0;
+        int take, tiles;
+        if (!wide_ok || left <= 32) {
+          take = left < 32 ? left : 32;
+          tiles = 0;
+        } else if (left <= 64) {
+          take = left;
+          tiles = 4;
+        } else if (left <= 96) {
+          take = left;
+          tiles = 6;
+        } else if (left <= 128) {
+          take = left;
+          tiles = 8;
+        } else {
+          take = 96;
+          tiles = 6;
+        }
+        passes.push_back(Pass{c0, take, tiles});
+        c0 += take;
       }
-      if (nblk)
-        hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
-                           D, nblk, 2, cw, kc * D, Apad.p + (size_t)kc * nblk * nfrag);
+    }
+    const size_t frag = (size_t)(D / 4) * 64;  // fragment words of one 16-column tile
+    size_t total_tiles = 0;
+    for (const Pass& ps : passes) total_tiles += ps.tiles ? ps.tiles : 2;
+    DevBuf<TC> Afrag;
+    RPT_TRY(Afrag.alloc(total_tiles * nkc * frag));
+    // fragment-order copies of the hyperplanes, one per (column pass, K chunk)
+    {
+      size_t off = 0;
+      for (int kc = 0; kc < nkc; ++kc)
+        for (const Pass& ps : passes) {
+          const int tl = ps.tiles ? ps.tiles : 2;
+          hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(16), dim3(256), 0, ctx->stream, R_dev, C, ds->d,
+                             D, 1, tl, ps.c0, kc * D, Afrag.p + off);
+          off += (size_t)tl * frag;
+        }
     }
     int64_t wblocks = (ntiles + 7) / 8;
     if (wblocks > ctx->n_cu) wblocks = ctx->n_cu;
     int64_t blocks = (ntiles + 3) / 4;
     const int64_t cap = (int64_t)ctx->n_cu * 2;
     if (blocks > cap) blocks = cap;
+    size_t off = 0;
     for (int kc = 0; kc < nkc; ++kc) {
       const int k0 = kc * D, accumulate = kc > 0;
       const int kvalid = ds->d - k0 < D ? ds->d - k0 : D;
-      for (int b = 0; b < nwide; ++b) {
-        const int c0 = b * WCOLS;
-        const int ncol = C - c0 < WCOLS ? C - c0 : WCOLS;
-        const TC* Ab = ApadW.p + ((size_t)kc * nwide + b) * wfrag;
-        ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);  // resolved into class 0 as well
-        if (ncol > 64) {
-          RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, k0, kvalid, accumulate, c0, ncol, Ab, P,
-                                                 ntiles, wblocks)));
+      for (const Pass& ps : passes) {
+        const TC* Ab = Afrag.p + off;
+        off += (size_t)(ps.tiles ? ps.tiles : 2) * frag;
+        if (ps.tiles) {
+          ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);  // resolved into class 0 as well
+          switch (ps.tiles) {
+            case 8:
+              RPT_TRY((launch_wide<TIn, TC, D, 8, KS8>(ctx, ds, k0, kvalid, accumulate, ps.c0,
+                                                       ps.ncol, Ab, P, ntiles, wblocks)));
+              break;
+            case 6:
+              RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, k0, kvalid, accumulate, ps.c0,
+                                                     ps.ncol, Ab, P, ntiles, wblocks)));
+              break;
+            default:
+              RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, k0, kvalid, accumulate, ps.c0,
+                                                     ps.ncol, Ab, P, ntiles, wblocks)));
+          }
         } else {
-          RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, k0, kvalid, accumulate, c0, ncol, Ab, P,
-                                                 ntiles, wblocks)));
+          ProfScope pn(ctx, RPT_PROF_PROJECT);
+          if (ps.ncol > 16)
+            hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
+                               ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n,
+                               ntiles, (int64_t)ds->d, accumulate, kvalid);
+          else
+            hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
+                               ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n,
+                               ntiles, (int64_t)ds->d, accumulate, kvalid);
         }
-      }
-      for (int b = 0; b < nblk; ++b) {
-        const int c0 = cw + b * 32;
-        const int ncol = C - c0 < 32 ? C - c0 : 32;
-        const TC* Ab = Apad.p + ((size_t)kc * nblk + b) * nfrag;
-        ProfScope ps(ctx, RPT_PROF_PROJECT);
-        if (ncol > 16)
-          hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
-                             ctx->stream, (const TIn*)ds->X + k0, n, Ab, c0, ncol, P, n, ntiles,
-                             (int64_t)ds->d, accumulate, kvalid);
-        else
-          hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
-                             ctx->stream, (const TIn*)ds->X + k0, n, Ab, c0, ncol, P, n, ntiles,
-                             (int64_t)ds->d, accumulate, kvalid);
       }
     }
     RPT_HIP(hipGetLastError());
-    return RPT_OK;  // the pad buffers return to the allocator, which recycles them only after
+    return RPT_OK;  // the fragment buffer returns to the allocator, which recycles it only after
                     // the stream has been synchronised
   }
   constexpr int WAVES = 4;
