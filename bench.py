@@ -340,6 +340,7 @@ def main():
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per MI355X_MICROARCH.md); only
         # valid for the exact configuration it was measured on, otherwise null
         traffic = None
+        mfma_busy = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             c = pj["config"]
@@ -348,6 +349,7 @@ def main():
             if (c["N"], c["d"]) == (N, d) and world == 1 and \
                     int(round(pj[kname]["cols"])) == int(round(cols)):
                 traffic = pj[kname]["hbm_bytes_per_launch"]
+                mfma_busy = pj[kname].get("mfma_util_pct")
         except Exception:
             traffic = None
         if mfma_frac > hbm_frac:
@@ -364,7 +366,9 @@ def main():
             "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_frac},
             "mfma_f64": {"achieved": mfma_achieved, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": mfma_frac},
+                         "frac": mfma_frac,
+                         # rocprofv3 --pmc MfmaUtil of the same launches (profiles/), not live
+                         "mfma_busy_pmc_pct": mfma_busy},
             # the reference formulation projects one tree level (32 hyperplanes) per read of X:
             # 8(d)'s 1.28 GB per level.  All projection launches of a build against that figure:
             "survey_8d_per_level": {
