@@ -537,7 +537,36 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     r_done = rd;
     pos_base = pb;
     __syncthreads();
-    // ---- distances of the new candidates: 8 rows in flight per wave ----
+    // ---- distances of the new candidates ----
+    constexpr int VV = 16 / (int)sizeof(TD);
+    const int lpr = (d % VV) == 0 ? d / VV : 0;  // lanes one row needs with 16-byte loads
+    if (lpr > 0 && lpr <= 32 && (lpr & (lpr - 1)) == 0) {
+      // short rows (<= 512 B): 64 / lpr rows per load instruction, eight instructions in flight
+      struct alignas(16) Raw { TD v[VV]; };
+      const int rpw = 64 / lpr, sub = lane / lpr, jl = (lane % lpr) * VV;
+      for (int i0 = first_new + wave * 8 * rpw; i0 < fill; i0 += 32 * rpw) {
+        TA s[8];
+        Raw x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * rpw + sub;
+          x[u] = *reinterpret_cast<const Raw*>(X + (int64_t)cid[i < fill ? i : i0] * d + jl);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s[u] = (TA)0;
+#pragma unroll
+          for (int v = 0; v < VV; ++v) {
+            const TA df = ld<TD>(&x[u].v[v]) - qs[jl + v];
+            s[u] += df * df;
+          }
+          for (int o = lpr >> 1; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);  // fixed butterfly
+          const int i = i0 + u * rpw + sub;
+          if (jl == 0 && i < fill) cdist[i] = (double)sqrt((double)s[u]);
+        }
+      }
+    } else
+    // ---- long rows: one row per load instruction, 8 rows in flight per wave ----
     for (int i0 = first_new + wave * 8; i0 < fill; i0 += 32) {
       TA s[8];
       const TD* rows[8];
