@@ -287,10 +287,15 @@ def main():
         same = 0
         knn(forest, rp.RPT_KNN_KEEP_DUPLICATES)
         got = ids_l[:nqs].cpu().numpy()
+        hit_ref = hit_gpu = 0
         t0 = time.perf_counter()
         for i in range(nqs):
             wi, _ = orc.knn_dense(fo, Xh, Qh[i], k)
             same += int(np.array_equal(wi, got[i, :len(wi)]))
+            if i < nq_eval:   # recall@k of the reference's knn (duplicates kept) vs brute force
+                kk = set(true_ids[i].tolist())
+                hit_ref += len(kk & set(wi.tolist()))
+                hit_gpu += len(kk & set(got[i].tolist()))
         t_cpuq = time.perf_counter() - t0
         cpu = {"value": cpu_build, "unit": "vectors/s", "cores": 1, "kind": "port",
                "sample": "oracle (C++ restatement, g++ -O2, 1 thread) building %d of the %d trees "
@@ -298,7 +303,11 @@ def main():
                          "full forest" % (nt, T, T, nqs),
                "knn_queries_per_s": nqs / t_cpuq,
                "knn_ids_identical_to_gpu": "%d/%d" % (same, nqs),
-               "trees_identical_to_gpu_exact_mode": "%d/%d" % (same_trees, ncmp)}
+               "trees_identical_to_gpu_exact_mode": "%d/%d" % (same_trees, ncmp),
+               # recall@k of `knn` (duplicates kept) against brute force on the same queries:
+               # the reference restatement vs the device
+               "recall_at_k_reference_vs_gpu": [hit_ref / float(min(nqs, nq_eval) * k),
+                                                hit_gpu / float(min(nqs, nq_eval) * k)]}
 
     if rank == 0:
         p_ms, p_n = prof["project"]
