@@ -663,35 +663,50 @@ __global__ __launch_bounds__(256) void proj_csr(const int64_t* __restrict__ rowp
 
 // ---------------------------------------------------------------------------------------
 // CSR fast path: the 16-hyperplane tile Rt[d][16] lives in LDS (d*16*sizeof(T) <= 128 KB, e.g.
-// 100 KB for the 784-dim C3 rows), one workgroup of 16 waves per CU.  A wave works on 4 rows
-// (16 lanes each, lane = hyperplane); the row's nonzeros are fetched 16 at a time, coalesced
-// and in REVERSE order, then broadcast one by one inside the 16-lane group (width-16 shuffle):
-// every lane accumulates `acc = val*r[col] + acc` from the last nonzero to the first — the
-// reference's innerSS order (Internal.hs:353-366).  Padding entries (val 0) add an exact zero.
+// 100 KB for the 784-dim C3 rows), one workgroup of 16 waves per CU.  A wave works on 16 rows:
+// FOUR lanes per row, each lane owning four of the 16 hyperplanes, so one nonzero costs a lane
+// two 16-byte LDS reads and four multiply-adds (16 lanes x one hyperplane each needed an LDS
+// read and three broadcasts per single multiply-add: the kernel was bound by instruction issue
+// at 2.3 TB/s).  The row's nonzeros are fetched sixteen at a time (four per lane), and broadcast
+// one by one in REVERSE order inside the quad (DPP quad_perm, a VALU move): every lane accumulates
+// `acc = val*r[col] + acc` from the last nonzero to the first — the reference's innerSS order
+// (Internal.hs:353-366).  Padding entries (val 0) add an exact zero.
 // ---------------------------------------------------------------------------------------
-// broadcast lane U of every 16-lane DPP row to the whole row (gfx90a+ row_newbcast): a VALU
-// move — the width-16 __shfl goes through ds_bpermute, i.e. the LDS pipe this kernel is bound by
 template <int U>
-__device__ inline int bcast16(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false);
+__device__ inline int quad_bcast(int x) {  // lane U of every quad to the whole quad
+  return __builtin_amdgcn_update_dpp(0, x, U | (U << 2) | (U << 4) | (U << 6), 0xf, 0xf, false);
 }
 template <int U>
-__device__ inline float bcast16(float x) {
-  return __int_as_float(bcast16<U>(__float_as_int(x)));
+__device__ inline float quad_bcast(float x) {
+  return __int_as_float(quad_bcast<U>(__float_as_int(x)));
 }
 template <int U>
-__device__ inline double bcast16(double x) {
+__device__ inline double quad_bcast(double x) {
   const long long b = __double_as_longlong(x);
-  const int lo = bcast16<U>((int)(b & 0xffffffffLL)), hi = bcast16<U>((int)(b >> 32));
+  const int lo = quad_bcast<U>((int)(b & 0xffffffffLL)), hi = quad_bcast<U>((int)(b >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <class T, int U>
-__device__ inline void csr_terms(int mycol, T myval, const T* rl, int c, T& acc) {
-  const int cu = bcast16<U>(mycol);
-  const T vu = bcast16<U>(myval);
-  acc = add_rn(mul_rn(vu, rl[cu * 16 + c]), acc);
-  if constexpr (U < 15) csr_terms<T, U + 1>(mycol, myval, rl, c, acc);
+// LDS row stride of the hyperplane tile in elements: 16 + 2 — with 16 the sixteen quads of a
+// wave, each reading the 16-element row of a different column index, all start at bank 0 or 32
+constexpr int kCsrLd = 18;
+
+// one nonzero of the batch: element E of quad lane U, broadcast to the quad
+template <class T, int U, int E>
+__device__ inline void csr_term(const int (&mycol)[4], const T (&myval)[4], const T* rl, int q,
+                                T (&acc)[4]) {
+  const int cu = quad_bcast<U>(mycol[E]);
+  const T vu = quad_bcast<U>(myval[E]);
+  const T* r = rl + cu * kCsrLd + 4 * q;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = add_rn(mul_rn(vu, r[k]), acc[k]);
+}
+// the 16 nonzeros of a batch from the LAST (lane 3, element 3) to the first (lane 0, element 0)
+template <class T, int I>
+__device__ inline void csr_batch(const int (&mycol)[4], const T (&myval)[4], const T* rl, int q,
+                                 T (&acc)[4]) {
+  csr_term<T, I / 4, I % 4>(mycol, myval, rl, q, acc);
+  if constexpr (I > 0) csr_batch<T, I - 1>(mycol, myval, rl, q, acc);
 }
 
 template <class T>
@@ -702,28 +717,39 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
                                                      T* __restrict__ P, int64_t ldp, int ncol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* rl = reinterpret_cast<T*>(smem_raw);
-  for (int i = threadIdx.x; i < d * 16; i += blockDim.x) rl[i] = Rt[i];
+  for (int i = threadIdx.x; i < d * 16; i += blockDim.x) rl[(i >> 4) * kCsrLd + (i & 15)] = Rt[i];
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int c = lane & 15;
+  const int q = lane & 3;  // hyperplanes 4q .. 4q+3
   const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int64_t nquads = (n + 3) / 4;
-  for (int64_t qd = wave_global; qd < nquads; qd += wave_stride) {
-    const int64_t row = qd * 4 + (lane >> 4);
+  const int64_t ngroups = (n + 15) / 16;
+  for (int64_t g = wave_global; g < ngroups; g += wave_stride) {
+    const int64_t row = g * 16 + (lane >> 2);
     const bool rv = row < n;
     const int64_t a = rv ? rowptr[row] : 0, b = rv ? rowptr[row + 1] : 0;
-    T acc = (T)0;
+    T acc[4] = {(T)0, (T)0, (T)0, (T)0};
     int64_t j0 = b;
     while (__any(j0 > a)) {
-      const int64_t idx = j0 - 1 - c;
-      const bool ok = idx >= a && j0 > a;
-      const int mycol = ok ? col[idx] : 0;
-      const T myval = ok ? val[idx] : (T)0;
-      csr_terms<T, 0>(mycol, myval, rl, c, acc);
+      // a batch of 16 nonzeros [j0 - 16, j0): lane q of the quad loads four consecutive ones,
+      // so the quad reads one 64-byte run of columns and one 128-byte run of values
+      int mycol[4];
+      T myval[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t idx = j0 - 16 + 4 * q + e;
+        const bool ok = idx >= a && j0 > a;
+        mycol[e] = ok ? col[idx] : 0;
+        myval[e] = ok ? val[idx] : (T)0;
+      }
+      csr_batch<T, 15>(mycol, myval, rl, q, acc);
       j0 -= 16;
     }
-    if (rv && c < ncol) P[(int64_t)c * ldp + row] = acc;
+    if (rv) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * q + k < ncol) P[(int64_t)(4 * q + k) * ldp + row] = acc[k];
+    }
   }
 }
 
@@ -919,8 +945,8 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
   DevBuf<T> Rt;
   RPT_TRY(Rt.alloc((size_t)nblk * d * CB));
   hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
-  const size_t tile = (size_t)d * CB * sizeof(T);
-  const bool lds_path = tile <= 128 * 1024;  // else the hyperplane tile is read through L2
+  const size_t tile = (size_t)d * kCsrLd * sizeof(T);  // padded rows, see kCsrLd
+  const bool lds_path = tile <= 144 * 1024;  // else the hyperplane tile is read through L2
   if (lds_path && tile > 64 * 1024)
     RPT_HIP(hipFuncSetAttribute((const void*)proj_csr_lds<T>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile));
