@@ -735,12 +735,25 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
       // so the quad reads one 64-byte run of columns and one 128-byte run of values
       int mycol[4];
       T myval[4];
+      const int64_t i4 = j0 - 16 + 4 * q;
+      if (i4 >= a && j0 > a) {  // the lane's four nonzeros all exist: two/three wide loads
+        struct __attribute__((packed, aligned(4))) C4 { int v[4]; };
+        struct __attribute__((packed, aligned(4))) V4 { T v[4]; };
+        const C4 c4 = *reinterpret_cast<const C4*>(col + i4);
+        const V4 v4 = *reinterpret_cast<const V4*>(val + i4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t idx = j0 - 16 + 4 * q + e;
-        const bool ok = idx >= a && j0 > a;
-        mycol[e] = ok ? col[idx] : 0;
-        myval[e] = ok ? val[idx] : (T)0;
+        for (int e = 0; e < 4; ++e) {
+          mycol[e] = c4.v[e];
+          myval[e] = v4.v[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t idx = i4 + e;
+          const bool ok = idx >= a && j0 > a;
+          mycol[e] = ok ? col[idx] : 0;
+          myval[e] = ok ? val[idx] : (T)0;
+        }
       }
       csr_batch<T, 15>(mycol, myval, rl, q, acc);
       j0 -= 16;
