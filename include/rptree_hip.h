@@ -176,7 +176,8 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                       double* dist_host, int64_t cap, int64_t* total);
 
 /* knn (RPTree.hs:168-176) with distf = metricL2 (Internal.hs:318, metricDDL2 :403-406 /
- * true Euclidean distance for CSR data): per query the k best (distance, id), stable in
+ * true Euclidean distance for CSR data, evaluated as |q|^2 + sum over the row's nonzeros of
+ * ((x_j - q_j)^2 - q_j^2): absolute error about 1e-8 |q|): per query the k best (distance, id), stable in
  * candidate order (tree ascending, then leaf order).  ids/dist are [nq][k]; count[nq] is the
  * number of valid entries (< k when fewer candidates).  Unused slots: id -1, dist +inf. */
 int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,

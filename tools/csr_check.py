@@ -50,3 +50,15 @@ for (t, l, i) in [(0, 0, 0), (1, 3, 17), (T-1, cfg.fpMaxTreeDepth-1, n-1)]:
         if R[t, l, col[j]] != 0: acc = val[j] * R[t, l, col[j]] + acc
     assert P[t, l, i] == acc, (P[t, l, i], acc)
 print("valid; stats", f.stats())
+
+# kNN over the sparse forest (general path: CSR rows, true Euclidean distance): 2000 queries
+nq = 2000
+qr = rowptr[:nq + 1].copy()
+qc, qv = col[:qr[-1]].copy(), val[:qr[-1]].copy()
+for it in range(2):
+    t0 = time.perf_counter()
+    ids, dist, cnt = rp.knnBatch(10, f, (qr, qc, qv, d))
+    dt = time.perf_counter() - t0
+    print("knn %d queries: %.2f ms = %.3f M queries/s (host call, incl. query upload)" % (nq, dt * 1e3, nq / dt / 1e6))
+# every row finds itself; the CSR distance |q|^2 + sum((x-q)^2 - q^2) cancels to ~1e-8 |q|, not 0
+assert (ids[:, 0] == np.arange(nq)).all() and (dist[:, 0] < 1e-6).all()
