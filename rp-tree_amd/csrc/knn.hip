@@ -717,17 +717,20 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
     while (done < rg.n) {
       int take = rg.n - done;
       if (take > cap - filled) take = cap - filled;
-      for (int i = wave; i < take; i += 4) {
+      // sixteen lanes per candidate row, four rows per wave in flight (a sparse row has ~150
+      // nonzeros: one row per wave left the loads latency-bound)
+      for (int i = wave * 4 + (lane >> 4); i < take; i += 16) {
         const int c = done + i;
         const int id = perm[rg.poff + c];
         double s = 0;
-        for (int64_t j = rowptr[id] + lane; j < rowptr[id + 1]; j += 64) {
+        for (int64_t j = rowptr[id] + (lane & 15); j < rowptr[id + 1]; j += 16) {
           const double qj = qs[col[j]];
           const double df = (double)val[j] - qj;
           s += df * df - qj * qj;
         }
-        s = wave_sum(s) + qn2;
-        if (lane == 0) buf[filled + i] = Entry{sqrt(s > 0 ? s : 0.0), rg.pos + c, id};
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);  // fixed butterfly inside the group
+        s += qn2;
+        if ((lane & 15) == 0) buf[filled + i] = Entry{sqrt(s > 0 ? s : 0.0), rg.pos + c, id};
       }
       filled += take;
       done += take;
