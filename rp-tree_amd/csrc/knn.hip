@@ -723,7 +723,9 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
         const int c = done + i;
         const int id = perm[rg.poff + c];
         double s = 0;
-        for (int64_t j = rowptr[id] + (lane & 15); j < rowptr[id + 1]; j += 16) {
+        const int64_t ra = rowptr[id], rb = rowptr[id + 1];
+#pragma unroll 4
+        for (int64_t j = ra + (lane & 15); j < rb; j += 16) {
           const double qj = qs[col[j]];
           const double df = (double)val[j] - qj;
           s += df * df - qj * qj;
@@ -1001,6 +1003,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
   const int dedup = flags & 3;
   if (data->csr) {
     const size_t smem = topk_smem(data->d, 8);
+    ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
     if (data->dtype == RPT_F64) {
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)topk_csr_kernel<double>,

@@ -62,3 +62,9 @@ for it in range(2):
     print("knn %d queries: %.2f ms = %.3f M queries/s (host call, incl. query upload)" % (nq, dt * 1e3, nq / dt / 1e6))
 # every row finds itself; the CSR distance |q|^2 + sum((x-q)^2 - q^2) cancels to ~1e-8 |q|, not 0
 assert (ids[:, 0] == np.arange(nq)).all() and (dist[:, 0] < 1e-6).all()
+_lib.check(L_.rpt_prof_reset(ctx._h)); _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+ids, dist, cnt = rp.knnBatch(10, f, (qr, qc, qv, d))
+for name, which in (("query projections + traversal plan", 2), ("distance / top-k kernel", 3)):
+    ms, c = C.c_double(), C.c_int64()
+    _lib.check(L_.rpt_prof_get(ctx._h, which, C.byref(ms), C.byref(c)))
+    print("  %-36s %.2f ms in %d spans" % (name, ms.value, c.value))
