@@ -7,7 +7,8 @@ A "step" = one forest build (projection batch + median splits of all levels) of 
 32-tree forest; with N > 1 the trees are sharded in contiguous blocks (rank r builds trees
 [r*T/N, (r+1)*T/N)), X is replicated — strong scaling, no collective in the build.
 The kNN leg (same K steps, its own barrier-bracketed timed region) answers all queries on every
-shard, all-gathers the per-shard top-k over RCCL and merges them (rpt_knn_merge_dev).
+shard, all-gathers the per-shard top-k records over RCCL (one collective, ordered on the
+device with the kernels around it) and merges them (rpt_knn_merge_records_dev).
 
 Prints ONE JSON line on rank 0.  `value` = forest-build vectors/s with the data resident in
 HBM; the kNN queries/s and recall@10 of the same run are in `knn` / `recall_at_10`.
@@ -116,38 +117,64 @@ def main():
     def build():
         return rp._build(ctx, ds, Rl, maxd, args.min_leaf, mode)
 
-    ids_l = torch.empty((nq, k), dtype=torch.int32, device=dev)
-    dist_l = torch.empty((nq, k), dtype=torch.float64, device=dev)
-    cnt_l = torch.empty((nq,), dtype=torch.int32, device=dev)
+    # one exchange record per shard (distances | ids | counts back to back): ONE all-gather
+    from rptree_amd import sharded
+    rec = sharded.ExchangeRecord(nq, k, dev)
+    ids_l, dist_l, cnt_l = rec.ids, rec.dist, rec.count
     if world > 1:
-        ids_g = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
-        dist_g = torch.empty((world, nq, k), dtype=torch.float64, device=dev)
-        cnt_g = torch.empty((world, nq), dtype=torch.int32, device=dev)
+        rec_g = torch.empty((world, rec.bytes), dtype=torch.uint8, device=dev)
+        ctx_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     ids_o = torch.empty((nq, k), dtype=torch.int32, device=dev)
     dist_o = torch.empty((nq, k), dtype=torch.float64, device=dev)
     cnt_o = torch.empty((nq,), dtype=torch.int32, device=dev)
+
+    exchange = {"mode": os.environ.get("RPT_BENCH_EXCHANGE", "stream-ordered")}
 
     def knn(forest, flags):
         _lib.check(L_.rpt_knn_dev(ctx._h, forest._h, ds._h, qs._h, k, flags, ids_l.data_ptr(),
                                   dist_l.data_ptr(), cnt_l.data_ptr()))
         if world == 1:
             return ids_l, dist_l, cnt_l
-        ctx.sync()
         if one_gpu:                                       # gloo rehearsal: stage through the host
-            for g_, l_ in ((ids_g, ids_l), (dist_g, dist_l), (cnt_g, cnt_l)):
-                parts = [torch.empty_like(l_, device="cpu") for _ in range(world)]
-                dist.all_gather(parts, l_.cpu())
-                g_.copy_(torch.stack(parts))
-        else:
-            dist.all_gather_into_tensor(ids_g, ids_l)    # RCCL over xGMI: nq*k*(4+8)+nq*4 B/rank
-            dist.all_gather_into_tensor(dist_g, dist_l)
-            dist.all_gather_into_tensor(cnt_g, cnt_l)
-        torch.cuda.synchronize()
-        _lib.check(L_.rpt_knn_merge_dev(ctx._h, ids_g.data_ptr(), dist_g.data_ptr(),
-                                        cnt_g.data_ptr(), world, nq, k, flags, ids_o.data_ptr(),
-                                        dist_o.data_ptr(), cnt_o.data_ptr()))
+            ctx.sync()
+            sharded.gather_records(rec, out=rec_g, via_host=True)
+            torch.cuda.synchronize()
+        elif exchange["mode"] == "stream-ordered":
+            # RCCL over xGMI, nq*k*12 + nq*4 B per rank; issued under the ctx stream, so the
+            # collective waits for the shard's kernels and the merge waits for the collective
+            # on the device — no host synchronisation in between
+            with torch.cuda.stream(ctx_stream):
+                sharded.gather_records(rec, out=rec_g)
+        else:                                             # host-synced: the conservative order
+            ctx.sync()
+            sharded.gather_records(rec, out=rec_g)
+            torch.cuda.synchronize()
+        _lib.check(L_.rpt_knn_merge_records_dev(ctx._h, rec_g.data_ptr(), rec.bytes, world, nq, k,
+                                                flags, ids_o.data_ptr(), dist_o.data_ptr(),
+                                                cnt_o.data_ptr()))
         ctx.sync()
         return ids_o, dist_o, cnt_o
+
+    def settle_exchange(forest):
+        """The stream-ordered exchange must give the host-synced one's result on every rank;
+        otherwise (or if it raises) the whole job uses the host-synced order."""
+        if world == 1 or one_gpu or exchange["mode"] != "stream-ordered":
+            return
+        ok = 1
+        try:
+            exchange["mode"] = "host-synced"
+            ref = [x.clone() for x in knn(forest, rp.RPT_KNN_KEEP_DUPLICATES)]
+            exchange["mode"] = "stream-ordered"
+            for _ in range(3):
+                got = knn(forest, rp.RPT_KNN_KEEP_DUPLICATES)
+                ok &= int(all(torch.equal(a, b) for a, b in zip(ref, got)))
+        except Exception as e:                            # noqa: BLE001
+            sys.stderr.write("stream-ordered exchange failed (%s): host-synced\n" % e)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        exchange["mode"] = "stream-ordered" if int(flag.item()) == 1 else "host-synced"
 
     # ---- warmup ----
     forest = None
@@ -156,6 +183,9 @@ def main():
             forest.close()
         forest = build()
         knn(forest, rp.RPT_KNN_KEEP_DUPLICATES)
+    if forest is None:
+        forest = build()
+    settle_exchange(forest)
 
     # ---- timed region 1: K forest builds ----
     _lib.check(L_.rpt_prof_reset(ctx._h))
@@ -410,7 +440,10 @@ def main():
                     "ms_per_batch": t_knn / args.steps * 1e3, "semantics": "duplicates kept "
                     "(RPTree.hs:174-176)", "candidates_per_query": cand_total.value / nq,
                     "topk_kernel_ms": prof["knn_topk"][0] / max(prof["knn_topk"][1], 1),
-                    "plan_ms": prof["knn_plan"][0] / max(prof["knn_plan"][1], 1)},
+                    "plan_ms": prof["knn_plan"][0] / max(prof["knn_plan"][1], 1),
+                    "exchange": None if world == 1 else
+                    ("gloo via host (rehearsal)" if one_gpu else
+                     "one RCCL all-gather of %d B records, %s" % (rec.bytes, exchange["mode"]))},
             "recall_at_10": {"forest_knn_dedup_vs_brute_force": recall_knn,
                              "reference_recallWith_mean_per_tree": recall_ref,
                              "queries": nq_eval},

@@ -196,6 +196,17 @@ int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* di
                           const int32_t* count_dev, int32_t G, int64_t nq, int32_t k,
                           int32_t flags, int32_t* out_ids_dev, double* out_dist_dev,
                           int32_t* out_count_dev);
+/* the same merge over G packed exchange records (ONE all-gather instead of three): a shard
+ * writes its rpt_knn_dev results into one record — distances at off_dist, ids at off_ids,
+ * counts at off_count, `bytes` in all (rpt_knn_record_layout; a multiple of 16) — the records
+ * of all shards are gathered back to back (record_bytes apart, shard-major), and
+ * rpt_knn_merge_records_dev merges them exactly like rpt_knn_merge_dev. */
+int32_t rpt_knn_record_layout(int64_t nq, int32_t k, int64_t* bytes, int64_t* off_dist,
+                              int64_t* off_ids, int64_t* off_count);
+int32_t rpt_knn_merge_records_dev(rpt_ctx* ctx, const void* records_dev, int64_t record_bytes,
+                                  int32_t G, int64_t nq, int32_t k, int32_t flags,
+                                  int32_t* out_ids_dev, double* out_dist_dev,
+                                  int32_t* out_count_dev);
 
 /* brute-force exact kNN on the device (evaluation of recall; ties by ascending id) */
 int32_t rpt_brute_knn_host(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* queries,

@@ -755,8 +755,39 @@ int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* di
   RPT_ARG(G >= 1 && nq >= 0 && k >= 1 && k <= 1024, "bad merge arguments");
   RPT_ARG((int64_t)G * k <= 8192, "G*k must be <= 8192");
   RPT_HIP(hipSetDevice(ctx->device));
-  return knn_merge_dev(ctx, ids_dev, dist_dev, count_dev, G, nq, k, flags, out_ids_dev,
+  return knn_merge_dev(ctx, ids_dev, dist_dev, count_dev, 0, G, nq, k, flags, out_ids_dev,
                        out_dist_dev, out_count_dev);
+}
+
+int32_t rpt_knn_record_layout(int64_t nq, int32_t k, int64_t* bytes, int64_t* off_dist,
+                              int64_t* off_ids, int64_t* off_count) {
+  RPT_ARG(bytes && off_dist && off_ids && off_count, "NULL argument");
+  RPT_ARG(nq >= 0 && k >= 1, "bad record arguments");
+  *off_dist = 0;
+  *off_ids = nq * k * 8;
+  *off_count = nq * k * 12;
+  *bytes = (nq * k * 12 + nq * 4 + 15) & ~(int64_t)15;
+  return RPT_OK;
+}
+
+int32_t rpt_knn_merge_records_dev(rpt_ctx* ctx, const void* records_dev, int64_t record_bytes,
+                                  int32_t G, int64_t nq, int32_t k, int32_t flags,
+                                  int32_t* out_ids_dev, double* out_dist_dev,
+                                  int32_t* out_count_dev) {
+  if (ctx) dev_set_stream(ctx->stream);
+  RPT_ARG(ctx && records_dev && out_ids_dev && out_dist_dev && out_count_dev, "NULL argument");
+  RPT_ARG(G >= 1 && nq >= 0 && k >= 1 && k <= 1024, "bad merge arguments");
+  RPT_ARG((int64_t)G * k <= 8192, "G*k must be <= 8192");
+  int64_t bytes, od, oi, oc;
+  RPT_TRY(rpt_knn_record_layout(nq, k, &bytes, &od, &oi, &oc));
+  RPT_ARG(record_bytes >= bytes && record_bytes % 8 == 0,
+          "record_bytes smaller than rpt_knn_record_layout's size or not a multiple of 8");
+  RPT_HIP(hipSetDevice(ctx->device));
+  const char* base = static_cast<const char*>(records_dev);
+  return knn_merge_dev(ctx, reinterpret_cast<const int32_t*>(base + oi),
+                       reinterpret_cast<const double*>(base + od),
+                       reinterpret_cast<const int32_t*>(base + oc), record_bytes, G, nq, k, flags,
+                       out_ids_dev, out_dist_dev, out_count_dev);
 }
 
 int32_t rpt_brute_knn_host(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* queries,

@@ -204,8 +204,9 @@ int32_t candidates(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, int64_t* o
 int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,
                 int32_t k, int32_t flags, int32_t* ids_dev, double* dist_dev, int32_t* count_dev);
 int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
-                      const int32_t* count_dev, int32_t G, int64_t nq, int32_t k, int32_t flags,
-                      int32_t* out_ids, double* out_dist, int32_t* out_count);
+                      const int32_t* count_dev, int64_t shard_stride, int32_t G, int64_t nq,
+                      int32_t k, int32_t flags, int32_t* out_ids, double* out_dist,
+                      int32_t* out_count);
 int32_t brute_knn(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* q, int32_t k,
                   int32_t* ids_host, double* dist_host);
 int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_dataset* q,

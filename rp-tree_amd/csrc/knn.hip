@@ -37,25 +37,19 @@ struct Range {
 };
 
 // ---- traversal ---------------------------------------------------------------------------
-// emit(off, n) is called for every leaf reached, left to right.
+// emit(off, n) is called for every leaf reached, left to right.  Depth-first, left child first;
+// the right children still to visit lie on the current path at distinct levels, so a 32-bit
+// mask of those levels plus the current node's heap index is the whole stack: a pop takes the
+// deepest pending level l, the ancestor of the current node at that level, its right child,
+// and replays the l+1 halvings along that child's path for (off, n).  (Explicit stacks of
+// (level, heap, off, n) cost 128 registers and held the fused kernels to 2 waves per SIMD.)
 template <class TK, class Emit>
 __device__ inline void traverse(const double* __restrict__ thr, const double* __restrict__ mglo,
                                 const double* __restrict__ mghi, const TK* __restrict__ pq,
                                 int64_t pq_stride, int L, int min_leaf, int64_t N, Emit emit) {
-  int s_level[32];
-  unsigned int s_heap[32];
-  int s_off[32], s_n[32];
-  int sp = 0;
-  s_level[0] = 0;
-  s_heap[0] = 0;
-  s_off[0] = 0;
-  s_n[0] = (int)N;
-  sp = 1;
-  while (sp > 0) {
-    --sp;
-    int level = s_level[sp];
-    unsigned int heap = s_heap[sp];
-    int off = s_off[sp], n = s_n[sp];
+  unsigned int pending = 0, heap = 0;
+  int level = 0, off = 0, n = (int)N;
+  for (;;) {
     for (;;) {
       if (level >= L || n <= min_leaf) {  // Tip (RPTree.hs:299)
         emit(off, n);
@@ -68,12 +62,8 @@ __device__ inline void traverse(const double* __restrict__ thr, const double* __
       const int nh = n / 2;
       const bool both = (proj < th && dl > dr) || (proj > th && dl < dr);  // :309-313
       const bool left = proj < th;
-      if (both) {  // push right, continue left
-        s_level[sp] = level + 1;
-        s_heap[sp] = 2 * heap + 2;
-        s_off[sp] = off + nh;
-        s_n[sp] = n - nh;
-        ++sp;
+      if (both) {  // the right child waits, continue left
+        pending |= 1u << level;
         heap = 2 * heap + 1;
         n = nh;
       } else if (left) {  // :311
@@ -86,6 +76,23 @@ __device__ inline void traverse(const double* __restrict__ thr, const double* __
       }
       ++level;
     }
+    if (!pending) break;
+    const int l = 31 - __clz((int)pending);
+    pending &= ~(1u << l);
+    heap = 2 * (((heap + 1) >> (level - l)) - 1) + 2;
+    const unsigned int path = heap + 1;  // 1, then the l+1 decisions from the root down
+    off = 0;
+    n = (int)N;
+    for (int i = l; i >= 0; --i) {
+      const int nh = n / 2;
+      if ((path >> i) & 1u) {
+        off += nh;
+        n -= nh;
+      } else {
+        n = nh;
+      }
+    }
+    level = l + 1;
   }
 }
 
@@ -414,6 +421,85 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
   if (threadIdx.x == 0) out_cnt[q] = best;
 }
 
+// distances of the candidates [first, fill) of an LDS batch (ids in cid) to the query in qs,
+// written to cdist.  The waves taking part are numbered slot = 0 .. nslots-1; every row is
+// reduced by the same fixed butterfly whichever wave handles it, so the value does not depend
+// on the kernel variant.  Each wave keeps EIGHT load instructions in flight.
+template <class TD, class TA>
+__device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d, const int* cid,
+                                       double* cdist, const TA* qs, int first, int fill, int slot,
+                                       int nslots, int lane) {
+  constexpr int VV = 16 / (int)sizeof(TD);
+  const int lpr = (d % VV) == 0 ? d / VV : 0;  // lanes one row needs with 16-byte loads
+  if (lpr > 0 && lpr <= 32 && (lpr & (lpr - 1)) == 0) {
+    // short rows (<= 512 B): 64 / lpr rows per load instruction, eight instructions in flight
+    struct alignas(16) Raw { TD v[VV]; };
+    const int rpw = 64 / lpr, sub = lane / lpr, jl = (lane % lpr) * VV;
+    for (int i0 = first + slot * 8 * rpw; i0 < fill; i0 += nslots * 8 * rpw) {
+      TA s[8];
+      Raw x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * rpw + sub;
+        x[u] = *reinterpret_cast<const Raw*>(X + (int64_t)cid[i < fill ? i : i0] * d + jl);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s[u] = (TA)0;
+#pragma unroll
+        for (int v = 0; v < VV; ++v) {
+          const TA df = ld<TD>(&x[u].v[v]) - qs[jl + v];
+          s[u] += df * df;
+        }
+        for (int o = lpr >> 1; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);  // fixed butterfly
+        const int i = i0 + u * rpw + sub;
+        if (jl == 0 && i < fill) cdist[i] = (double)sqrt((double)s[u]);
+      }
+    }
+  } else
+  // ---- long rows: one row per load instruction, 8 rows in flight per wave ----
+  for (int i0 = first + slot * 8; i0 < fill; i0 += nslots * 8) {
+    TA s[8];
+    const TD* rows[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u < fill ? i0 + u : i0;
+      rows[u] = X + (int64_t)cid[i] * d;
+      s[u] = (TA)0;
+    }
+    constexpr int V = 16 / (int)sizeof(TD);
+    if ((d % V) == 0) {
+      struct alignas(16) Raw { TD v[V]; };
+      for (int j = lane * V; j < d; j += 64 * V) {
+        Raw x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const Raw*>(rows[u] + j);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const TA df = ld<TD>(&x[u].v[v]) - qs[j + v];
+            s[u] += df * df;
+          }
+      }
+    } else {
+      for (int j = lane; j < d; j += 64) {
+        const TA qj = qs[j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const TA df = ld<TD>(rows[u] + j) - qj;
+          s[u] += df * df;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const TA tot = wave_sum(s[u]);
+      if (lane == 0 && i0 + u < fill) cdist[i0 + u] = (double)sqrt((double)tot);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // fused query kernel (dense data): one workgroup per query does everything after the query
 // projections — traversal of every tree (thread = tree, twice: count, then emit ranges in
@@ -538,75 +624,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     pos_base = pb;
     __syncthreads();
     // ---- distances of the new candidates ----
-    constexpr int VV = 16 / (int)sizeof(TD);
-    const int lpr = (d % VV) == 0 ? d / VV : 0;  // lanes one row needs with 16-byte loads
-    if (lpr > 0 && lpr <= 32 && (lpr & (lpr - 1)) == 0) {
-      // short rows (<= 512 B): 64 / lpr rows per load instruction, eight instructions in flight
-      struct alignas(16) Raw { TD v[VV]; };
-      const int rpw = 64 / lpr, sub = lane / lpr, jl = (lane % lpr) * VV;
-      for (int i0 = first_new + wave * 8 * rpw; i0 < fill; i0 += 32 * rpw) {
-        TA s[8];
-        Raw x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * rpw + sub;
-          x[u] = *reinterpret_cast<const Raw*>(X + (int64_t)cid[i < fill ? i : i0] * d + jl);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          s[u] = (TA)0;
-#pragma unroll
-          for (int v = 0; v < VV; ++v) {
-            const TA df = ld<TD>(&x[u].v[v]) - qs[jl + v];
-            s[u] += df * df;
-          }
-          for (int o = lpr >> 1; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);  // fixed butterfly
-          const int i = i0 + u * rpw + sub;
-          if (jl == 0 && i < fill) cdist[i] = (double)sqrt((double)s[u]);
-        }
-      }
-    } else
-    // ---- long rows: one row per load instruction, 8 rows in flight per wave ----
-    for (int i0 = first_new + wave * 8; i0 < fill; i0 += 32) {
-      TA s[8];
-      const TD* rows[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u < fill ? i0 + u : i0;
-        rows[u] = X + (int64_t)cid[i] * d;
-        s[u] = (TA)0;
-      }
-      constexpr int V = 16 / (int)sizeof(TD);
-      if ((d % V) == 0) {
-        struct alignas(16) Raw { TD v[V]; };
-        for (int j = lane * V; j < d; j += 64 * V) {
-          Raw x[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const Raw*>(rows[u] + j);
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-              const TA df = ld<TD>(&x[u].v[v]) - qs[j + v];
-              s[u] += df * df;
-            }
-        }
-      } else {
-        for (int j = lane; j < d; j += 64) {
-          const TA qj = qs[j];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const TA df = ld<TD>(rows[u] + j) - qj;
-            s[u] += df * df;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const TA tot = wave_sum(s[u]);
-        if (lane == 0 && i0 + u < fill) cdist[i0 + u] = (double)sqrt((double)tot);
-      }
-    }
+    batch_distances<TD, TA>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     __syncthreads();
     // ---- selection: k rounds of block-wide arg-min by (distance, position) ----
     int nb = 0;
@@ -677,6 +695,209 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     out_dist[q * k + i] = ok ? bdist[i] : __longlong_as_double(0x7ff0000000000000LL);
   }
   if (tid == 0) out_cnt[q] = best;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused query kernel, wave variant: ONE WAVE per query, four independent queries per
+// workgroup and no workgroup barrier anywhere.  For small shards (a few trees per GPU, a few
+// hundred candidates per query) the workgroup variant spends most of a query's life in its
+// serial phases — traversal by T threads, range scan, k selection rounds with two barriers
+// each — while the other waves of the CU can only cover for it if they belong to other
+// queries; here every wave is its own query, so 12 queries per CU are in flight and their
+// traversal latencies overlap the others' row gathers.  Lane = tree in the traversal (one
+// pass: the leaf ranges go to per-tree slots and are compacted after a shuffle scan; a second
+// pass only if a tree outgrew its slots), batches of kWC candidates, the wave's own entries of
+// the batch in registers during the k arg-min rounds.  Same total order (distance, candidate
+// position) and the same distance reduction as the workgroup variant: identical results.
+// ---------------------------------------------------------------------------------------
+constexpr int kWC = 512;  // candidates per batch of one wave
+constexpr int kWR = 128;  // leaf ranges per query
+constexpr int kWT = 64;   // trees (lane = tree)
+// the variant is chosen when trees x minLeaf (~ candidates per query) is at most this
+constexpr int64_t kWaveCandidates = 1024;
+
+__device__ inline void wave_sync() {  // LDS writes of the wave visible to all its lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__host__ __device__ inline size_t fused_wave_bytes(int d, size_t acc_size) {
+  const size_t b = (size_t)kWC * 12 + (size_t)kWR * 24 + (size_t)kFK * 16 + (size_t)d * acc_size;
+  return (b + 15) & ~(size_t)15;
+}
+
+template <class TD, class TK>
+__global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
+    const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
+    const double* __restrict__ thr, const double* __restrict__ mglo,
+    const double* __restrict__ mghi, int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T,
+    int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
+    double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
+    unsigned int* ovf_count, unsigned long long* cand_total) {
+  typedef typename AccOf<TD>::type TA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  if (q >= nq) return;  // no workgroup barrier below
+  unsigned char* base = smem + (size_t)wave * fused_wave_bytes(d, sizeof(TA));
+  double* cdist = reinterpret_cast<double*>(base);                 // [kWC]
+  double* bdist = cdist + kWC;                                     // [kFK]
+  int64_t* rpoff = reinterpret_cast<int64_t*>(bdist + kFK);        // [kWR] compact, tree order
+  int64_t* spoff = rpoff + kWR;                                    // [kWR] per-tree slots
+  TA* qs = reinterpret_cast<TA*>(spoff + kWR);                     // [d]
+  int* cid = reinterpret_cast<int*>(base + (size_t)kWC * 8 + (size_t)kFK * 8 + (size_t)kWR * 16 +
+                                    (((size_t)d * sizeof(TA) + 7) & ~(size_t)7));  // [kWC]
+  int* rn = cid + kWC;                                             // [kWR]
+  int* sn = rn + kWR;                                              // [kWR]
+  int* bid = sn + kWR;                                             // [kFK]
+  int* bpos = bid + kFK;                                           // [kFK]
+
+  for (int j = lane; j < d; j += 64) qs[j] = ld<TD>(Q + q * d + j);
+
+  // ---- traversal: lane = tree; ranges into the tree's S slots, counted in any case ----
+  const int S = kWR / T;
+  int my_nc = 0, my_nr = 0;
+  if (lane < T) {
+    const int t = lane;
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                 nq, L, min_leaf, N, [&](int off, int n) {
+                   if (my_nr < S) {
+                     spoff[t * S + my_nr] = (int64_t)t * N + off;
+                     sn[t * S + my_nr] = n;
+                   }
+                   my_nc += n;
+                   ++my_nr;
+                 });
+  }
+  int inc_c = my_nc, inc_r = my_nr;  // inclusive scans over the trees
+  for (int o = 1; o < 64; o <<= 1) {
+    const int a = __shfl_up(inc_c, o), b = __shfl_up(inc_r, o);
+    if (lane >= o) {
+      inc_c += a;
+      inc_r += b;
+    }
+  }
+  const int nc_tot = __shfl(inc_c, 63), nr_tot = __shfl(inc_r, 63);
+  if (nr_tot > kWR) {  // too many leaf ranges for the slab: general path
+    if (lane == 0) {
+      ovf_flags[q] = 1u;
+      atomicAdd(ovf_count, 1u);
+    }
+    return;
+  }
+  if (lane == 0) atomicAdd(cand_total, (unsigned long long)nc_tot);
+  if (__ballot(my_nr > S) == 0ULL) {  // the usual case: compact the slots (a lane reads its own)
+    if (lane < T) {
+      const int r0 = inc_r - my_nr;
+      for (int r = 0; r < my_nr; ++r) {
+        rpoff[r0 + r] = spoff[lane * S + r];
+        rn[r0 + r] = sn[lane * S + r];
+      }
+    }
+  } else if (lane < T) {  // some tree reached more leaves than its slots hold: second pass
+    const int t = lane;
+    int r = inc_r - my_nr;
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                 nq, L, min_leaf, N, [&](int off, int n) {
+                   rpoff[r] = (int64_t)t * N + off;
+                   rn[r] = n;
+                   ++r;
+                 });
+  }
+  wave_sync();
+
+  constexpr int E = kWC / 64;  // batch entries a lane owns: lane, lane + 64, ...
+  const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+  int best = 0, r_next = 0, r_done = 0, pos_base = 0;
+  while (r_next < nr_tot || best == 0) {
+    // ---- fill the batch: best list first (keeps its positions), then new candidates ----
+    for (int i = lane; i < best; i += 64) {
+      cdist[i] = bdist[i];
+      cid[i] = bid[i];
+    }
+    int fill = best;
+    const int first_new = best, pb0 = pos_base;
+    int rr = r_next, rd = r_done, pb = pos_base;
+    while (rr < nr_tot && fill < kWC) {
+      int take = rn[rr] - rd;
+      if (take > kWC - fill) take = kWC - fill;
+      for (int i = lane; i < take; i += 64) cid[fill + i] = perm[rpoff[rr] + rd + i];
+      fill += take;
+      rd += take;
+      pb += take;
+      if (rd == rn[rr]) {
+        ++rr;
+        rd = 0;
+      }
+    }
+    r_next = rr;
+    r_done = rd;
+    pos_base = pb;
+    wave_sync();
+    batch_distances<TD, TA>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
+    wave_sync();
+    // ---- the lane's entries: distance and candidate position (-1 = none / consumed) ----
+    double dd[E];
+    int pp[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+      const int i = lane + 64 * s;
+      dd[s] = i < fill ? cdist[i] : kInf;
+      pp[s] = i < fill ? (i < first_new ? bpos[i] : pb0 + (i - first_new)) : -1;
+    }
+    wave_sync();  // bpos is rewritten below
+    // ---- selection: k rounds of wave-wide arg-min by (distance, position) ----
+    int nb = 0;
+    double last_d = -1.0;
+    while (nb < k) {
+      double bd = kInf;
+      int bp = 0x7fffffff, bi = -1;
+#pragma unroll
+      for (int s = 0; s < E; ++s)
+        if (pp[s] >= 0 && (dd[s] < bd || (dd[s] == bd && pp[s] < bp))) {
+          bd = dd[s];
+          bp = pp[s];
+          bi = lane + 64 * s;
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double od = __shfl_xor(bd, o);
+        const int op = __shfl_xor(bp, o), oi = __shfl_xor(bi, o);
+        if (od < bd || (od == bd && op < bp)) {
+          bd = od;
+          bp = op;
+          bi = oi;
+        }
+      }
+      if (bi < 0) break;  // candidates exhausted
+#pragma unroll
+      for (int s = 0; s < E; ++s)
+        if (bi == lane + 64 * s) pp[s] = -1;  // consumed
+      bool keep = true;
+      if (dedup == 2 && nb > 0 && bd == last_d) keep = false;  // knnPQ: one per distance
+      else if (dedup && bd == last_d)  // same id => same distance: duplicates are among equal dist
+        for (int j = nb - 1; j >= 0 && bdist[j] == bd; --j)
+          if (bid[j] == cid[bi]) keep = false;
+      if (keep) {
+        if (lane == 0) {
+          bdist[nb] = bd;
+          bid[nb] = cid[bi];
+          bpos[nb] = bp;
+        }
+        wave_sync();
+        ++nb;
+        last_d = bd;
+      }
+    }
+    best = nb;
+    if (r_next >= nr_tot) break;
+  }
+  for (int i = lane; i < k; i += 64) {
+    const bool ok = i < best;
+    out_ids[q * k + i] = ok ? bid[i] : -1;
+    out_dist[q * k + i] = ok ? bdist[i] : kInf;
+  }
+  if (lane == 0) out_cnt[q] = best;
 }
 
 // CSR data and CSR queries: the query is densified into LDS; distance of a sparse row x:
@@ -835,12 +1056,15 @@ __global__ __launch_bounds__(256) void dist_sel_csr_kernel(
   }
 }
 
-// multi-GPU merge: G shard results per query, shard-major [G][nq][k]
+// multi-GPU merge: G shard results per query; shard g's [nq][k] ids / distances and [nq] counts
+// start g * sstride BYTES after the base pointers (shard-major arrays: sstride = the array's
+// own size; one packed exchange record per shard: sstride = the record size)
 __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ ids,
                                                     const double* __restrict__ dist,
-                                                    const int32_t* __restrict__ cnt, int G,
-                                                    int64_t nq, int k, int dedup,
-                                                    int32_t* __restrict__ out_ids,
+                                                    const int32_t* __restrict__ cnt,
+                                                    int64_t ids_stride, int64_t dist_stride,
+                                                    int64_t cnt_stride, int G, int64_t nq, int k,
+                                                    int dedup, int32_t* __restrict__ out_ids,
                                                     double* __restrict__ out_dist,
                                                     int32_t* __restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -850,17 +1074,23 @@ __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ 
   Entry* buf = reinterpret_cast<Entry*>(smem);
   int* scratch = reinterpret_cast<int*>(smem + sizeof(Entry) * np);
   const int64_t q = blockIdx.x;
+  auto shard_cnt = [&](int g) {
+    return reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(cnt) + g * cnt_stride)[q];
+  };
   // invalid slots sort last: dist = +inf, pos keeps shard order
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int g = i / k, r = i % k;
-    const bool ok = r < cnt[(int64_t)g * nq + q];
-    const int64_t src = ((int64_t)g * nq + q) * k + r;
-    buf[i] = Entry{ok ? dist[src] : __longlong_as_double(0x7ff0000000000000LL), i,
-                   ok ? ids[src] : -1};
+    const bool ok = r < shard_cnt(g);
+    const int64_t src = q * k + r;
+    const double* dg =
+        reinterpret_cast<const double*>(reinterpret_cast<const char*>(dist) + g * dist_stride);
+    const int32_t* ig =
+        reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ids) + g * ids_stride);
+    buf[i] = Entry{ok ? dg[src] : __longlong_as_double(0x7ff0000000000000LL), i, ok ? ig[src] : -1};
   }
   __syncthreads();
   int valid = 0;
-  for (int g = 0; g < G; ++g) valid += cnt[(int64_t)g * nq + q];
+  for (int g = 0; g < G; ++g) valid += shard_cnt(g);
   int best = merge_best(buf, total, k, dedup, scratch);
   // merge_best counted +inf padding as entries: clamp to the valid ones (dedup can only
   // shrink further; invalid entries have id -1 and sort last)
@@ -979,12 +1209,31 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                             int32_t* ids, double* dist, int32_t* cnt, unsigned int* ovf,
                             unsigned long long* cand_total) {
   typedef typename AccOf<TD>::type TA;
+  // small shards (few trees => a few hundred candidates per query): one wave per query
+  const char* force = getenv("RPT_KNN_WAVE");
+  const size_t wbytes = fused_wave_bytes(data->d, sizeof(TA));
+  bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 &&
+              (int64_t)f->T * f->min_leaf <= kWaveCandidates;
+  if (force) wave = force[0] == '1' && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
+  ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
+  if (wave) {
+    const size_t smem = 4 * wbytes;
+    if (smem > 64 * 1024)
+      RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_wave_kernel<TD, TK>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((knn_fused_wave_kernel<TD, TK>), dim3((unsigned)((q->n + 3) / 4)),
+                       dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
+                       (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
+                       (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
+                       cnt, ovf + 1, ovf, cand_total);
+    RPT_HIP(hipGetLastError());
+    return RPT_OK;
+  }
   const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFK * 16 +
                       (size_t)data->d * sizeof(TA) + 64;
   if (smem > 64 * 1024)
     RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   hipLaunchKernelGGL((knn_fused_kernel<TD, TK>), dim3((unsigned)q->n), dim3(256), smem,
                      ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                      f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
@@ -1210,8 +1459,9 @@ int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_da
 }
 
 int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
-                      const int32_t* count_dev, int32_t G, int64_t nq, int32_t k, int32_t flags,
-                      int32_t* out_ids, double* out_dist, int32_t* out_count) {
+                      const int32_t* count_dev, int64_t shard_stride, int32_t G, int64_t nq,
+                      int32_t k, int32_t flags, int32_t* out_ids, double* out_dist,
+                      int32_t* out_count) {
   if (nq == 0) return RPT_OK;
   int np = 1;
   while (np < G * k) np <<= 1;
@@ -1219,9 +1469,12 @@ int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_d
   if (smem > 64 * 1024)
     RPT_HIP(hipFuncSetAttribute((const void*)merge_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  // shard_stride 0: three shard-major arrays [G][nq][k], [G][nq][k], [G][nq]
+  const int64_t is = shard_stride ? shard_stride : nq * k * 4, ds = shard_stride ? shard_stride : nq * k * 8,
+                cs = shard_stride ? shard_stride : nq * 4;
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, ctx->stream, ids_dev,
-                     dist_dev, count_dev, G, nq, k, flags & 3, out_ids,
-                     out_dist, out_count);
+                     dist_dev, count_dev, is, ds, cs, G, nq, k, flags & 3, out_ids, out_dist,
+                     out_count);
   RPT_HIP(hipGetLastError());
   return RPT_OK;
 }

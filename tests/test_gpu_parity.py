@@ -365,6 +365,106 @@ def test_knn_merge_shards(rp, ctx, small_forest, oracle):
     assert np.array_equal(od.cpu().numpy(), full[1])
 
 
+def test_knn_merge_records_equals_merge(rp, ctx, small_forest):
+    """rpt_knn_merge_records_dev over packed exchange records (one all-gather) == rpt_knn_merge_dev
+    over the three shard-major arrays; the record is filled directly by rpt_knn_dev."""
+    import torch
+    from rptree_amd import _lib, sharded
+    X, f, fo, Q = small_forest
+    k, nq = 10, len(Q)
+    R = f.R
+    shards = [rp.forestBatch(0, f.L, f.min_leaf, 2, 0, f.d, X, ctx=ctx, hyperplanes=R[:2]),
+              rp.forestBatch(0, f.L, f.min_leaf, 3, 0, f.d, X, ctx=ctx, hyperplanes=R[2:])]
+    ds, qs = rp.Dataset.of(ctx, X), rp.Dataset.of(ctx, Q)
+    L_ = _lib.lib()
+    recs = []
+    for sh in shards:
+        rec = sharded.ExchangeRecord(nq, k, torch.device("cuda", 0))
+        _lib.check(L_.rpt_knn_dev(ctx._h, sh._h, ds._h, qs._h, k, 0, rec.ids.data_ptr(),
+                                  rec.dist.data_ptr(), rec.count.data_ptr()))
+        recs.append(rec)
+    ctx.sync()
+    assert recs[0].bytes % 16 == 0
+    gathered = torch.stack([r.buf for r in recs]).contiguous()       # what the all-gather returns
+    for g, sh in enumerate(shards):                                  # the views address shard g
+        want = rp.knnBatch(k, sh, Q)
+        vi, vd, vc = sharded.ExchangeRecord.views_of(gathered, g, nq, k)
+        assert np.array_equal(vi.cpu().numpy(), want[0]) and np.array_equal(vd.cpu().numpy(), want[1])
+        assert np.array_equal(vc.cpu().numpy(), want[2])
+    outs = []
+    for packed in (True, False):
+        oi = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        od = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+        oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        if packed:
+            _lib.check(L_.rpt_knn_merge_records_dev(ctx._h, gathered.data_ptr(), recs[0].bytes, 2,
+                                                    nq, k, 0, oi.data_ptr(), od.data_ptr(),
+                                                    oc.data_ptr()))
+        else:
+            ids = torch.stack([r.ids for r in recs]).contiguous()
+            dd = torch.stack([r.dist for r in recs]).contiguous()
+            cc = torch.stack([r.count for r in recs]).contiguous()
+            torch.cuda.synchronize()
+            _lib.check(L_.rpt_knn_merge_dev(ctx._h, ids.data_ptr(), dd.data_ptr(), cc.data_ptr(), 2,
+                                            nq, k, 0, oi.data_ptr(), od.data_ptr(), oc.data_ptr()))
+        ctx.sync()
+        outs.append((oi.cpu().numpy(), od.cpu().numpy(), oc.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    full = rp.knnBatch(k, f, Q)
+    assert np.array_equal(outs[0][0], full[0]) and np.array_equal(outs[0][1], full[1])
+    with pytest.raises(_lib.RPTError):                               # record smaller than the layout
+        _lib.check(L_.rpt_knn_merge_records_dev(ctx._h, gathered.data_ptr(), 8, 2, nq, k, 0,
+                                                oi.data_ptr(), od.data_ptr(), oc.data_ptr()))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_knn_wave_and_workgroup_variants_agree_with_oracle(rp, ctx, oracle, monkeypatch, dtype):
+    """The fused query kernel has a one-wave-per-query variant (small shards) and a
+    one-workgroup-per-query variant; both must give the oracle's ids/distances, including
+    batches beyond the per-wave capacity (512 candidates), trees that outgrow their range
+    slots (second traversal pass) and every duplicate rule."""
+    n, d, T, ml, k = 6000, 24, 6, 60, 12
+    X = oracle.data_normal_dense2(77, n, d)
+    Q = oracle.data_normal_dense2(78, 40, d)
+    if dtype == "f32":
+        X, Q = X.astype(np.float32), Q.astype(np.float32)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(5, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    res = {}
+    for force in ("1", "0"):
+        monkeypatch.setenv("RPT_KNN_WAVE", force)
+        res[force] = [rp.knnBatch(k, f, Q, dedup=m) for m in (0, 1, 2)]
+    monkeypatch.delenv("RPT_KNN_WAVE")
+    for m in range(3):
+        for a, b in zip(res["1"][m], res["0"][m]):
+            assert np.array_equal(a, b)
+    if dtype == "f64":
+        fo = oracle.forest_build_dense(X, R, ml)
+        ids, dist, cnt = res["1"][0]
+        for i in range(len(Q)):
+            wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+            assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=0)
+    # a wide-margin forest: many leaves per tree per query (slots overflow -> second pass)
+    X2 = oracle.data_normal_dense2(79, 3000, 4)
+    if dtype == "f32":
+        X2 = X2.astype(np.float32)
+    L2, _, pnz2 = oracle.tree_cfg(8, 3000, 4)
+    R2, _ = oracle.forest_hyperplanes(6, 16, L2, pnz2, 4)
+    f2 = rp.forestBatch(0, L2, 8, 16, pnz2, 4, X2, ctx=ctx, hyperplanes=R2, mode=rp.RPT_PROJ_EXACT)
+    Q2 = X2[:64] * 1.0001
+    out = {}
+    for force in ("1", "0"):
+        monkeypatch.setenv("RPT_KNN_WAVE", force)
+        out[force] = rp.knnBatch(5, f2, Q2)
+    monkeypatch.delenv("RPT_KNN_WAVE")
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+
+
 def test_forest_save_load_roundtrip(rp, ctx, small_forest, tmp_path):
     X, f, fo, Q = small_forest
     path = str(tmp_path / "forest.npz")

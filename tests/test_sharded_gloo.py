@@ -75,6 +75,18 @@ def _worker(rank, world, port, out):
             ok = ok and np.array_equal(oi[i, :len(a)], a) and np.array_equal(od[i, :len(a)], b)
     # shard layout: slot g of the gathered tensor is rank g's list
     ok = ok and np.array_equal(gi[rank].numpy(), ids)
+    # the packed exchange record (ONE all-gather): same content, shard-major, layout from the C ABI
+    rec = sharded.ExchangeRecord(nq, k, torch.device("cpu"))
+    rec.ids.copy_(torch.from_numpy(ids))
+    rec.dist.copy_(torch.from_numpy(dd))
+    rec.count.copy_(torch.from_numpy(cnt))
+    gathered = sharded.gather_records(rec)
+    ok = ok and tuple(gathered.shape) == (world, rec.bytes)
+    for g in range(world):
+        vi, vd, vc = sharded.ExchangeRecord.views_of(gathered, g, nq, k)
+        ok = ok and torch.equal(vi, gi[g]) and torch.equal(vd, gd[g]) and torch.equal(vc, gc[g])
+    g2 = sharded.gather_records(rec, via_host=True)
+    ok = ok and torch.equal(g2, gathered)
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -85,6 +97,22 @@ def test_tree_shard():
     assert [sharded.tree_shard(32, 8, r) for r in (0, 3, 7)] == [(0, 4), (12, 16), (28, 32)]
     with pytest.raises(ValueError):
         sharded.tree_shard(10, 4, 0)
+
+
+def test_record_layout():
+    from rptree_amd import sharded
+    nq, k = 1000, 10
+    b, od, oi, oc = sharded.record_layout(nq, k)
+    assert (od, oi, oc) == (0, nq * k * 8, nq * k * 12)
+    assert b % 16 == 0 and nq * k * 12 + nq * 4 <= b < nq * k * 12 + nq * 4 + 16
+    rec = sharded.ExchangeRecord(7, 3, torch.device("cpu"))
+    rec.dist.fill_(1.5)
+    rec.ids.fill_(-2)
+    rec.count.fill_(3)
+    raw = rec.buf.numpy()
+    assert np.all(raw[:7 * 3 * 8].view(np.float64) == 1.5)
+    assert np.all(raw[7 * 3 * 8:7 * 3 * 12].view(np.int32) == -2)
+    assert np.all(raw[7 * 3 * 12:7 * 3 * 12 + 28].view(np.int32) == 3)
 
 
 def test_sharded_knn_protocol_gloo(oracle):
