@@ -104,7 +104,15 @@ __device__ inline void wsync() {
 // In-LDS bitonic sort of np (power of two) (key, id) pairs by Keys::less.  All threads of
 // the block must call it; with WAVE the region belongs to the calling wave alone and only its
 // 64 lanes take part (no workgroup barrier).
-template <class TK, bool WAVE = false>
+// (key, id) order without the earlier levels' keys: branch-free.  It equals Keys::less unless
+// two REAL entries have equal keys; callers that use it check the sorted neighbours for that and
+// re-sort with the exact comparator (never on continuous data, always on tie-heavy data).
+template <class TK>
+__device__ inline bool fast_less(TK ka, int a, TK kb, int b) {
+  return (ka < kb) | ((ka == kb) & (a < b));
+}
+
+template <class TK, bool WAVE = false, bool FAST = false>
 __device__ void lds_bitonic(TK* skey, int* sid, int np, const Keys<TK>& K) {
   const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   const int nthr = WAVE ? 64 : (int)blockDim.x;
@@ -116,8 +124,8 @@ __device__ void lds_bitonic(TK* skey, int* sid, int np, const Keys<TK>& K) {
         const bool up = (lo & k) == 0;
         const TK kl = skey[lo], kh = skey[hi];
         const int il = sid[lo], ih = sid[hi];
-        const bool h_lt_l = K.less(kh, ih, kl, il);
-        const bool l_lt_h = K.less(kl, il, kh, ih);
+        const bool h_lt_l = FAST ? fast_less(kh, ih, kl, il) : K.less(kh, ih, kl, il);
+        const bool l_lt_h = FAST ? fast_less(kl, il, kh, ih) : K.less(kl, il, kh, ih);
         if (up ? h_lt_l : l_lt_h) {
           skey[lo] = kh;
           skey[hi] = kl;
@@ -151,7 +159,7 @@ __device__ inline float pos_inf<float>() { return __uint_as_float(0x7f800000u); 
 // Bitonic sort of NR*64 (key, id) pairs held NR per lane (index = r*64 + lane) by one wave:
 // partners at distance >= 64 are other registers of the same lane, closer partners come
 // through lane shuffles.  No LDS, no barrier.
-template <class TK, int NR, int KK, int J>
+template <class TK, int NR, int KK, int J, bool FAST = false>
 __device__ inline void wave_bitonic_stage(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K, int lane) {
   if constexpr (J >= 64) {
     constexpr int JR = J >> 6;
@@ -160,7 +168,7 @@ __device__ inline void wave_bitonic_stage(TK (&k)[NR], int (&id)[NR], const Keys
       if ((r & JR) == 0) {
         const int r2 = r + JR;
         const bool up = ((r * 64) & KK) == 0;  // KK >= 128: the direction bit lives in r
-        const bool hi_lt_lo = K.less(k[r2], id[r2], k[r], id[r]);
+        const bool hi_lt_lo = FAST ? fast_less(k[r2], id[r2], k[r], id[r]) : K.less(k[r2], id[r2], k[r], id[r]);
         if (up ? hi_lt_lo : !hi_lt_lo) {
           const TK tk = k[r];
           k[r] = k[r2];
@@ -182,25 +190,51 @@ __device__ inline void wave_bitonic_stage(TK (&k)[NR], int (&id)[NR], const Keys
       // take part in the exchange)
       asm volatile("" : "+v"(ok), "+v"(oi));
       const bool up = ((r * 64 + lane) & KK) == 0;
-      const bool o_lt_me = K.less(ok, oi, k[r], id[r]);
+      const bool o_lt_me = FAST ? fast_less(ok, oi, k[r], id[r]) : K.less(ok, oi, k[r], id[r]);
       if ((lower == up) ? o_lt_me : !o_lt_me) {
         k[r] = ok;
         id[r] = oi;
       }
     }
   }
-  if constexpr (J > 1) wave_bitonic_stage<TK, NR, KK, (J >> 1)>(k, id, K, lane);
+  if constexpr (J > 1) wave_bitonic_stage<TK, NR, KK, (J >> 1), FAST>(k, id, K, lane);
 }
 
-template <class TK, int NR, int KK>
+template <class TK, int NR, int KK, bool FAST = false>
 __device__ inline void wave_bitonic_phase(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K, int lane) {
-  wave_bitonic_stage<TK, NR, KK, (KK >> 1)>(k, id, K, lane);
-  if constexpr (KK < 64 * NR) wave_bitonic_phase<TK, NR, (KK << 1)>(k, id, K, lane);
+  wave_bitonic_stage<TK, NR, KK, (KK >> 1), FAST>(k, id, K, lane);
+  if constexpr (KK < 64 * NR) wave_bitonic_phase<TK, NR, (KK << 1), FAST>(k, id, K, lane);
 }
 
-template <class TK, int NR>
+template <class TK, int NR, bool FAST = false>
 __device__ inline void wave_bitonic(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K) {
-  wave_bitonic_phase<TK, NR, 2>(k, id, K, threadIdx.x & 63);
+  wave_bitonic_phase<TK, NR, 2, FAST>(k, id, K, threadIdx.x & 63);
+}
+
+// the same sort, branch-free comparator first; the exact one only if two real neighbours of the
+// sorted sequence have equal keys (then the earlier levels' keys decide their order)
+template <class TK, int NR>
+__device__ inline void wave_bitonic_fast(TK (&k)[NR], int (&id)[NR], const Keys<TK>& K) {
+  const int lane = threadIdx.x & 63;
+  wave_bitonic<TK, NR, true>(k, id, K);
+  bool eq = false;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    TK nk = __shfl_down(k[r], 1);
+    int ni = __shfl_down(id[r], 1);
+    if (r + 1 < NR) {  // lane 63's successor is lane 0 of the next register
+      const TK fk = __shfl(k[r + 1 < NR ? r + 1 : r], 0);
+      const int fi = __shfl(id[r + 1 < NR ? r + 1 : r], 0);
+      if (lane == 63) {
+        nk = fk;
+        ni = fi;
+      }
+    } else if (lane == 63) {
+      ni = kPad;
+    }
+    eq |= id[r] != kPad && ni != kPad && k[r] == nk;
+  }
+  if (__ballot(eq)) wave_bitonic<TK, NR, false>(k, id, K);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2088,11 +2122,11 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
   if (cMid <= 64) {
     TK k1[1] = {k[0]};
     int i1[1] = {id[0]};
-    wave_bitonic<TK, 1>(k1, i1, K);
+    wave_bitonic_fast<TK, 1>(k1, i1, K);
     k[0] = k1[0];
     id[0] = i1[0];
   } else {
-    wave_bitonic<TK, 2>(k, id, K);
+    wave_bitonic_fast<TK, 2>(k, id, K);
   }
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
   uint16_t* no = A.node_of + (int64_t)t * N;
@@ -2183,7 +2217,13 @@ __device__ inline void mid_lds_path(const MidArgs<TK>& A, const SNode<TK>& a, in
   }
   if (WAVE) wsync();
   else __syncthreads();
-  lds_bitonic<TK, WAVE>(skey, sid, np, K);
+  lds_bitonic<TK, WAVE, true>(skey, sid, np, K);
+  {  // equal keys among real neighbours: the exact comparator decides (see fast_less)
+    int eq = 0;
+    for (int i = tid; i + 1 < cMid; i += nthr) eq |= skey[i] == skey[i + 1];
+    const bool any = WAVE ? __ballot(eq) != 0ULL : __syncthreads_or(eq) != 0;
+    if (any) lds_bitonic<TK, WAVE, false>(skey, sid, np, K);
+  }
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
   uint16_t* no = A.node_of + (int64_t)t * N;
   const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
