@@ -77,3 +77,43 @@ for name, Pn in res.items():
                 w0 + idx[:, 1].min().item(), w0 + idx[:, 1].max().item()))
     print("%-9s max |err| / (|x||r|) over three 4096-point windows = %.2e (%d entries above 1e-5)"
           % (name, worst, bad))
+
+# ---- a C5-shaped shard end to end: 16 trees, minLeaf 256, k = 50 ----
+if len(sys.argv) > 4 and sys.argv[4] == "build":
+    T, min_leaf, k, nq = 16, 256, 50, 10_000
+    cfg = rp.rpTreeCfg(min_leaf, N, d)
+    _, Rf = rp.gen.forest_hyperplanes(99, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
+    Q = X[torch.randint(0, N, (nq,), device=dev, generator=g)].clone()
+    qs = rp.Dataset.dense_device(ctx, Q.data_ptr(), nq, d, rp.RPT_BF16, keep=Q)
+    torch.cuda.synchronize()
+    for name, env in (("bf16x3", None), ("f32-mfma", "1")):
+        if env:
+            os.environ["RPT_PROJ_BF16_F32"] = env
+        else:
+            os.environ.pop("RPT_PROJ_BF16_F32", None)
+        for it in range(3):
+            ctx.sync()
+            t0 = time.perf_counter()
+            f = rp._build(ctx, ds, Rf, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_MFMA)
+            ctx.sync()
+            t1 = time.perf_counter()
+            if it < 2:
+                f.close()
+        print("%-9s build (T %d, L %d): %.2f ms = %.1f M vectors/s" % (
+            name, T, cfg.fpMaxTreeDepth, (t1 - t0) * 1e3, N / (t1 - t0) / 1e6), flush=True)
+        if env is None:
+            perm = f.perm
+            assert np.array_equal(np.bincount(perm[0], minlength=N), np.ones(N, dtype=np.int64))
+            ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+            dist = torch.empty((nq, k), dtype=torch.float64, device=dev)
+            cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+            for it in range(2):
+                ctx.sync()
+                t0 = time.perf_counter()
+                _lib.check(L_.rpt_knn_dev(ctx._h, f._h, ds._h, qs._h, k, 0, ids.data_ptr(),
+                                          dist.data_ptr(), cnt.data_ptr()))
+                ctx.sync()
+                t1 = time.perf_counter()
+            print("          knn k=%d: %d queries in %.2f ms = %.2f M queries/s; self hit first: %.3f" % (
+                k, nq, (t1 - t0) * 1e3, nq / (t1 - t0) / 1e6, float((dist[:, 0] < 1e-3).double().mean())))
+        f.close()
