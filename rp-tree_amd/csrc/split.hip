@@ -2266,10 +2266,211 @@ __device__ inline void mid_lds_path(const MidArgs<TK>& A, const SNode<TK>& a, in
   }
 }
 
+// Large pivot bins (the first levels; every level of a 10 M-point shard): SELECTION instead of
+// a sort.  The split needs the element of rank kk in the pivot bin, its two neighbours' keys and
+// every element's side — not the order.  One linear pass bins the keys into 1024 sub-bins of
+// the bin's own [min, max] (any monotone map keeps the split exact), a scan finds the sub-bin
+// holding rank kk, and only that sub-bin's elements — which include every key tied with the
+// threshold — are sorted with the exact comparator (one wave, <= 128 elements; more, i.e.
+// heavy ties: the caller falls back to the full LDS sort).  Elements of lower / higher sub-bins
+// go left / right unsorted; the neighbours outside the candidates are the max below / min above.
+// Whole block (256 threads); smem holds the list (keys, ids).  Returns false for the fallback.
+template <class TK>
+__device__ inline bool mid_select_path(const MidArgs<TK>& A, const SNode<TK>& a, int t, int j,
+                                       unsigned char* smem) {
+  __shared__ int sel_hist[1024];
+  __shared__ unsigned long long sel_red[8];
+  __shared__ int sel_misc[4];   // [0] sub-bin, [1] below, [2] m, [3] candidate cursor
+  __shared__ int sel_cand[128];
+  const int cMid = a.cMid, M = A.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t N = A.N;
+  TK* skey = reinterpret_cast<TK*>(smem);
+  int* sid = reinterpret_cast<int*>(smem + (size_t)cMid * sizeof(TK));
+  const int32_t* m = A.pool + (int64_t)t * N + a.midoff;
+  const TK* mk = A.poolkey + (int64_t)t * N + a.midoff;
+  unsigned long long omn = ~0ULL, omx = 0ULL;
+  for (int i = tid; i < cMid; i += 256) {
+    const TK k = mk[i];
+    skey[i] = k;
+    sid[i] = m[i];
+    const unsigned long long o = ord_of(k);
+    omn = o < omn ? o : omn;
+    omx = o > omx ? o : omx;
+  }
+  for (int i = tid; i < 1024; i += 256) sel_hist[i] = 0;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long p = __shfl_xor(omn, o), q = __shfl_xor(omx, o);
+    omn = p < omn ? p : omn;
+    omx = q > omx ? q : omx;
+  }
+  if (lane == 0) {
+    sel_red[wave] = omn;
+    sel_red[4 + wave] = omx;
+  }
+  if (tid == 0) sel_misc[3] = 0;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    omn = sel_red[w] < omn ? sel_red[w] : omn;
+    omx = sel_red[4 + w] > omx ? sel_red[4 + w] : omx;
+  }
+  const TK kmin = ord_to(omn, TK()), kmax = ord_to(omx, TK());
+  if (!(kmin < kmax)) return false;  // one value: the exact comparator has to order all of it
+  const double inv = 1024.0 / ((double)kmax - (double)kmin);
+  auto sub_of = [&](TK k) -> int {
+    const int b = (int)(((double)k - (double)kmin) * inv);
+    return b > 1023 ? 1023 : b;
+  };
+  for (int i = tid; i < cMid; i += 256) atomicAdd(&sel_hist[sub_of(skey[i])], 1);
+  __syncthreads();
+  const int kk = a.nh - a.cL;  // rank (in the sorted pivot bin) of the threshold element
+  if (wave == 0) {  // scan of 1024 counters, 16 per lane
+    int c[16], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      c[q] = sel_hist[lane * 16 + q];
+      tot += c[q];
+    }
+    int inc = tot;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int p = __shfl_up(inc, o);
+      if (lane >= o) inc += p;
+    }
+    int run = inc - tot;  // elements before this lane's 16 sub-bins
+    if (kk >= run && kk < inc) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (kk >= run && kk < run + c[q]) {
+          sel_misc[0] = lane * 16 + q;
+          sel_misc[1] = run;
+          sel_misc[2] = c[q];
+        }
+        run += c[q];
+      }
+    }
+  }
+  __syncthreads();
+  const int sstar = sel_misc[0], below = sel_misc[1], mc = sel_misc[2];
+  if (mc > 128) return false;  // heavy ties around the threshold: full sort
+  // candidates; max key below / min key above them
+  unsigned long long lowmax = 0ULL, highmin = ~0ULL;
+  for (int i = tid; i < cMid; i += 256) {
+    const TK k = skey[i];
+    const int sb = sub_of(k);
+    if (sb == sstar) {
+      sel_cand[atomicAdd(&sel_misc[3], 1)] = i;
+    } else {
+      const unsigned long long o = ord_of(k);
+      if (sb < sstar) lowmax = o > lowmax ? o : lowmax;
+      else highmin = o < highmin ? o : highmin;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long p = __shfl_xor(lowmax, o), q = __shfl_xor(highmin, o);
+    lowmax = p > lowmax ? p : lowmax;
+    highmin = q < highmin ? q : highmin;
+  }
+  __syncthreads();  // sel_red is read above by every thread: rewrite only now
+  if (lane == 0) {
+    sel_red[wave] = lowmax;
+    sel_red[4 + wave] = highmin;
+  }
+  __syncthreads();
+  uint16_t* no = A.node_of + (int64_t)t * N;
+  const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
+  unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
+  const bool feed_next = A.has_next && cMid * 4 >= a.n;  // see mid_wave_path
+  auto place = [&](int id, int side) {
+    no[id] = (uint16_t)(2 * j + side);
+    if (feed_next) {
+      const unsigned long long o = ord_of(Pn[id]);
+      mn[side] = o < mn[side] ? o : mn[side];
+      mx[side] = o > mx[side] ? o : mx[side];
+    }
+  };
+  if (wave == 0) {
+    for (int w = 0; w < 4; ++w) {
+      lowmax = sel_red[w] > lowmax ? sel_red[w] : lowmax;
+      highmin = sel_red[4 + w] < highmin ? sel_red[4 + w] : highmin;
+    }
+    Keys<TK> K{A.P + (int64_t)t * A.L * N, N, A.level, nullptr};
+    TK k[2];
+    int id[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int q = r * 64 + lane;
+      const int i = q < mc ? sel_cand[q] : -1;
+      id[r] = i >= 0 ? sid[i] : kPad;
+      k[r] = i >= 0 ? skey[i] : pos_inf<TK>();
+    }
+    wave_bitonic_fast<TK, 2>(k, id, K);
+    // key at rank q of the sorted pivot bin, for q in [below - 1, below + mc]
+    const int n = a.n, nh = a.nh;
+    const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
+    const int ql = il - a.cL, qh = ih - a.cL;  // may leave the pivot bin: maxL / minR
+    TK vthr = (TK)0, vlo = (TK)0, vhi = (TK)0;
+    int have = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int q = below + r * 64 + lane;  // rank of this lane's element
+      if (r * 64 + lane < mc) {
+        place(id[r], q >= kk);
+        if (q == kk) {
+          vthr = k[r];
+          have |= 1;
+        }
+        if (q == ql) {
+          vlo = k[r];
+          have |= 2;
+        }
+        if (q == qh) {
+          vhi = k[r];
+          have |= 4;
+        }
+      }
+    }
+    const unsigned long long b1 = __ballot(have & 1), b2 = __ballot(have & 2), b4 = __ballot(have & 4);
+    const TK tthr = __shfl(vthr, __ffsll((long long)b1) - 1);
+    TK tlo, thi;
+    if (b2) tlo = __shfl(vlo, __ffsll((long long)b2) - 1);
+    else if (ql < 0) tlo = ord_to(a.maxL, TK());
+    else tlo = ord_to(lowmax, TK());   // ql == below - 1
+    if (b4) thi = __shfl(vhi, __ffsll((long long)b4) - 1);
+    else if (qh >= cMid) thi = ord_to(a.minR, TK());
+    else thi = ord_to(highmin, TK());  // qh == below + mc
+    if (lane == 0) {
+      const int64_t h = (int64_t)t * A.nodes + A.heap0 + j;
+      A.thr[h] = (double)tthr;
+      A.mglo[h] = (double)tlo;
+      A.mghi[h] = (double)thi;
+      if (nh > 0 && !(tlo < tthr)) atomicAdd(A.tie_count, 1ULL);
+    }
+  }
+  for (int i = tid; i < cMid; i += 256) {
+    const int sb = sub_of(skey[i]);
+    if (sb != sstar) place(sid[i], sb > sstar);
+  }
+  if (feed_next) {
+    for (int sd = 0; sd < 2; ++sd) {
+      unsigned long long x = mn[sd], y = mx[sd];
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long p = __shfl_xor(x, o), q = __shfl_xor(y, o);
+        x = p < x ? p : x;
+        y = q > y ? q : y;
+      }
+      if (lane == 0) {
+        if (x != ~0ULL) atomicMin(&A.cmin_next[(int64_t)t * 2 * M + 2 * j + sd], x);
+        if (y != 0ULL) atomicMax(&A.cmax_next[(int64_t)t * 2 * M + 2 * j + sd], y);
+      }
+    }
+  }
+  return true;
+}
+
 constexpr int kMidWaveLds = 512;  // pivot bins up to this size: LDS sort by one wave
 
 template <class TK>
-__global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, int wave_max) {
+__global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, int wave_max,
+                                                  int use_select /* 0: always the full sort */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int sbig[4];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, t = blockIdx.y;
@@ -2292,6 +2493,12 @@ __global__ __launch_bounds__(256) void stream_mid(const MidArgs<TK> A, int npb, 
     if (!sbig[q]) continue;  // block-uniform
     const int j = blockIdx.x * npb + q;
     const SNode<TK> a = A.nd[(int64_t)t * A.M + j];
+    // selection first (linear); the full LDS sort when ties make its candidate set too large
+    if (use_select && mid_select_path<TK>(A, a, t, j, smem)) {
+      __syncthreads();
+      continue;
+    }
+    __syncthreads();
     mid_lds_path<TK, false>(A, a, t, j, smem);
     __syncthreads();
   }
@@ -2744,6 +2951,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     DevBuf<TK> poolkey;      // keys of the pivot-bin lists, same indexing as pool
     RPT_TRY(poolkey.alloc((size_t)T * N));
     const int wave_max = getenv("RPT_NO_WMID") ? 0 : 128;
+    const int use_select = getenv("RPT_NO_MIDSELECT") ? 0 : 1;
     // nodes above this size get more than 4096 bins (RPT_STREAM_BIG_NODE: test hook)
     const int64_t big_node = getenv("RPT_STREAM_BIG_NODE") ? atoll(getenv("RPT_STREAM_BIG_NODE"))
                                                            : ((int64_t)1 << 21);
@@ -2788,7 +2996,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
                        has_next, snodes.p, pool, poolkey.p, cminN, cmaxN, (int64_t)M - 1, f->nodes,
                        f->thr.p, f->mglo.p, f->mghi.p, tie_count};
         hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)((M + npb - 1) / npb), (unsigned)T),
-                           dim3(256), smem, st, ma, npb, wave_max);
+                           dim3(256), smem, st, ma, npb, wave_max, use_select);
         std::swap(cmin, cminN);
         std::swap(cmax, cmaxN);
       }

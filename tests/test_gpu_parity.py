@@ -493,6 +493,32 @@ def test_knn_wave_and_workgroup_variants_agree_with_oracle(rp, ctx, oracle, monk
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("decimals", [None, 3, 1])
+def test_large_pivot_bins_selection_path(rp, ctx, oracle, monkeypatch, decimals):
+    """Pivot bins above 128 points at the first levels (400 000 points: ~250 per bin) are split
+    by SELECTION (sub-histogram of the bin, exact sort of the one sub-bin around the threshold);
+    continuous keys, keys with moderate ties (3 decimals: ties inside the sorted sub-bin, decided
+    by the earlier levels' keys) and heavy ties (1 decimal: the candidate set outgrows a wave and
+    the full LDS sort takes over) must all give the oracle's forest, as must the build with the
+    selection switched off."""
+    n, d, T, ml = 400_000, 6, 2, 64
+    X = oracle.data_normal_dense2(31, n, d)
+    if decimals is not None:
+        X = np.round(X, decimals)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    L = min(L, 9)
+    R, _ = oracle.forest_hyperplanes(8, T, L, 1.0, d)
+    if decimals is not None:
+        R = np.round(R, 1)          # projections of rounded data on rounded hyperplanes tie often
+    fo = oracle.forest_build_dense(X, R, ml)
+    f = rp.forestBatch(0, L, ml, T, 1.0, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    assert_forest_equal(f, fo)
+    monkeypatch.setenv("RPT_NO_MIDSELECT", "1")
+    g = rp.forestBatch(0, L, ml, T, 1.0, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    monkeypatch.delenv("RPT_NO_MIDSELECT")
+    assert_forest_equal(g, fo)
+
+
 def test_forest_save_load_roundtrip(rp, ctx, small_forest, tmp_path):
     X, f, fo, Q = small_forest
     path = str(tmp_path / "forest.npz")
