@@ -2908,7 +2908,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   {
     // measured at C2: with 32 bins per node (1024 nodes) an eighth of all points lands in pivot
     // bins and the exact resolution eats what the shorter wave phase saves -> 512 by default
-    int max_nodes = getenv("RPT_STREAM_MAXNODES") ? atoi(getenv("RPT_STREAM_MAXNODES")) : 512;
+    // (a level whose nodes would still be above the block kernel's 4096 points afterwards is
+    // cheaper streamed with coarse bins — large pivot bins are split by selection — than on the
+    // general path: 10 M-point shards stream one more level)
+    int max_nodes = getenv("RPT_STREAM_MAXNODES") ? atoi(getenv("RPT_STREAM_MAXNODES"))
+                                                  : (N / 1024 > kSmallCap ? 1024 : 512);
     if (max_nodes > kStreamMaxNodes) max_nodes = kStreamMaxNodes;
     while (Lstream < Lused && splits[(size_t)Lstream].size() == ((size_t)1 << Lstream) &&
            (1 << Lstream) <= max_nodes)
