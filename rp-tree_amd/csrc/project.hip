@@ -692,22 +692,23 @@ __global__ void split_A_bf16x3(const double* __restrict__ R, int d, int c0, int 
   }
 }
 
-template <int CBT, int NT /* 16-point tiles per wave */, bool RESIDENT /* d <= 128: both chunks stay in LDS */>
-__global__ __launch_bounds__(512) void proj_bf16x3(
+template <int CBT, int NT /* 16-point tiles per wave */, bool RESIDENT /* d <= 128: both chunks stay in LDS */,
+          int WAVES /* per workgroup */>
+__global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
     const __hip_bfloat16* __restrict__ X, int64_t n, int d, const uint4* __restrict__ Aimg,
     int nch /* even */, int c0, int ncol, float* __restrict__ P, int64_t ldp, int64_t ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds_a[];  // [2][CH16]
   constexpr int CH16 = kB3KC * 3 * CBT * 64;  // uint4 per chunk
-  constexpr int kB3NT = NT, kB3Pts = 8 * NT * 16;  // points per workgroup tile
-  constexpr int ST = CH16 / 512;              // uint4 a thread stages per chunk
+  constexpr int kB3NT = NT, kB3Pts = WAVES * NT * 16, NTHR = WAVES * 64;  // points per workgroup tile
+  constexpr int ST = CH16 / NTHR;              // uint4 a thread stages per chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nks = nch * kB3KC;                // k-steps per tile, a multiple of 4
   constexpr bool resident = RESIDENT;
   const int kg = 8 * (lane >> 4);             // the lane's k offset inside a k-step
   // prologue: chunk 0 (and chunk 1 when resident) into LDS
-  for (int s = 0; s < ST; ++s) lds_a[s * 512 + tid] = Aimg[s * 512 + tid];
+  for (int s = 0; s < ST; ++s) lds_a[s * NTHR + tid] = Aimg[s * NTHR + tid];
   if constexpr (resident)
-    for (int s = 0; s < ST; ++s) lds_a[CH16 + s * 512 + tid] = Aimg[CH16 + s * 512 + tid];
+    for (int s = 0; s < ST; ++s) lds_a[CH16 + s * NTHR + tid] = Aimg[CH16 + s * NTHR + tid];
   __syncthreads();
 
   // B fragment of k-step ks of tile t for n-tile nt: zero past d; rows past n clamped
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(512) void proj_bf16x3(
         if constexpr (!resident) {  // the chunk after this one (of the next tile at the end)
           const int cn = c + 1 == nch ? 0 : c + 1;
 #pragma unroll
-          for (int s = 0; s < ST; ++s) stage[s] = Aimg[(size_t)cn * CH16 + s * 512 + tid];
+          for (int s = 0; s < ST; ++s) stage[s] = Aimg[(size_t)cn * CH16 + s * NTHR + tid];
         }
         const uint4* ab = lds_a + h * CH16;
 #pragma unroll
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(512) void proj_bf16x3(
         }
         if constexpr (!resident) {
 #pragma unroll
-          for (int s = 0; s < ST; ++s) lds_a[(h ^ 1) * CH16 + s * 512 + tid] = stage[s];
+          for (int s = 0; s < ST; ++s) lds_a[(h ^ 1) * CH16 + s * NTHR + tid] = stage[s];
           __syncthreads();
         }
       }
@@ -1070,27 +1071,27 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
 }
 
 // bf16 rows of 16-byte granularity on the bf16 matrix pipe (see proj_bf16x3)
-template <int CBT, int NT>
+template <int CBT, int NT, int WAVES>
 int32_t launch_bf16x3_pass(rpt_ctx* ctx, const rpt_dataset* ds, const uint4* Aimg, int nch, int c0,
                            int ncol, float* P) {
-  const int64_t ntiles = (ds->n + 8 * NT * 16 - 1) / (8 * NT * 16);
+  const int64_t ntiles = (ds->n + WAVES * NT * 16 - 1) / (WAVES * NT * 16);
   int64_t blocks = ntiles < ctx->n_cu ? ntiles : ctx->n_cu;
   if (blocks < 1) blocks = 1;
   constexpr size_t smem = (size_t)2 * kB3KC * 3 * CBT * 64 * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
   if (nch == 2)
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true>), dim3((unsigned)blocks), dim3(512), smem,
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), smem,
                        ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
                        P, ds->n, ntiles);
   else
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false>), dim3((unsigned)blocks), dim3(512), smem,
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), smem,
                        ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
                        P, ds->n, ntiles);
   return RPT_OK;
@@ -1124,10 +1125,16 @@ int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, 
     ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
     // (four 16-point tiles per wave would halve the LDS fragment traffic per MFMA, but with the
     // 4-deep B ring that is 256 VGPRs + 300 bytes of scratch: two tiles it is)
-    if (ps.cbt == 8)
-      RPT_TRY((launch_bf16x3_pass<8, 2>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+    // rows of up to 128 elements (A resident in LDS, no staging): four waves of 64 points each
+    // — half the LDS fragment reads per MFMA, accumulators in AGPRs — are 14 % faster than
+    // eight waves of 32 points (4 M x 128 x 416: 2.98 -> 2.56 ms); with the chunked A stream of
+    // longer rows the single wave per SIMD hides less and loses (2 M x 768 x 256: 3.09 -> 3.27 ms)
+    if (ps.cbt == 8 && nch == 2)
+      RPT_TRY((launch_bf16x3_pass<8, 4, 4>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+    else if (ps.cbt == 8)
+      RPT_TRY((launch_bf16x3_pass<8, 2, 8>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
     else
-      RPT_TRY((launch_bf16x3_pass<4, 2>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<4, 2, 8>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
     off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
   }
   RPT_HIP(hipGetLastError());
