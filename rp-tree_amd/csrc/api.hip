@@ -439,6 +439,7 @@ int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int
 int32_t rpt_dataset_free(rpt_dataset* ds) {
   if (ds) dev_set_stream(ds->ctx->stream);
   if (!ds) return RPT_OK;
+  if (ds->shadow32) dev_free(ds->shadow32);
   if (ds->owns) {
     (void)hipSetDevice(ds->ctx->device);
     (void)stream_sync(ds->ctx->stream);

@@ -158,6 +158,10 @@ struct rpt_dataset {
   int32_t* col = nullptr;
   void* val = nullptr;
   int64_t nnz = 0;
+  // lazily built by the first kNN call on dense f64 data: f32 copy of X (the fused kernel ranks
+  // candidates on it before it computes exact distances of the survivors) and the largest row norm
+  mutable float* shadow32 = nullptr;
+  mutable double max_norm = -1.0;
 };
 
 struct rpt_forest {

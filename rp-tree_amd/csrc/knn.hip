@@ -18,9 +18,11 @@
 #include <hip/hip_bf16.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
 // written to cdist.  The waves taking part are numbered slot = 0 .. nslots-1; every row is
 // reduced by the same fixed butterfly whichever wave handles it, so the value does not depend
 // on the kernel variant.  Each wave keeps EIGHT load instructions in flight.
-template <class TD, class TA>
+template <class TD, class TA, int INFL = 8 /* load instructions in flight per wave */>
 __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d, const int* cid,
                                        double* cdist, const TA* qs, int first, int fill, int slot,
                                        int nslots, int lane) {
@@ -435,16 +437,16 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
     // short rows (<= 512 B): 64 / lpr rows per load instruction, eight instructions in flight
     struct alignas(16) Raw { TD v[VV]; };
     const int rpw = 64 / lpr, sub = lane / lpr, jl = (lane % lpr) * VV;
-    for (int i0 = first + slot * 8 * rpw; i0 < fill; i0 += nslots * 8 * rpw) {
-      TA s[8];
-      Raw x[8];
+    for (int i0 = first + slot * INFL * rpw; i0 < fill; i0 += nslots * INFL * rpw) {
+      TA s[INFL];
+      Raw x[INFL];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < INFL; ++u) {
         const int i = i0 + u * rpw + sub;
         x[u] = *reinterpret_cast<const Raw*>(X + (int64_t)cid[i < fill ? i : i0] * d + jl);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < INFL; ++u) {
         s[u] = (TA)0;
 #pragma unroll
         for (int v = 0; v < VV; ++v) {
@@ -514,14 +516,16 @@ constexpr int kFC = 2048;     // candidates per batch
 constexpr int kFR = 512;      // leaf ranges per query in LDS
 constexpr int kFK = 64;       // largest k served by the arg-min selection
 
-template <class TD, class TK>
+template <class TD, class TK, bool PRE32>
 __global__ __launch_bounds__(256) void knn_fused_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
     const double* __restrict__ thr, const double* __restrict__ mglo,
     const double* __restrict__ mghi, int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T,
     int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
-    unsigned int* ovf_count, unsigned long long* cand_total) {
+    unsigned int* ovf_count, unsigned long long* cand_total,
+    const float* __restrict__ Xf /* PRE32: f32 shadow of X */, double xmax /* max row norm */,
+    int k1 /* PRE32: entries kept by the f32 pass, the last one = the first excluded */) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* cdist = reinterpret_cast<double*>(smem);                 // [kFC]
@@ -535,13 +539,17 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   int* bid = reinterpret_cast<int*>(bdist + kFK);                  // [kFK]
   int* bpos = bid + kFK;                                           // [kFK]
   TA* qs = reinterpret_cast<TA*>(bpos + kFK);                      // [d]
+  float* qs32 = reinterpret_cast<float*>(qs + d);                  // [d] (PRE32)
   __shared__ int s_nr, s_nc;
-  __shared__ double s_red_d[4];
-  __shared__ int s_red_p[4], s_red_i[4];
+  __shared__ double s_qn;
+  __shared__ double s_red_d[8];
+  __shared__ int s_red_p[8], s_red_i[8];
 
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
+  if (PRE32)
+    for (int j = tid; j < d; j += 256) qs32[j] = (float)ld<TD>(Q + q * d + j);
 
   // ---- traversal 1: counts per tree ----
   for (int t = tid; t < T; t += 256) {
@@ -589,6 +597,81 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   }
   __syncthreads();
 
+  // ---- selection: ksel rounds of block-wide arg-min by (distance, position) over the batch
+  // entries [0, fill); the winners go to bdist / bid / bpos.  A thread keeps its eight entries
+  // in registers (a consumed one gets position -1), a round costs one arg-min over them, a
+  // butterfly, four LDS words and ONE barrier (the per-wave results alternate between two
+  // buffers) ----
+  auto select = [&](int fill, int ksel, int dedup) -> int {
+    constexpr int E = kFC / 256;
+    double dd[E];
+    int pp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = tid + 256 * e;
+      dd[e] = i < fill ? cdist[i] : __longlong_as_double(0x7ff0000000000000LL);
+      pp[e] = i < fill ? cpos[i] : -1;
+    }
+    int nb = 0, par = 0;
+    double last_d = -1.0;
+    while (nb < ksel) {
+      double bd = __longlong_as_double(0x7ff0000000000000LL);
+      int bp = 0x7fffffff, bi = -1;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (pp[e] >= 0 && (dd[e] < bd || (dd[e] == bd && pp[e] < bp))) {
+          bd = dd[e];
+          bp = pp[e];
+          bi = tid + 256 * e;
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double od = __shfl_xor(bd, o);
+        const int op = __shfl_xor(bp, o), oi = __shfl_xor(bi, o);
+        if (od < bd || (od == bd && op < bp)) {
+          bd = od;
+          bp = op;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        s_red_d[par * 4 + wave] = bd;
+        s_red_p[par * 4 + wave] = bp;
+        s_red_i[par * 4 + wave] = bi;
+      }
+      __syncthreads();
+      bd = s_red_d[par * 4];
+      bp = s_red_p[par * 4];
+      bi = s_red_i[par * 4];
+      for (int w = 1; w < 4; ++w)
+        if (s_red_d[par * 4 + w] < bd || (s_red_d[par * 4 + w] == bd && s_red_p[par * 4 + w] < bp)) {
+          bd = s_red_d[par * 4 + w];
+          bp = s_red_p[par * 4 + w];
+          bi = s_red_i[par * 4 + w];
+        }
+      par ^= 1;
+      if (bi < 0) break;  // candidates exhausted
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (bi == tid + 256 * e) pp[e] = -1;  // consumed
+      bool keep = true;
+      if (dedup == 2 && nb > 0 && bd == last_d) keep = false;  // knnPQ: one per distance
+      else if (dedup && bd == last_d)  // same id => same distance: duplicates are among equal dist
+        for (int j = nb - 1; j >= 0 && bdist[j] == bd; --j)
+          if (bid[j] == cid[bi]) keep = false;
+      if (keep) {
+        if (tid == 0) {
+          bdist[nb] = bd;
+          bid[nb] = cid[bi];
+          bpos[nb] = bp;
+        }
+        ++nb;
+        last_d = bd;
+      }
+    }
+    __syncthreads();  // the winners are visible; cdist / cid / cpos may be refilled
+    return nb;
+  };
+
   int best = 0;       // entries of the running best list
   int r_next = 0;     // next range to consume
   int r_done = 0;     // candidates of range r_next already consumed
@@ -624,70 +707,50 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     pos_base = pb;
     __syncthreads();
     // ---- distances of the new candidates ----
-    batch_distances<TD, TA>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
+    if constexpr (PRE32)
+      batch_distances<float, float, 16>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
+    else
+      batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     __syncthreads();
-    // ---- selection: k rounds of block-wide arg-min by (distance, position) ----
-    int nb = 0;
-    double last_d = -1.0;
-    while (nb < k) {
-      double bd = __longlong_as_double(0x7ff0000000000000LL);
-      int bp = 0x7fffffff, bi = -1;
-      for (int i = tid; i < fill; i += 256) {
-        const double dd = cdist[i];
-        const int pp = cpos[i];
-        if (pp >= 0 && (dd < bd || (dd == bd && pp < bp))) {
-          bd = dd;
-          bp = pp;
-          bi = i;
-        }
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        const double od = __shfl_xor(bd, o);
-        const int op = __shfl_xor(bp, o), oi = __shfl_xor(bi, o);
-        if (od < bd || (od == bd && op < bp)) {
-          bd = od;
-          bp = op;
-          bi = oi;
-        }
-      }
-      if (lane == 0) {
-        s_red_d[wave] = bd;
-        s_red_p[wave] = bp;
-        s_red_i[wave] = bi;
-      }
-      __syncthreads();
-      bd = s_red_d[0];
-      bp = s_red_p[0];
-      bi = s_red_i[0];
-      for (int w = 1; w < 4; ++w)
-        if (s_red_d[w] < bd || (s_red_d[w] == bd && s_red_p[w] < bp)) {
-          bd = s_red_d[w];
-          bp = s_red_p[w];
-          bi = s_red_i[w];
-        }
-      __syncthreads();
-      if (bi < 0) break;  // candidates exhausted
-      bool keep = true;
-      if (dedup == 2 && nb > 0 && bd == last_d) keep = false;  // knnPQ: one per distance
-      else if (dedup && bd == last_d)  // same id => same distance: duplicates are among equal dist
-        for (int j = nb - 1; j >= 0 && bdist[j] == bd; --j)
-          if (bid[j] == cid[bi]) keep = false;
-      if (tid == 0) {
-        if (keep) {
-          bdist[nb] = bd;
-          bid[nb] = cid[bi];
-          bpos[nb] = bp;
-        }
-        cpos[bi] = -1;  // consumed
-      }
-      __syncthreads();
-      if (keep) {
-        ++nb;
-        last_d = bd;
-      }
-    }
+    const int nb = select(fill, PRE32 ? k1 : k, PRE32 ? 0 : dedup);
     best = nb;
     if (r_next >= nr_tot) break;
+  }
+  if constexpr (PRE32) {
+    // ---- refine: exact distances of the entries the f32 pass kept; certify the cut ----
+    // The f32 distance of a row differs from the exact one by at most
+    //   err(x) = 2.1 u (|x| + |q|) + (d + 2) u dist32,  u = 2^-24
+    // (inputs rounded to f32, the differences, the f32 accumulation), so every candidate the
+    // f32 pass dropped has an exact distance >= F - err(F), F = the smallest dropped f32
+    // distance.  If that is not above the exact k-th distance the query goes to the exact path.
+    const bool cut = best == k1;                    // something was dropped
+    const double F = cut ? bdist[k1 - 1] : 0.0;
+    const int m = cut ? k1 - 1 : best;
+    if (wave == 0) {
+      double qn = 0.0;
+      for (int j = lane; j < d; j += 64) qn += (double)qs[j] * (double)qs[j];
+      for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+      if (lane == 0) s_qn = sqrt(qn);
+    }
+    for (int i = tid; i < m; i += 256) {
+      cid[i] = bid[i];
+      cpos[i] = bpos[i];
+    }
+    __syncthreads();
+    batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, wave, 4, lane);
+    __syncthreads();
+    best = select(m, k, 0);
+    if (cut && best > 0) {
+      const double u = 5.9604644775390625e-08;
+      const double err = 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F;
+      if (!(F - err > bdist[best - 1])) {
+        if (tid == 0) {
+          ovf_flags[q] = 1u;
+          atomicAdd(ovf_count, 1u);
+        }
+        return;
+      }
+    }
   }
   for (int i = tid; i < k; i += 256) {
     const bool ok = i < best;
@@ -1203,6 +1266,48 @@ static int32_t launch_topk_dense(rpt_ctx* ctx, const rpt_dataset* data, const rp
   return RPT_OK;
 }
 
+// f32 shadow of a dense f64 dataset + its largest row norm (one wave per row)
+__global__ __launch_bounds__(256) void shadow32_kernel(const double* __restrict__ X, int64_t n, int d,
+                                                       float* __restrict__ Xf,
+                                                       unsigned long long* __restrict__ max_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  double mx = 0.0;
+  for (int64_t r = row0; r < n; r += (int64_t)gridDim.x * 4) {
+    double s = 0.0;
+    for (int j = lane; j < d; j += 64) {
+      const double v = X[r * d + j];
+      Xf[r * d + j] = (float)v;
+      s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    mx = s > mx ? s : mx;
+  }
+  if (lane == 0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));  // mx >= 0
+}
+
+static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
+  if (data->shadow32) return RPT_OK;
+  void* p = nullptr;
+  if (dev_alloc(&p, (size_t)data->n * data->d * sizeof(float)) != hipSuccess)
+    return fail(RPT_E_NOMEM, "f32 shadow of the dataset");
+  DevBuf<unsigned long long> mb;
+  RPT_TRY(mb.alloc(1));
+  RPT_HIP(hipMemsetAsync(mb.p, 0, 8, ctx->stream));
+  int64_t blocks = (data->n + 3) / 4;
+  if (blocks > (int64_t)ctx->n_cu * 16) blocks = (int64_t)ctx->n_cu * 16;
+  hipLaunchKernelGGL(shadow32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                     (const double*)data->X, data->n, data->d, (float*)p, mb.p);
+  unsigned long long bits = 0;
+  RPT_HIP(hipMemcpyAsync(&bits, mb.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  RPT_HIP(stream_sync(ctx->stream));
+  double m2;
+  std::memcpy(&m2, &bits, 8);
+  data->shadow32 = (float*)p;
+  data->max_norm = std::sqrt(m2) * (1.0 + 1e-12);
+  return RPT_OK;
+}
+
 template <class TD, class TK>
 static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                             const rpt_dataset* q, const void* Pq, int32_t k, int dedup,
@@ -1230,14 +1335,32 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
     return RPT_OK;
   }
   const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFK * 16 +
-                      (size_t)data->d * sizeof(TA) + 64;
+                      (size_t)data->d * (sizeof(TA) + 4) + 64;
+  // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
+  // bytes), exact distances for the best k' only, cut certified per query (see the kernel)
+  if constexpr (std::is_same<TD, double>::value) {
+    const int kp = 2 * k + 12 < 32 ? 32 : 2 * k + 12;
+    if (dedup == 0 && kp + 1 <= kFK && !getenv("RPT_KNN_NO_PRE32") && data->shadow32) {
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL((knn_fused_kernel<TD, TK, true>), dim3((unsigned)q->n), dim3(256), smem,
+                         ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
+                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
+                         f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
+                         (const float*)data->shadow32, data->max_norm, kp + 1);
+      RPT_HIP(hipGetLastError());
+      return RPT_OK;
+    }
+  }
   if (smem > 64 * 1024)
-    RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK>,
+    RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((knn_fused_kernel<TD, TK>), dim3((unsigned)q->n), dim3(256), smem,
+  hipLaunchKernelGGL((knn_fused_kernel<TD, TK, false>), dim3((unsigned)q->n), dim3(256), smem,
                      ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                      f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
-                     f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total);
+                     f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
+                     (const float*)nullptr, 0.0, 0);
   RPT_HIP(hipGetLastError());
   return RPT_OK;
 }
@@ -1311,6 +1434,9 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
   int32_t s = RPT_OK;
+  if (f->pdtype == RPT_F64 && dedup == 0 && 2 * k + 12 < kFK && !getenv("RPT_KNN_NO_PRE32") &&
+      (int64_t)f->T * f->min_leaf > kWaveCandidates)
+    RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
   if (f->pdtype == RPT_F64) {
     s = launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev, count_dev,
                                      ovf.p, ctot.p);

@@ -519,6 +519,39 @@ def test_large_pivot_bins_selection_path(rp, ctx, oracle, monkeypatch, decimals)
     assert_forest_equal(g, fo)
 
 
+@pytest.mark.parametrize("kind", ["cont", "ties", "dups"])
+@pytest.mark.parametrize("k", [1, 10, 24])
+def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
+    """f64 data, duplicates kept: the fused kernel ranks the candidates on an f32 shadow of X,
+    computes exact distances for the best 2k+12 (>= 32) only and certifies the cut per query
+    (falling back to the exact path when it cannot: heavy ties).  ids, distances and counts must
+    equal the oracle's and the all-f64 kernel's, bit for bit — on continuous data, on rounded
+    data (many exactly equal distances) and on data with repeated points."""
+    n, d, T, ml = 20000, 16, 12, 100          # 12 x 100 candidates: the workgroup kernel
+    X = oracle.data_normal_dense2(55, n, d)
+    if kind == "ties":
+        X = np.round(X * 2) / 2
+    elif kind == "dups":
+        X[n // 2:] = X[:n - n // 2]             # every point twice
+    rng = np.random.default_rng(3)
+    Q = X[rng.integers(0, n, 48)] + (0.0 if kind != "cont" else 0.003)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(21, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    got = rp.knnBatch(k, f, Q)
+    monkeypatch.setenv("RPT_KNN_NO_PRE32", "1")
+    ref = rp.knnBatch(k, f, Q)
+    monkeypatch.delenv("RPT_KNN_NO_PRE32")
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    fo = oracle.forest_build_dense(X, R, ml)
+    ids, dist, cnt = got
+    for i in range(0, len(Q), 4):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+        assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+        assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
+
+
 def test_forest_save_load_roundtrip(rp, ctx, small_forest, tmp_path):
     X, f, fo, Q = small_forest
     path = str(tmp_path / "forest.npz")
