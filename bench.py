@@ -441,6 +441,10 @@ def main():
                     "(RPTree.hs:174-176)", "candidates_per_query": cand_total.value / nq,
                     "topk_kernel_ms": prof["knn_topk"][0] / max(prof["knn_topk"][1], 1),
                     "plan_ms": prof["knn_plan"][0] / max(prof["knn_plan"][1], 1),
+                    "method": "all-f64 distances" if os.environ.get("RPT_KNN_NO_PRE32") else
+                    "candidates ranked on an f32 shadow of X, exact f64 distances for the best "
+                    "2k+12, cut certified per query (exact fallback); results identical to the "
+                    "all-f64 kernel",
                     "exchange": None if world == 1 else
                     ("gloo via host (rehearsal)" if one_gpu else
                      "one RCCL all-gather of %d B records, %s" % (rec.bytes, exchange["mode"]))},

@@ -786,18 +786,19 @@ __device__ inline void wave_sync() {  // LDS writes of the wave visible to all i
 }
 
 __host__ __device__ inline size_t fused_wave_bytes(int d, size_t acc_size) {
-  const size_t b = (size_t)kWC * 12 + (size_t)kWR * 24 + (size_t)kFK * 16 + (size_t)d * acc_size;
+  const size_t b = (size_t)kWC * 12 + (size_t)kWR * 24 + (size_t)kFK * 16 + (size_t)d * (acc_size + 4);
   return (b + 15) & ~(size_t)15;
 }
 
-template <class TD, class TK>
+template <class TD, class TK, bool PRE32>
 __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
     const double* __restrict__ thr, const double* __restrict__ mglo,
     const double* __restrict__ mghi, int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T,
     int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
-    unsigned int* ovf_count, unsigned long long* cand_total) {
+    unsigned int* ovf_count, unsigned long long* cand_total,
+    const float* __restrict__ Xf, double xmax, int k1 /* PRE32: see knn_fused_kernel */) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -815,8 +816,11 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   int* sn = rn + kWR;                                              // [kWR]
   int* bid = sn + kWR;                                             // [kFK]
   int* bpos = bid + kFK;                                           // [kFK]
+  float* qs32 = reinterpret_cast<float*>(bpos + kFK);              // [d] (PRE32)
 
   for (int j = lane; j < d; j += 64) qs[j] = ld<TD>(Q + q * d + j);
+  if (PRE32)
+    for (int j = lane; j < d; j += 64) qs32[j] = (float)ld<TD>(Q + q * d + j);
 
   // ---- traversal: lane = tree; ranges into the tree's S slots, counted in any case ----
   const int S = kWR / T;
@@ -872,34 +876,10 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
 
   constexpr int E = kWC / 64;  // batch entries a lane owns: lane, lane + 64, ...
   const double kInf = __longlong_as_double(0x7ff0000000000000LL);
-  int best = 0, r_next = 0, r_done = 0, pos_base = 0;
-  while (r_next < nr_tot || best == 0) {
-    // ---- fill the batch: best list first (keeps its positions), then new candidates ----
-    for (int i = lane; i < best; i += 64) {
-      cdist[i] = bdist[i];
-      cid[i] = bid[i];
-    }
-    int fill = best;
-    const int first_new = best, pb0 = pos_base;
-    int rr = r_next, rd = r_done, pb = pos_base;
-    while (rr < nr_tot && fill < kWC) {
-      int take = rn[rr] - rd;
-      if (take > kWC - fill) take = kWC - fill;
-      for (int i = lane; i < take; i += 64) cid[fill + i] = perm[rpoff[rr] + rd + i];
-      fill += take;
-      rd += take;
-      pb += take;
-      if (rd == rn[rr]) {
-        ++rr;
-        rd = 0;
-      }
-    }
-    r_next = rr;
-    r_done = rd;
-    pos_base = pb;
-    wave_sync();
-    batch_distances<TD, TA>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
-    wave_sync();
+  // ---- selection over the batch entries [0, fill): entries below first_new are the running
+  // best list (positions in bpos), the others are new candidates at positions pb0, pb0 + 1, ...;
+  // ksel rounds of wave-wide arg-min by (distance, position); winners to bdist / bid / bpos ----
+  auto wselect = [&](int fill, int first_new, int pb0, int ksel, int dedup) -> int {
     // ---- the lane's entries: distance and candidate position (-1 = none / consumed) ----
     double dd[E];
     int pp[E];
@@ -913,7 +893,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     // ---- selection: k rounds of wave-wide arg-min by (distance, position) ----
     int nb = 0;
     double last_d = -1.0;
-    while (nb < k) {
+    while (nb < ksel) {
       double bd = kInf;
       int bp = 0x7fffffff, bi = -1;
 #pragma unroll
@@ -952,8 +932,67 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
         last_d = bd;
       }
     }
+    return nb;
+  };
+
+  int best = 0, r_next = 0, r_done = 0, pos_base = 0;
+  while (r_next < nr_tot || best == 0) {
+    // ---- fill the batch: best list first (keeps its positions), then new candidates ----
+    for (int i = lane; i < best; i += 64) {
+      cdist[i] = bdist[i];
+      cid[i] = bid[i];
+    }
+    int fill = best;
+    const int first_new = best, pb0 = pos_base;
+    int rr = r_next, rd = r_done, pb = pos_base;
+    while (rr < nr_tot && fill < kWC) {
+      int take = rn[rr] - rd;
+      if (take > kWC - fill) take = kWC - fill;
+      for (int i = lane; i < take; i += 64) cid[fill + i] = perm[rpoff[rr] + rd + i];
+      fill += take;
+      rd += take;
+      pb += take;
+      if (rd == rn[rr]) {
+        ++rr;
+        rd = 0;
+      }
+    }
+    r_next = rr;
+    r_done = rd;
+    pos_base = pb;
+    wave_sync();
+    if constexpr (PRE32)
+      batch_distances<float, float, 16>(Xf, d, cid, cdist, qs32, first_new, fill, 0, 1, lane);
+    else
+      batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
+    wave_sync();
+    const int nb = wselect(fill, first_new, pb0, PRE32 ? k1 : k, PRE32 ? 0 : dedup);
     best = nb;
     if (r_next >= nr_tot) break;
+  }
+  if constexpr (PRE32) {  // exact distances of the kept entries + certified cut (knn_fused_kernel)
+    const bool cut = best == k1;
+    const double F = cut ? bdist[k1 - 1] : 0.0;
+    const int m = cut ? k1 - 1 : best;
+    double qn = 0.0;
+    for (int j = lane; j < d; j += 64) qn += (double)qs[j] * (double)qs[j];
+    for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+    for (int i = lane; i < m; i += 64) cid[i] = bid[i];
+    wave_sync();
+    batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, 0, 1, lane);
+    wave_sync();
+    best = wselect(m, m, 0, k, 0);
+    if (cut && best > 0) {
+      const double u = 5.9604644775390625e-08;
+      const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F;
+      if (!(F - err > bdist[best - 1])) {
+        if (lane == 0) {
+          ovf_flags[q] = 1u;
+          atomicAdd(ovf_count, 1u);
+        }
+        return;
+      }
+    }
   }
   for (int i = lane; i < k; i += 64) {
     const bool ok = i < best;
@@ -1321,26 +1360,43 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
               (int64_t)f->T * f->min_leaf <= kWaveCandidates;
   if (force) wave = force[0] == '1' && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
   ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
+  // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
+  // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
+  const int kp = 2 * k + 12 < 32 ? 32 : 2 * k + 12;
+  const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
+                     !getenv("RPT_KNN_NO_PRE32") && data->shadow32;
   if (wave) {
     const size_t smem = 4 * wbytes;
+    if constexpr (std::is_same<TD, double>::value) {
+      if (pre32) {
+        if (smem > 64 * 1024)
+          RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_wave_kernel<TD, TK, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((knn_fused_wave_kernel<TD, TK, true>), dim3((unsigned)((q->n + 3) / 4)),
+                           dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
+                           (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
+                           (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
+                           cnt, ovf + 1, ovf, cand_total, (const float*)data->shadow32,
+                           data->max_norm, kp + 1);
+        RPT_HIP(hipGetLastError());
+        return RPT_OK;
+      }
+    }
     if (smem > 64 * 1024)
-      RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_wave_kernel<TD, TK>,
+      RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_wave_kernel<TD, TK, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((knn_fused_wave_kernel<TD, TK>), dim3((unsigned)((q->n + 3) / 4)),
+    hipLaunchKernelGGL((knn_fused_wave_kernel<TD, TK, false>), dim3((unsigned)((q->n + 3) / 4)),
                        dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
                        (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                        (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
-                       cnt, ovf + 1, ovf, cand_total);
+                       cnt, ovf + 1, ovf, cand_total, (const float*)nullptr, 0.0, 0);
     RPT_HIP(hipGetLastError());
     return RPT_OK;
   }
   const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFK * 16 +
                       (size_t)data->d * (sizeof(TA) + 4) + 64;
-  // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
-  // bytes), exact distances for the best k' only, cut certified per query (see the kernel)
   if constexpr (std::is_same<TD, double>::value) {
-    const int kp = 2 * k + 12 < 32 ? 32 : 2 * k + 12;
-    if (dedup == 0 && kp + 1 <= kFK && !getenv("RPT_KNN_NO_PRE32") && data->shadow32) {
+    if (pre32) {
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1434,8 +1490,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
   int32_t s = RPT_OK;
-  if (f->pdtype == RPT_F64 && dedup == 0 && 2 * k + 12 < kFK && !getenv("RPT_KNN_NO_PRE32") &&
-      (int64_t)f->T * f->min_leaf > kWaveCandidates)
+  if (f->pdtype == RPT_F64 && dedup == 0 && 2 * k + 12 < kFK && !getenv("RPT_KNN_NO_PRE32"))
     RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
   if (f->pdtype == RPT_F64) {
     s = launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev, count_dev,

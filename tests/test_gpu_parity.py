@@ -528,6 +528,8 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
     equal the oracle's and the all-f64 kernel's, bit for bit — on continuous data, on rounded
     data (many exactly equal distances) and on data with repeated points."""
     n, d, T, ml = 20000, 16, 12, 100          # 12 x 100 candidates: the workgroup kernel
+    if k == 10:
+        T, ml = 6, 100                        # ... and 6 x 100: the one-wave-per-query kernel
     X = oracle.data_normal_dense2(55, n, d)
     if kind == "ties":
         X = np.round(X * 2) / 2
