@@ -742,8 +742,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     best = select(m, k, 0);
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
-      const double err = 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F;
-      if (!(F - err > bdist[best - 1])) {
+      const double err = 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F + 1e-30;
+      // (norms whose squares leave the f32 range — inf - inf = NaN entries are never ranked —
+      // fail the test through s_qn; the dataset side is checked when the shadow is built)
+      if (!(s_qn < 1e18) || !(F - err > bdist[best - 1])) {
         if (tid == 0) {
           ovf_flags[q] = 1u;
           atomicAdd(ovf_count, 1u);
@@ -984,8 +986,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     best = wselect(m, m, 0, k, 0);
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
-      const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F;
-      if (!(F - err > bdist[best - 1])) {
+      const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + 1e-30;
+      if (!(sqrt(qn) < 1e18) || !(F - err > bdist[best - 1])) {
         if (lane == 0) {
           ovf_flags[q] = 1u;
           atomicAdd(ovf_count, 1u);
@@ -1326,7 +1328,7 @@ __global__ __launch_bounds__(256) void shadow32_kernel(const double* __restrict_
 }
 
 static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
-  if (data->shadow32) return RPT_OK;
+  if (data->shadow32 || data->max_norm == -2.0) return RPT_OK;
   void* p = nullptr;
   if (dev_alloc(&p, (size_t)data->n * data->d * sizeof(float)) != hipSuccess)
     return fail(RPT_E_NOMEM, "f32 shadow of the dataset");
@@ -1342,8 +1344,13 @@ static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
   RPT_HIP(stream_sync(ctx->stream));
   double m2;
   std::memcpy(&m2, &bits, 8);
-  data->shadow32 = (float*)p;
   data->max_norm = std::sqrt(m2) * (1.0 + 1e-12);
+  if (!(data->max_norm < 1e18)) {  // squares would leave the f32 range (or NaN rows): no shadow
+    dev_free(p);
+    data->max_norm = -2.0;         // tried, unusable
+    return RPT_OK;
+  }
+  data->shadow32 = (float*)p;
   return RPT_OK;
 }
 

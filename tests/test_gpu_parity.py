@@ -554,6 +554,26 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
         assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
 
 
+def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle, monkeypatch):
+    """Values whose squares leave the f32 range (the shadow would hold inf): no prefilter, the
+    all-f64 kernel answers; tiny values (f32 subnormals): certified or sent to the exact path —
+    the oracle's result either way."""
+    n, d, T, ml, k = 6000, 8, 12, 100, 5
+    base = oracle.data_normal_dense2(9, n, d)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(4, T, L, pnz, d)
+    for scale in (1e30, 1e-42):
+        X = base * scale
+        Q = X[:16].copy()
+        f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+        ids, dist, cnt = rp.knnBatch(k, f, Q)
+        fo = oracle.forest_build_dense(X, R, ml)
+        for i in range(len(Q)):
+            wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+            assert np.array_equal(dist[i, :cnt[i]], wd) or np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=0)
+
+
 def test_forest_save_load_roundtrip(rp, ctx, small_forest, tmp_path):
     X, f, fo, Q = small_forest
     path = str(tmp_path / "forest.npz")
