@@ -742,10 +742,13 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     best = select(m, k, 0);
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
-      const double err = 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F + 1e-30;
+      // + sqrt(d) * 4e-23: products in the f32 subnormal range lose relative accuracy
+      // (absolute error 2^-150 each; |sqrt a - sqrt b| <= sqrt |a - b|)
+      const double err = 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
       // (norms whose squares leave the f32 range — inf - inf = NaN entries are never ranked —
       // fail the test through s_qn; the dataset side is checked when the shadow is built)
-      if (!(s_qn < 1e18) || !(F - err > bdist[best - 1])) {
+      // F must be finite: an overflowed f32 sum (inf) orders nothing among the dropped
+      if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
         if (tid == 0) {
           ovf_flags[q] = 1u;
           atomicAdd(ovf_count, 1u);
@@ -986,8 +989,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     best = wselect(m, m, 0, k, 0);
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
-      const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + 1e-30;
-      if (!(sqrt(qn) < 1e18) || !(F - err > bdist[best - 1])) {
+      const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
+      if (!(sqrt(qn) < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
         if (lane == 0) {
           ovf_flags[q] = 1u;
           atomicAdd(ovf_count, 1u);

@@ -562,7 +562,7 @@ def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle, monkeypatch):
     base = oracle.data_normal_dense2(9, n, d)
     L, _, pnz = oracle.tree_cfg(ml, n, d)
     R, _ = oracle.forest_hyperplanes(4, T, L, pnz, d)
-    for scale in (1e30, 1e-42):
+    for scale in (1e30, 1e17, 1e-19, 1e-21, 1e-42):
         X = base * scale
         Q = X[:16].copy()
         f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
