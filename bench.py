@@ -269,6 +269,8 @@ def main():
     prof["knn_plan"], prof["knn_topk"] = prof_q["knn_plan"], prof_q["knn_topk"]
     cand_total = C.c_int64()
     _lib.check(L_.rpt_knn_last_candidates(ctx._h, C.byref(cand_total)))
+    uncertified = C.c_int64()
+    _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(uncertified)))
 
     # ---- recall (untimed) ----
     nq_eval = min(nq, 500)
@@ -441,6 +443,7 @@ def main():
                     "(RPTree.hs:174-176)", "candidates_per_query": cand_total.value / nq,
                     "topk_kernel_ms": prof["knn_topk"][0] / max(prof["knn_topk"][1], 1),
                     "plan_ms": prof["knn_plan"][0] / max(prof["knn_plan"][1], 1),
+                    "prefilter_uncertified_queries": uncertified.value,
                     "method": "all-f64 distances" if os.environ.get("RPT_KNN_NO_PRE32") else
                     "candidates ranked on an f32 shadow of X, exact f64 distances for the best "
                     "2k+12, cut certified per query (exact fallback); results identical to the "

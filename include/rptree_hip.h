@@ -194,6 +194,9 @@ int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                     double* dist_dev, int32_t* count_dev);
 /* statistics of the last rpt_knn_* call: total candidates visited (sum over queries) */
 int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total);
+/* ... and how many of its queries the f32 prefilter could not certify (equal distances at its
+ * cut) and were answered again with all-f64 distances; 0 when the prefilter was not used */
+int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total);
 
 /* multi-GPU merge: G per-shard results (shard g holds trees [g*T/G, (g+1)*T/G)), gathered
  * shard-major as ids_dev[G][nq][k] etc. (e.g. by an RCCL all-gather), merged into the

@@ -745,6 +745,12 @@ int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total) {
   return RPT_OK;
 }
 
+int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total) {
+  RPT_ARG(ctx && total, "NULL argument");
+  *total = ctx->last_uncertified;
+  return RPT_OK;
+}
+
 int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
                           const int32_t* count_dev, int32_t G, int64_t nq, int32_t k,
                           int32_t flags, int32_t* out_ids_dev, double* out_dist_dev,

@@ -114,6 +114,7 @@ struct rpt_ctx {
   // pinned bump arena for small asynchronous host<->device transfers (api.hip: pin_alloc)
   char* pin = nullptr;
   size_t pin_cap = 0, pin_off = 0;
+  int64_t last_uncertified = 0;  // queries of the last kNN call re-run with all-f64 distances
   int64_t last_candidates = 0;
   int32_t n_cu = 256;
   bool prof = false;

@@ -547,6 +547,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
 
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool rerun = !PRE32 && k1 == -1;  // second pass: only the queries the prefilter gave up on
+  if (rerun && ovf_flags[q] != 2u) return;
   for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
   if (PRE32)
     for (int j = tid; j < d; j += 256) qs32[j] = (float)ld<TD>(Q + q * d + j);
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     }
     return;
   }
-  if (tid == 0) atomicAdd(cand_total, (unsigned long long)nc_tot);
+  if (tid == 0 && !rerun) atomicAdd(cand_total, (unsigned long long)nc_tot);
   // ---- traversal 2: ranges in tree order ----
   for (int t = tid; t < T; t += 256) {
     int r = trng[t];
@@ -749,9 +751,9 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       // fail the test through s_qn; the dataset side is checked when the shadow is built)
       // F must be finite: an overflowed f32 sum (inf) orders nothing among the dropped
       if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
-        if (tid == 0) {
-          ovf_flags[q] = 1u;
-          atomicAdd(ovf_count, 1u);
+        if (tid == 0) {  // flag 2: the host re-runs this query with the all-f64 kernel
+          ovf_flags[q] = 2u;
+          atomicAdd(cand_total + 1, 1ULL);
         }
         return;
       }
@@ -809,6 +811,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t q = (int64_t)blockIdx.x * 4 + wave;
   if (q >= nq) return;  // no workgroup barrier below
+  const bool rerun = !PRE32 && k1 == -1;  // second pass: only the queries the prefilter gave up on
+  if (rerun && ovf_flags[q] != 2u) return;
   unsigned char* base = smem + (size_t)wave * fused_wave_bytes(d, sizeof(TA));
   double* cdist = reinterpret_cast<double*>(base);                 // [kWC]
   double* bdist = cdist + kWC;                                     // [kFK]
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     }
     return;
   }
-  if (lane == 0) atomicAdd(cand_total, (unsigned long long)nc_tot);
+  if (lane == 0 && !rerun) atomicAdd(cand_total, (unsigned long long)nc_tot);
   if (__ballot(my_nr > S) == 0ULL) {  // the usual case: compact the slots (a lane reads its own)
     if (lane < T) {
       const int r0 = inc_r - my_nr;
@@ -992,8 +996,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
       const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
       if (!(sqrt(qn) < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
         if (lane == 0) {
-          ovf_flags[q] = 1u;
-          atomicAdd(ovf_count, 1u);
+          ovf_flags[q] = 2u;
+          atomicAdd(cand_total + 1, 1ULL);
         }
         return;
       }
@@ -1361,7 +1365,7 @@ template <class TD, class TK>
 static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                             const rpt_dataset* q, const void* Pq, int32_t k, int dedup,
                             int32_t* ids, double* dist, int32_t* cnt, unsigned int* ovf,
-                            unsigned long long* cand_total) {
+                            unsigned long long* cand_total, bool rerun = false) {
   typedef typename AccOf<TD>::type TA;
   // small shards (few trees => a few hundred candidates per query): one wave per query
   const char* force = getenv("RPT_KNN_WAVE");
@@ -1374,7 +1378,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
   const int kp = 2 * k + 12 < 32 ? 32 : 2 * k + 12;
   const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
-                     !getenv("RPT_KNN_NO_PRE32") && data->shadow32;
+                     !getenv("RPT_KNN_NO_PRE32") && data->shadow32 && !rerun;
   if (wave) {
     const size_t smem = 4 * wbytes;
     if constexpr (std::is_same<TD, double>::value) {
@@ -1399,7 +1403,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                        dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
                        (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                        (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
-                       cnt, ovf + 1, ovf, cand_total, (const float*)nullptr, 0.0, 0);
+                       cnt, ovf + 1, ovf, cand_total, (const float*)nullptr, 0.0, rerun ? -1 : 0);
     RPT_HIP(hipGetLastError());
     return RPT_OK;
   }
@@ -1426,7 +1430,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                      ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                      f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                      f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                     (const float*)nullptr, 0.0, 0);
+                     (const float*)nullptr, 0.0, rerun ? -1 : 0);
   RPT_HIP(hipGetLastError());
   return RPT_OK;
 }
@@ -1492,35 +1496,39 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   const size_t esz = f->pdtype == RPT_F64 ? 8 : 4;
   RPT_TRY(Pq.alloc((size_t)f->T * f->L * nq * esz + 16));
   RPT_TRY(ovf.alloc((size_t)nq + 1));
-  RPT_TRY(ctot.alloc(1));
+  RPT_TRY(ctot.alloc(2));  // [0] candidates visited, [1] queries whose prefilter cut was not certified
   RPT_HIP(hipMemsetAsync(ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
-  RPT_HIP(hipMemsetAsync(ctot.p, 0, 8, ctx->stream));
+  RPT_HIP(hipMemsetAsync(ctot.p, 0, 16, ctx->stream));
   {
     ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
-  int32_t s = RPT_OK;
   if (f->pdtype == RPT_F64 && dedup == 0 && 2 * k + 12 < kFK && !getenv("RPT_KNN_NO_PRE32"))
     RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
-  if (f->pdtype == RPT_F64) {
-    s = launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev, count_dev,
-                                     ovf.p, ctot.p);
-  } else if (data->dtype == RPT_F32) {
-    s = launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev, count_dev,
-                                   ovf.p, ctot.p);
-  } else {
-    s = launch_fused<__hip_bfloat16, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                            count_dev, ovf.p, ctot.p);
-  }
-  RPT_TRY(s);
+  auto launch = [&](bool rerun) -> int32_t {
+    if (f->pdtype == RPT_F64)
+      return launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
+                                          count_dev, ovf.p, ctot.p, rerun);
+    if (data->dtype == RPT_F32)
+      return launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
+                                        count_dev, ovf.p, ctot.p, rerun);
+    return launch_fused<__hip_bfloat16, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
+                                               count_dev, ovf.p, ctot.p, rerun);
+  };
+  RPT_TRY(launch(false));
   unsigned int novf = 0;
-  unsigned long long tot = 0;
+  unsigned long long tot[2] = {0, 0};
   RPT_HIP(hipMemcpyAsync(&novf, ovf.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  RPT_HIP(hipMemcpyAsync(&tot, ctot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  RPT_HIP(hipMemcpyAsync(tot, ctot.p, 16, hipMemcpyDeviceToHost, ctx->stream));
   RPT_HIP(stream_sync(ctx->stream));
-  ctx->last_candidates = (int64_t)tot;
+  ctx->last_candidates = (int64_t)tot[0];
+  ctx->last_uncertified = (int64_t)tot[1];
   if (novf)  // some query reached more leaf ranges than the LDS slab holds: general path
     return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
+  if (tot[1]) {  // queries with equal distances at the prefilter's cut: the all-f64 kernel, them only
+    RPT_TRY(launch(true));
+    RPT_HIP(stream_sync(ctx->stream));  // Pq / ovf are released on return
+  }
   return RPT_OK;
 }
 

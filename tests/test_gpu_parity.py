@@ -541,6 +541,12 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
     R, _ = oracle.forest_hyperplanes(21, T, L, pnz, d)
     f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
     got = rp.knnBatch(k, f, Q)
+    import ctypes as C
+    from rptree_amd import _lib
+    unc = C.c_int64(-1)
+    _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+    if kind == "cont":
+        assert unc.value == 0                   # every cut certified
     monkeypatch.setenv("RPT_KNN_NO_PRE32", "1")
     ref = rp.knnBatch(k, f, Q)
     monkeypatch.delenv("RPT_KNN_NO_PRE32")
@@ -549,6 +555,30 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
     fo = oracle.forest_build_dense(X, R, ml)
     ids, dist, cnt = got
     for i in range(0, len(Q), 4):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+        assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+        assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
+
+
+def test_knn_f32_prefilter_uncertified_queries_rerun(rp, ctx, oracle):
+    """Half of the points are one and the same point: for queries near it every distance at the
+    prefilter's cut is equal, nothing can be certified, and exactly those queries are answered
+    again by the all-f64 kernel — the others keep their prefiltered answers; all match the oracle."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, ml, k = 8000, 8, 12, 100, 10
+    X = oracle.data_normal_dense2(91, n, d)
+    X[n // 2:] = 1.0
+    Q = np.concatenate([X[:20] + 0.001, np.ones((12, d))])
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(2, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    ids, dist, cnt = rp.knnBatch(k, f, Q)
+    unc = C.c_int64(-1)
+    _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+    assert 12 <= unc.value < len(Q)
+    fo = oracle.forest_build_dense(X, R, ml)
+    for i in range(len(Q)):
         wi, wd = oracle.knn_dense(fo, X, Q[i], k)
         assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
         assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
