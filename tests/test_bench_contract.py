@@ -1,0 +1,46 @@
+"""The driver's contract with bench.py: one JSON line on stdout with the fields it reads, the
+roofline and cpu_baseline objects, on a reduced workload (the full C2 run is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--npoints", "200000", "--trees", "8", "--nq", "1000", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "cpu_baseline", "knn"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert j["unit"] == "vectors/s" and j["value"] > 0 and j["ms_per_step"] > 0
+    assert abs(j["value"] - 200000 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert j["knn"]["value"] > 0 and j["knn"]["unit"] == "queries/s"
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """--gpus N without the launcher's WORLD_SIZE must not silently run on one GPU (checked
+    before any device is touched, so this runs without a GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "torch.distributed.run --nproc-per-node 2" in (out.stderr + out.stdout)
