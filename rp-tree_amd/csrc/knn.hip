@@ -1491,14 +1491,15 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   const int64_t nq = q->n;
   const int dedup = flags & 3;
   DevBuf<char> Pq;
-  DevBuf<unsigned int> ovf;
-  DevBuf<unsigned long long> ctot;
+  // one control block, one memset, one read-back: u64 candidates visited, u64 queries whose
+  // prefilter cut was not certified, u32 queries that overflowed the range slab, pad, flags[nq]
+  DevBuf<unsigned int> ctl;
   const size_t esz = f->pdtype == RPT_F64 ? 8 : 4;
   RPT_TRY(Pq.alloc((size_t)f->T * f->L * nq * esz + 16));
-  RPT_TRY(ovf.alloc((size_t)nq + 1));
-  RPT_TRY(ctot.alloc(2));  // [0] candidates visited, [1] queries whose prefilter cut was not certified
-  RPT_HIP(hipMemsetAsync(ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
-  RPT_HIP(hipMemsetAsync(ctot.p, 0, 16, ctx->stream));
+  RPT_TRY(ctl.alloc((size_t)nq + 6));
+  RPT_HIP(hipMemsetAsync(ctl.p, 0, ((size_t)nq + 6) * 4, ctx->stream));
+  unsigned int* ovf_p = ctl.p + 5;  // launch_fused: the count at ovf_p[0], the flags from ovf_p + 1
+  unsigned long long* ctot_p = reinterpret_cast<unsigned long long*>(ctl.p);
   {
     ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
@@ -1508,19 +1509,20 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
       return launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                          count_dev, ovf.p, ctot.p, rerun);
+                                          count_dev, ovf_p, ctot_p, rerun);
     if (data->dtype == RPT_F32)
       return launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                        count_dev, ovf.p, ctot.p, rerun);
+                                        count_dev, ovf_p, ctot_p, rerun);
     return launch_fused<__hip_bfloat16, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                               count_dev, ovf.p, ctot.p, rerun);
+                                               count_dev, ovf_p, ctot_p, rerun);
   };
   RPT_TRY(launch(false));
-  unsigned int novf = 0;
-  unsigned long long tot[2] = {0, 0};
-  RPT_HIP(hipMemcpyAsync(&novf, ovf.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  RPT_HIP(hipMemcpyAsync(tot, ctot.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned int hctl[6] = {0, 0, 0, 0, 0, 0};
+  RPT_HIP(hipMemcpyAsync(hctl, ctl.p, 24, hipMemcpyDeviceToHost, ctx->stream));
   RPT_HIP(stream_sync(ctx->stream));
+  const unsigned int novf = hctl[5];
+  unsigned long long tot[2];
+  std::memcpy(tot, hctl, 16);
   ctx->last_candidates = (int64_t)tot[0];
   ctx->last_uncertified = (int64_t)tot[1];
   if (novf)  // some query reached more leaf ranges than the LDS slab holds: general path
