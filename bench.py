@@ -446,7 +446,7 @@ def main():
                     "prefilter_uncertified_queries": uncertified.value,
                     "method": "all-f64 distances" if os.environ.get("RPT_KNN_NO_PRE32") else
                     "candidates ranked on an f32 shadow of X, exact f64 distances for the best "
-                    "2k+12, cut certified per query (exact fallback); results identical to the "
+                    "k+6, cut certified per query (exact fallback); results identical to the "
                     "all-f64 kernel",
                     "exchange": None if world == 1 else
                     ("gloo via host (rehearsal)" if one_gpu else

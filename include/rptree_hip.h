@@ -180,9 +180,9 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
  * ((x_j - q_j)^2 - q_j^2): absolute error about 1e-8 |q|): per query the k best (distance, id), stable in
  * candidate order (tree ascending, then leaf order).  ids/dist are [nq][k]; count[nq] is the
  * number of valid entries (< k when fewer candidates).  Unused slots: id -1, dist +inf. */
-/* Memory note: the first rpt_knn_* call with duplicates kept (flags 0) and k <= 24 on a dense
+/* Memory note: the first rpt_knn_* call with duplicates kept (flags 0) and k <= 42 on a dense
  * f64 dataset builds an f32 copy of it on the device (+50 % of the dataset's size, freed with the
- * dataset): candidates are ranked on it, exact f64 distances are computed for the best 2k+12,
+ * dataset): candidates are ranked on it, exact f64 distances are computed for the best k + max(6, k/2),
  * and a per-query error bound certifies the cut (uncertifiable queries take the all-f64 path).
  * Results are identical either way.  A dataset borrowed with rpt_dataset_dense_dev must not be
  * modified while the library holds it. */

@@ -171,6 +171,10 @@ struct rpt_forest {
   int32_t d = 0, T = 0, L = 0, min_leaf = 0;
   int32_t pdtype = RPT_F64;  // type of proj
   int32_t mode = RPT_PROJ_AUTO;  // projection mode used by the build (queries reuse it)
+  // set when a query batch had more than a quarter of its f32-prefilter cuts uncertified (many
+  // equal distances: e.g. the queries are data points, found once per tree): later batches on this
+  // forest go straight to the all-f64 kernel
+  bool prefilter_off = false;
   int64_t nodes = 0;         // 2^L - 1
   rpt::DevBuf<int32_t> perm;  // [T][N] final leaf-ordered permutation
   rpt::DevBuf<double> thr, mglo, mghi;  // [T][nodes]

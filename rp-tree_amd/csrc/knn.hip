@@ -1314,6 +1314,8 @@ static int32_t launch_topk_dense(rpt_ctx* ctx, const rpt_dataset* data, const rp
   return RPT_OK;
 }
 
+static inline int prefilter_keep(int k) { return k + (k / 2 > 6 ? k / 2 : 6); }
+
 // f32 shadow of a dense f64 dataset + its largest row norm (one wave per row)
 __global__ __launch_bounds__(256) void shadow32_kernel(const double* __restrict__ X, int64_t n, int d,
                                                        float* __restrict__ Xf,
@@ -1376,9 +1378,13 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
   // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
-  const int kp = 2 * k + 12 < 32 ? 32 : 2 * k + 12;
+  const int kp_env = getenv("RPT_KNN_KP") ? atoi(getenv("RPT_KNN_KP")) : 0;
+  // entries the f32 pass keeps: every one costs a selection round per batch (16 of them: 0.75 ms
+  // per 10 000 queries at C2), too few and cuts fail their certificate (re-run per query): k + 6
+  // certifies 10 000 of 10 000 C2 queries
+  const int kp = kp_env > k && kp_env < kFK ? kp_env : prefilter_keep(k);
   const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
-                     !getenv("RPT_KNN_NO_PRE32") && data->shadow32 && !rerun;
+                     !getenv("RPT_KNN_NO_PRE32") && data->shadow32 && !rerun && !f->prefilter_off;
   if (wave) {
     const size_t smem = 4 * wbytes;
     if constexpr (std::is_same<TD, double>::value) {
@@ -1504,7 +1510,8 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
-  if (f->pdtype == RPT_F64 && dedup == 0 && 2 * k + 12 < kFK && !getenv("RPT_KNN_NO_PRE32"))
+  if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !getenv("RPT_KNN_NO_PRE32") &&
+      !f->prefilter_off)
     RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
@@ -1527,6 +1534,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   ctx->last_uncertified = (int64_t)tot[1];
   if (novf)  // some query reached more leaf ranges than the LDS slab holds: general path
     return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
+  if (tot[1] * 4 > (unsigned long long)nq) f->prefilter_off = true;  // not worth it on this forest
   if (tot[1]) {  // queries with equal distances at the prefilter's cut: the all-f64 kernel, them only
     RPT_TRY(launch(true));
     RPT_HIP(stream_sync(ctx->stream));  // Pq / ovf are released on return

@@ -523,7 +523,7 @@ def test_large_pivot_bins_selection_path(rp, ctx, oracle, monkeypatch, decimals)
 @pytest.mark.parametrize("k", [1, 10, 24])
 def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
     """f64 data, duplicates kept: the fused kernel ranks the candidates on an f32 shadow of X,
-    computes exact distances for the best 2k+12 (>= 32) only and certifies the cut per query
+    computes exact distances for the best k + max(6, k/2) only and certifies the cut per query
     (falling back to the exact path when it cannot: heavy ties).  ids, distances and counts must
     equal the oracle's and the all-f64 kernel's, bit for bit — on continuous data, on rounded
     data (many exactly equal distances) and on data with repeated points."""
@@ -545,8 +545,10 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
     from rptree_amd import _lib
     unc = C.c_int64(-1)
     _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
-    if kind == "cont":
+    if kind == "cont" and k == 24:
         assert unc.value == 0                   # every cut certified
+    # (k = 1: a query is a data point + 0.003, its source is found once per tree, and a cut inside
+    # that group of equal distances cannot be certified: those queries are re-run in f64)
     monkeypatch.setenv("RPT_KNN_NO_PRE32", "1")
     ref = rp.knnBatch(k, f, Q)
     monkeypatch.delenv("RPT_KNN_NO_PRE32")
@@ -582,6 +584,32 @@ def test_knn_f32_prefilter_uncertified_queries_rerun(rp, ctx, oracle):
         wi, wd = oracle.knn_dense(fo, X, Q[i], k)
         assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
         assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
+
+
+def test_knn_f32_prefilter_switches_itself_off_on_self_queries(rp, ctx, oracle):
+    """Queries that ARE data points are found once per tree with equal distances; when more than a
+    quarter of a batch cannot be certified the forest stops using the prefilter (the next batch
+    reports 0 uncertified because it never tries), and the answers stay the oracle's."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, ml, k = 8000, 8, 12, 100, 4
+    X = oracle.data_normal_dense2(17, n, d)
+    Q = X[:24].copy()
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(6, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    fo = oracle.forest_build_dense(X, R, ml)
+    seen = []
+    for rnd in range(2):
+        ids, dist, cnt = rp.knnBatch(k, f, Q)
+        unc = C.c_int64(-1)
+        _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+        seen.append(unc.value)
+        for i in range(len(Q)):
+            wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+            assert np.array_equal(dist[i, :cnt[i]], wd)
+    assert seen[0] > len(Q) // 4 and seen[1] == 0
 
 
 def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle, monkeypatch):
