@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
 // written to cdist.  The waves taking part are numbered slot = 0 .. nslots-1; every row is
 // reduced by the same fixed butterfly whichever wave handles it, so the value does not depend
 // on the kernel variant.  Each wave keeps EIGHT load instructions in flight.
-template <class TD, class TA, int INFL = 8 /* load instructions in flight per wave */>
+template <class TD, class TA, int INFL = 8 /* load instructions in flight per wave */,
+          bool SQRT = true /* false: leave the squared distance (a TA value) in cdist */>
 __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d, const int* cid,
                                        double* cdist, const TA* qs, int first, int fill, int slot,
                                        int nslots, int lane) {
@@ -455,7 +456,7 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
         }
         for (int o = lpr >> 1; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);  // fixed butterfly
         const int i = i0 + u * rpw + sub;
-        if (jl == 0 && i < fill) cdist[i] = (double)sqrt((double)s[u]);
+        if (jl == 0 && i < fill) cdist[i] = SQRT ? (double)sqrt((double)s[u]) : (double)s[u];
       }
     }
   } else
@@ -497,7 +498,7 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const TA tot = wave_sum(s[u]);
-      if (lane == 0 && i0 + u < fill) cdist[i0 + u] = (double)sqrt((double)tot);
+      if (lane == 0 && i0 + u < fill) cdist[i0 + u] = SQRT ? (double)sqrt((double)tot) : (double)tot;
     }
   }
 }
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   __shared__ double s_qn;
   __shared__ double s_red_d[8];
   __shared__ int s_red_p[8], s_red_i[8];
+  __shared__ unsigned long long s_red64[8];
 
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -604,6 +606,46 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   // in registers (a consumed one gets position -1), a round costs one arg-min over them, a
   // butterfly, four LDS words and ONE barrier (the per-wave results alternate between two
   // buffers) ----
+  // The f32 pass ranks SQUARED f32 distances (exact float values): (value bits << 32 | position)
+  // is one 64-bit key whose unsigned order is the (distance, position) order — half the
+  // cross-lane traffic per round, and the owner of the winner writes it out itself.
+  auto select_packed = [&](int fill, int ksel) -> int {
+    constexpr int E = kFC / 256;
+    unsigned long long key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = tid + 256 * e;
+      key[e] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | (unsigned int)cpos[i]
+                        : ~0ULL;
+    }
+    int nb = 0, par = 0;
+    while (nb < ksel) {
+      unsigned long long m = key[0];
+#pragma unroll
+      for (int e = 1; e < E; ++e) m = key[e] < m ? key[e] : m;
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t2 = __shfl_xor(m, o);
+        m = t2 < m ? t2 : m;
+      }
+      if (lane == 0) s_red64[par * 4 + wave] = m;
+      __syncthreads();
+      m = s_red64[par * 4];
+      for (int w = 1; w < 4; ++w) m = s_red64[par * 4 + w] < m ? s_red64[par * 4 + w] : m;
+      par ^= 1;
+      if (m == ~0ULL) break;  // candidates exhausted
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (key[e] == m) {  // keys are unique (positions are): exactly one owner
+          key[e] = ~0ULL;
+          bdist[nb] = (double)__uint_as_float((unsigned int)(m >> 32));
+          bid[nb] = cid[tid + 256 * e];
+          bpos[nb] = (int)(unsigned int)m;
+        }
+      ++nb;
+    }
+    __syncthreads();
+    return nb;
+  };
   auto select = [&](int fill, int ksel, int dedup) -> int {
     constexpr int E = kFC / 256;
     double dd[E];
@@ -710,11 +752,11 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     __syncthreads();
     // ---- distances of the new candidates ----
     if constexpr (PRE32)
-      batch_distances<float, float, 16>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
+      batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     __syncthreads();
-    const int nb = select(fill, PRE32 ? k1 : k, PRE32 ? 0 : dedup);
+    const int nb = PRE32 ? select_packed(fill, k1) : select(fill, k, dedup);
     best = nb;
     if (r_next >= nr_tot) break;
   }
@@ -726,7 +768,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     // f32 pass dropped has an exact distance >= F - err(F), F = the smallest dropped f32
     // distance.  If that is not above the exact k-th distance the query goes to the exact path.
     const bool cut = best == k1;                    // something was dropped
-    const double F = cut ? bdist[k1 - 1] : 0.0;
+    const double F = cut ? sqrt(bdist[k1 - 1]) : 0.0;  // the f32 pass keeps squared distances
     const int m = cut ? k1 - 1 : best;
     if (wave == 0) {
       double qn = 0.0;
@@ -888,6 +930,39 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   // ---- selection over the batch entries [0, fill): entries below first_new are the running
   // best list (positions in bpos), the others are new candidates at positions pb0, pb0 + 1, ...;
   // ksel rounds of wave-wide arg-min by (distance, position); winners to bdist / bid / bpos ----
+  // f32 pass: squared f32 distance bits << 32 | position as one key (see knn_fused_kernel)
+  auto wselect_packed = [&](int fill, int first_new, int pb0, int ksel) -> int {
+    unsigned long long key[E];
+#pragma unroll
+    for (int s2 = 0; s2 < E; ++s2) {
+      const int i = lane + 64 * s2;
+      const unsigned int pos = i < first_new ? (unsigned int)bpos[i < kFK ? i : 0] : (unsigned int)(pb0 + (i - first_new));
+      key[s2] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | pos : ~0ULL;
+    }
+    wave_sync();  // bpos is rewritten below
+    int nb = 0;
+    while (nb < ksel) {
+      unsigned long long m = key[0];
+#pragma unroll
+      for (int s2 = 1; s2 < E; ++s2) m = key[s2] < m ? key[s2] : m;
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t2 = __shfl_xor(m, o);
+        m = t2 < m ? t2 : m;
+      }
+      if (m == ~0ULL) break;
+#pragma unroll
+      for (int s2 = 0; s2 < E; ++s2)
+        if (key[s2] == m) {
+          key[s2] = ~0ULL;
+          bdist[nb] = (double)__uint_as_float((unsigned int)(m >> 32));
+          bid[nb] = cid[lane + 64 * s2];
+          bpos[nb] = (int)(unsigned int)m;
+        }
+      ++nb;
+    }
+    wave_sync();
+    return nb;
+  };
   auto wselect = [&](int fill, int first_new, int pb0, int ksel, int dedup) -> int {
     // ---- the lane's entries: distance and candidate position (-1 = none / consumed) ----
     double dd[E];
@@ -971,17 +1046,18 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     pos_base = pb;
     wave_sync();
     if constexpr (PRE32)
-      batch_distances<float, float, 16>(Xf, d, cid, cdist, qs32, first_new, fill, 0, 1, lane);
+      batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, 0, 1, lane);
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
     wave_sync();
-    const int nb = wselect(fill, first_new, pb0, PRE32 ? k1 : k, PRE32 ? 0 : dedup);
+    const int nb = PRE32 ? wselect_packed(fill, first_new, pb0, k1)
+                         : wselect(fill, first_new, pb0, k, dedup);
     best = nb;
     if (r_next >= nr_tot) break;
   }
   if constexpr (PRE32) {  // exact distances of the kept entries + certified cut (knn_fused_kernel)
     const bool cut = best == k1;
-    const double F = cut ? bdist[k1 - 1] : 0.0;
+    const double F = cut ? sqrt(bdist[k1 - 1]) : 0.0;  // the f32 pass keeps squared distances
     const int m = cut ? k1 - 1 : best;
     double qn = 0.0;
     for (int j = lane; j < d; j += 64) qn += (double)qs[j] * (double)qs[j];
