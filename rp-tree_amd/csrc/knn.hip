@@ -551,6 +551,9 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool rerun = !PRE32 && k1 == -1;  // second pass: only the queries the prefilter gave up on
   if (rerun && ovf_flags[q] != 2u) return;
+  // f32 / bf16 data with duplicates kept: the distances are f32 values, so the squared distance is
+  // ranked through the packed key as well and the root is taken once, on output (same bits)
+  const bool pack32 = !PRE32 && sizeof(TA) == 4 && dedup == 0;
   for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
   if (PRE32)
     for (int j = tid; j < d; j += 256) qs32[j] = (float)ld<TD>(Q + q * d + j);
@@ -753,10 +756,12 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     // ---- distances of the new candidates ----
     if constexpr (PRE32)
       batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
+    else if (pack32)
+      batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8), false>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     __syncthreads();
-    const int nb = PRE32 ? select_packed(fill, k1) : select(fill, k, dedup);
+    const int nb = PRE32 ? select_packed(fill, k1) : pack32 ? select_packed(fill, k) : select(fill, k, dedup);
     best = nb;
     if (r_next >= nr_tot) break;
   }
@@ -804,7 +809,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   for (int i = tid; i < k; i += 256) {
     const bool ok = i < best;
     out_ids[q * k + i] = ok ? bid[i] : -1;
-    out_dist[q * k + i] = ok ? bdist[i] : __longlong_as_double(0x7ff0000000000000LL);
+    out_dist[q * k + i] = ok ? (pack32 ? (double)sqrt(bdist[i]) : bdist[i])
+                             : __longlong_as_double(0x7ff0000000000000LL);
   }
   if (tid == 0) out_cnt[q] = best;
 }
@@ -855,6 +861,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   if (q >= nq) return;  // no workgroup barrier below
   const bool rerun = !PRE32 && k1 == -1;  // second pass: only the queries the prefilter gave up on
   if (rerun && ovf_flags[q] != 2u) return;
+  const bool pack32 = !PRE32 && sizeof(TA) == 4 && dedup == 0;  // see knn_fused_kernel
   unsigned char* base = smem + (size_t)wave * fused_wave_bytes(d, sizeof(TA));
   double* cdist = reinterpret_cast<double*>(base);                 // [kWC]
   double* bdist = cdist + kWC;                                     // [kFK]
@@ -1047,11 +1054,14 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     wave_sync();
     if constexpr (PRE32)
       batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, 0, 1, lane);
+    else if (pack32)
+      batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8), false>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
     wave_sync();
     const int nb = PRE32 ? wselect_packed(fill, first_new, pb0, k1)
-                         : wselect(fill, first_new, pb0, k, dedup);
+                 : pack32 ? wselect_packed(fill, first_new, pb0, k)
+                          : wselect(fill, first_new, pb0, k, dedup);
     best = nb;
     if (r_next >= nr_tot) break;
   }
@@ -1082,7 +1092,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   for (int i = lane; i < k; i += 64) {
     const bool ok = i < best;
     out_ids[q * k + i] = ok ? bid[i] : -1;
-    out_dist[q * k + i] = ok ? bdist[i] : kInf;
+    out_dist[q * k + i] = ok ? (pack32 ? (double)sqrt(bdist[i]) : bdist[i]) : kInf;
   }
   if (lane == 0) out_cnt[q] = best;
 }
