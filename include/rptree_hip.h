@@ -11,7 +11,8 @@
  *   - Plain C: opaque handles, raw pointers, sizes.  No torch / C++ types.
  *   - Every function returns an int32 status: 0 = ok, negative = error (RPT_E_*).
  *     rpt_last_error() returns a message for the calling thread.  Nothing throws or aborts
- *     across the ABI.  There is NO CPU fallback: without a usable HIP device every compute
+ *     across the ABI: every entry point catches C++ exceptions of its host-side planners
+ *     (std::bad_alloc -> RPT_E_NOMEM, anything else -> RPT_E_INTERNAL).  There is NO CPU fallback: without a usable HIP device every compute
  *     entry point fails with RPT_E_HIP.
  *   - Ownership: the caller owns every host buffer it passes or receives.  The library owns
  *     device memory behind the opaque handles; release it with the matching *_free.
@@ -84,6 +85,19 @@ int32_t rpt_ctx_trim(rpt_ctx* ctx);
 /* the hipStream_t all work of this ctx is enqueued on (for HIP-event timing by the caller) */
 int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
 
+/* Algorithm switches of a context.  They exist for the parity tests of the fallback paths and
+ * for A/B timing; every default is the tuned path and results never depend on them (beyond the
+ * documented tolerances of the MFMA projections).  rpt_ctx_create seeds them ONCE from the
+ * environment (RPT_<NAME>, upper case); no entry point reads the environment afterwards.
+ *   no_stream, stream_maxnodes, stream_minper, no_wmid, no_midselect, stream_big_node, no_wsub
+ *       median split: which regime handles which level
+ *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
+ *   knn_wave (-1 auto, 0, 1), knn_kp, knn_no_pre32, knn_general     query kernels
+ *   debug_host, debug_stamps       stderr diagnostics
+ * Unknown names: RPT_E_ARG. */
+int32_t rpt_ctx_set_option(rpt_ctx* ctx, const char* name, int64_t value);
+int32_t rpt_ctx_get_option(rpt_ctx* ctx, const char* name, int64_t* value);
+
 /* ---- kernel timing (bench.py roofline): HIP events recorded on the ctx stream around every
  * launch of a kernel class while enabled.  which: 0 = projection batch kernels (one launch =
  * one pass over the whole point set for up to 96 hyperplanes), 1 = split work,
@@ -145,6 +159,11 @@ int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_h
                           int32_t L, int32_t min_leaf, const int32_t* perm_host,
                           const double* thr_host, const double* mglo_host,
                           const double* mghi_host, rpt_forest** out);
+/* projection mode the forest's thresholds were computed with; queries project with the same
+ * kernels.  A forest imported with rpt_forest_import starts as RPT_PROJ_AUTO: restore the
+ * builder's mode with rpt_forest_set_mode (the flat on-disk format stores it). */
+int32_t rpt_forest_get_mode(const rpt_forest* f, int32_t* mode);
+int32_t rpt_forest_set_mode(rpt_forest* f, int32_t mode);
 /* number of nodes whose cut went through the exact tie-resolution path (statistics) */
 int32_t rpt_forest_stats(rpt_forest* f, int64_t* tie_nodes, int64_t* big_mid_nodes);
 
@@ -200,7 +219,9 @@ int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total);
 
 /* multi-GPU merge: G per-shard results (shard g holds trees [g*T/G, (g+1)*T/G)), gathered
  * shard-major as ids_dev[G][nq][k] etc. (e.g. by an RCCL all-gather), merged into the
- * global top-k with the reference's stable order (shard ascending = tree ascending). */
+ * global top-k with the reference's stable order (shard ascending = tree ascending).
+ * Any G >= 1 and k <= 1024: up to 4096 entries per query merge in one launch, larger merges
+ * fold the shards in one at a time (same order). */
 int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
                           const int32_t* count_dev, int32_t G, int64_t nq, int32_t k,
                           int32_t flags, int32_t* out_ids_dev, double* out_dist_dev,
@@ -216,6 +237,54 @@ int32_t rpt_knn_merge_records_dev(rpt_ctx* ctx, const void* records_dev, int64_t
                                   int32_t G, int64_t nq, int32_t k, int32_t flags,
                                   int32_t* out_ids_dev, double* out_dist_dev,
                                   int32_t* out_count_dev);
+
+/* ---- multi-GPU: tree shards per device, ONE RCCL all-gather per query batch ----
+ * Reference contract: the trees of a forest are independent (createMulti maps create over the
+ * IntMap, Internal.hs:234-240) and knn concatenates the per-tree candidates in key order before
+ * one stable sort (RPTree.hs:174-176).  Rank r of G holds the contiguous tree block
+ * [r*T/G, (r+1)*T/G) and a replica of the point set; the build needs no communication; a query
+ * batch is answered per shard into one exchange record (rpt_knn_record_layout), the records are
+ * all-gathered over xGMI (ncclAllGather on the ctx streams, librccl) and merged on every device
+ * in (distance, shard, rank) order = the reference's order.  The result is identical to
+ * rpt_knn_* on the whole forest on one device.
+ *
+ * A communicator is formed either by ONE process for n devices (rpt_comm_init: ncclCommInitAll,
+ * one rpt_ctx and one host worker thread per device; the ctxs are owned by the communicator)
+ * or by one process PER device (rpt_comm_init_rank with the caller's ctx; rank 0 makes the id
+ * with rpt_comm_unique_id and the host distributes its RPT_COMM_UID_BYTES bytes, e.g. through
+ * the launcher's store).  Per-device arguments (ds, data, queries, outputs) are arrays of
+ * `nlocal` entries, entry g living on the device of rpt_comm_ctx(comm, g): n entries after
+ * rpt_comm_init(n), one after rpt_comm_init_rank. */
+#define RPT_COMM_UID_BYTES 128
+typedef struct rpt_comm rpt_comm;
+typedef struct rpt_sharded_forest rpt_sharded_forest;
+int32_t rpt_comm_init(int32_t n_gpus, rpt_comm** out);
+int32_t rpt_comm_unique_id(void* uid_out /*[RPT_COMM_UID_BYTES]*/);
+int32_t rpt_comm_init_rank(rpt_ctx* ctx, int32_t nranks, int32_t rank,
+                           const void* uid /*[RPT_COMM_UID_BYTES]*/, rpt_comm** out);
+int32_t rpt_comm_destroy(rpt_comm* comm);
+int32_t rpt_comm_info(const rpt_comm* comm, int32_t* nranks, int32_t* nlocal, int32_t* first_rank);
+int32_t rpt_comm_ctx(rpt_comm* comm, int32_t local_index, rpt_ctx** ctx);   /* borrowed */
+int32_t rpt_comm_sync(rpt_comm* comm);                    /* rpt_ctx_sync of every local ctx */
+/* createMulti (Internal.hs:234-240) sharded: R_host is the WHOLE forest's [T][L][d] block (every
+ * rank passes the same); local device g builds the trees of rank first_rank + g.  T >= nranks. */
+int32_t rpt_forest_build_sharded(rpt_comm* comm, const rpt_dataset* const* ds,
+                                 const double* R_host, int32_t T, int32_t L, int32_t min_leaf,
+                                 int32_t flags, rpt_sharded_forest** out);
+int32_t rpt_sharded_forest_free(rpt_sharded_forest* sf);
+/* the shard of local device g as an ordinary forest handle (borrowed) and its tree block */
+int32_t rpt_sharded_forest_local(rpt_sharded_forest* sf, int32_t local_index, rpt_forest** f,
+                                 int32_t* first_tree, int32_t* n_trees);
+/* knn (RPTree.hs:168-176) over the sharded forest.  _dev: every local device receives the merged
+ * answer in its own output buffers ([nq][k] ids / distances, [nq] counts), enqueued on the ctx
+ * streams (rpt_comm_sync before reading).  rpt_knn_sharded copies device 0's answer to the host. */
+int32_t rpt_knn_sharded_dev(rpt_comm* comm, rpt_sharded_forest* sf,
+                            const rpt_dataset* const* data, const rpt_dataset* const* queries,
+                            int32_t k, int32_t flags, int32_t* const* ids_dev,
+                            double* const* dist_dev, int32_t* const* count_dev);
+int32_t rpt_knn_sharded(rpt_comm* comm, rpt_sharded_forest* sf, const rpt_dataset* const* data,
+                        const rpt_dataset* const* queries, int32_t k, int32_t flags,
+                        int32_t* ids_host, double* dist_host, int32_t* count_host);
 
 /* brute-force exact kNN on the device (evaluation of recall; ties by ascending id) */
 int32_t rpt_brute_knn_host(rpt_ctx* ctx, const rpt_dataset* data, const rpt_dataset* queries,

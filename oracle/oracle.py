@@ -67,6 +67,8 @@ def lib():
         L.rpo_next_double.restype = C.c_double
         L.rpo_next_word64.restype = C.c_uint64
         L.rpo_normal.restype = C.c_double
+        L.rpo_keep_counts.restype = C.c_int64
+        L.rpo_recall_with_dense_values.restype = C.c_double
     return _lib
 
 
@@ -217,21 +219,33 @@ def _alloc(N, T, L, want_proj):
     return perm, thr, mglo, mghi, proj
 
 
-def forest_build_dense(X, R, min_leaf, want_proj=False):
-    X = np.ascontiguousarray(X, dtype=np.float64)
+def _rows(X):
+    """dense rows for the typed entry points: float32 stays float32 (upcast exactly on read by
+    the oracle), everything else becomes float64 -> (array, xdtype)"""
+    X = np.asarray(X)
+    if X.dtype == np.float32:
+        return np.ascontiguousarray(X), 1
+    return np.ascontiguousarray(X, dtype=np.float64), 0
+
+
+def forest_build_dense(X, R, min_leaf, want_proj=False, threads=1):
+    """float32 X: the reference's arithmetic on the exactly-upcast rows.  threads > 1 builds
+    trees concurrently (identical result; the reference is single-threaded)."""
+    X, xdt = _rows(X)
     R = np.ascontiguousarray(R, dtype=np.float64)
     N, d = X.shape
     T, L, d2 = R.shape
     assert d2 == d
     perm, thr, mglo, mghi, proj = _alloc(N, T, L, want_proj)
-    lib().rpo_forest_build_dense(_p(X, _f64p), C.c_int64(N), C.c_int32(d), _p(R, _f64p),
-                                 C.c_int32(T), C.c_int32(L), C.c_int32(min_leaf),
-                                 _p(perm, _i32p), _p(thr, _f64p), _p(mglo, _f64p),
-                                 _p(mghi, _f64p), _p(proj, _f64p))
+    lib().rpo_forest_build_dense_ex(C.c_void_p(X.ctypes.data), C.c_int32(xdt), C.c_int64(N),
+                                    C.c_int32(d), _p(R, _f64p), C.c_int32(T), C.c_int32(L),
+                                    C.c_int32(min_leaf), _p(perm, _i32p), _p(thr, _f64p),
+                                    _p(mglo, _f64p), _p(mghi, _f64p), _p(proj, _f64p),
+                                    C.c_int32(threads))
     return Forest(N, d, R, L, min_leaf, perm, thr, mglo, mghi, proj)
 
 
-def forest_build_csr(rowptr, col, val, d, R, min_leaf, want_proj=False):
+def forest_build_csr(rowptr, col, val, d, R, min_leaf, want_proj=False, threads=1):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int32)
     val = np.ascontiguousarray(val, dtype=np.float64)
@@ -240,10 +254,11 @@ def forest_build_csr(rowptr, col, val, d, R, min_leaf, want_proj=False):
     T, L, d2 = R.shape
     assert d2 == d
     perm, thr, mglo, mghi, proj = _alloc(N, T, L, want_proj)
-    lib().rpo_forest_build_csr(_p(rowptr, _i64p), _p(col, _i32p), _p(val, _f64p), C.c_int64(N),
-                               C.c_int32(d), _p(R, _f64p), C.c_int32(T), C.c_int32(L),
-                               C.c_int32(min_leaf), _p(perm, _i32p), _p(thr, _f64p),
-                               _p(mglo, _f64p), _p(mghi, _f64p), _p(proj, _f64p))
+    lib().rpo_forest_build_csr_ex(_p(rowptr, _i64p), _p(col, _i32p), _p(val, _f64p),
+                                  C.c_int64(N), C.c_int32(d), _p(R, _f64p), C.c_int32(T),
+                                  C.c_int32(L), C.c_int32(min_leaf), _p(perm, _i32p),
+                                  _p(thr, _f64p), _p(mglo, _f64p), _p(mghi, _f64p),
+                                  _p(proj, _f64p), C.c_int32(threads))
     return Forest(N, d, R, L, min_leaf, perm, thr, mglo, mghi, proj)
 
 
@@ -283,6 +298,35 @@ def knn_dense(f, X, q, k, dedup=False):
                             *_fargs(f), *_targs(f), C.c_int32(k), C.c_int32(int(dedup)),
                             _p(ids, _i32p), _p(dist, _f64p))
     return ids[:m].copy(), dist[:m].copy()
+
+
+def knn_dense_batch(f, X, Q, k, dedup=0, vote_thr=0, threads=1):
+    """knn for a batch of dense queries -> (ids[nq][k], dist[nq][k], count[nq]); float32 X is
+    upcast exactly on read; vote_thr > 0 = keepCounts before the distances (extension)."""
+    X, xdt = _rows(X)
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    if Q.ndim == 1:
+        Q = Q[None, :]
+    nq = Q.shape[0]
+    ids = np.empty((nq, k), dtype=np.int32)
+    dist = np.empty((nq, k), dtype=np.float64)
+    cnt = np.empty(nq, dtype=np.int32)
+    lib().rpo_knn_dense_batch(C.c_void_p(X.ctypes.data), C.c_int32(xdt), C.c_int64(f.N),
+                              C.c_int32(f.d), _p(Q, _f64p), C.c_int64(nq), *_fargs(f),
+                              *_targs(f), C.c_int32(k), C.c_int32(int(dedup)),
+                              C.c_int32(int(vote_thr)), _p(ids, _i32p), _p(dist, _f64p),
+                              _p(cnt, _i32p), C.c_int32(threads))
+    return ids, dist, cnt
+
+
+def keep_counts(ids, thr):
+    """RPTree.hs:464-478 counts + keepCounts -> (ids ascending, counts)"""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    oi = np.empty(len(ids), dtype=np.int32)
+    oc = np.empty(len(ids), dtype=np.int32)
+    m = lib().rpo_keep_counts(_p(ids, _i32p), C.c_int64(len(ids)), C.c_int32(thr), _p(oi, _i32p),
+                              _p(oc, _i32p))
+    return oi[:m].copy(), oc[:m].copy()
 
 
 def knn_csr(f, rowptr, col, val, qi, qv, k, dedup=False, true_l2=False):
@@ -353,6 +397,51 @@ def recall_with_dense(f, X, q, k):
     q = np.ascontiguousarray(q, dtype=np.float64)
     return lib().rpo_recall_with_dense(_p(X, _f64p), C.c_int64(f.N), C.c_int32(f.d),
                                        _p(q, _f64p), *_fargs(f), *_targs(f), C.c_int32(k))
+
+
+def recall_with_dense_values(f, X, q, k):
+    """RPTree.hs:259-282 with Set-of-values semantics (equal rows are one element)"""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    return lib().rpo_recall_with_dense_values(_p(X, _f64p), C.c_int64(f.N), C.c_int32(f.d),
+                                              _p(q, _f64p), *_fargs(f), *_targs(f), C.c_int32(k))
+
+
+class StreamForest:
+    """Result of the streaming build (heap arrays of 2^(L+1)-1 slots per tree)."""
+
+    def __init__(self, N, L, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids, held):
+        self.N, self.L = N, L
+        self.kind, self.thr, self.mglo, self.mghi = kind, thr, mglo, mghi
+        self.leaf_off, self.leaf_len, self.leaf_ids, self.held = leaf_off, leaf_len, leaf_ids, held
+
+    def leaves(self, t):
+        """Tip payloads of tree t in heap order: {heap: ids}"""
+        return {int(h): self.leaf_ids[t, self.leaf_off[t, h]:self.leaf_off[t, h] + self.leaf_len[t, h]]
+                for h in np.nonzero(self.kind[t] == 2)[0]}
+
+
+def stream_forest_dense(X, R, min_leaf, chunk):
+    """Conduit.hs:104-121 `forest` on a source yielding the rows of X in order, in chunks of
+    `chunk` points (insertMultiC / Internal.hs:245-297)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    N, d = X.shape
+    T, L, _ = R.shape
+    S = (1 << (L + 1)) - 1
+    kind = np.zeros((T, S), dtype=np.int8)
+    thr, mglo, mghi = (np.empty((T, S), dtype=np.float64) for _ in range(3))
+    leaf_off = np.zeros((T, S), dtype=np.int64)
+    leaf_len = np.zeros((T, S), dtype=np.int64)
+    leaf_ids = np.full((T, max(N, 1)), -1, dtype=np.int32)
+    held = np.zeros(T, dtype=np.int64)
+    lib().rpo_stream_forest_dense(_p(X, _f64p), C.c_int64(N), C.c_int32(d), _p(R, _f64p),
+                                  C.c_int32(T), C.c_int32(L), C.c_int32(min_leaf),
+                                  C.c_int64(chunk), kind.ctypes.data_as(C.POINTER(C.c_int8)),
+                                  _p(thr, _f64p), _p(mglo, _f64p), _p(mghi, _f64p),
+                                  _p(leaf_off, _i64p), _p(leaf_len, _i64p), _p(leaf_ids, _i32p),
+                                  _p(held, _i64p))
+    return StreamForest(N, L, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids, held)
 
 
 def brute_knn_dense(X, q, k):

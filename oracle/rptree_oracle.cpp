@@ -8,10 +8,13 @@
 #include "rptree_oracle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <set>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -79,14 +82,31 @@ std::vector<SparseVec> sparsify(const double* R, int32_t T, int32_t L, int32_t d
 
 // A data accessor abstracts DVector rows vs SVector (CSR) rows so that the tree code is
 // written once, like the reference's `Inner SVector v` constraint (Internal.hs:316-341).
-struct DenseData {
-  const double* X;
+// E = double is the reference's type; E = float rows (f32 / bf16 datasets, build extensions)
+// are converted to double on read, which is exact, so the arithmetic below is the reference's
+// arithmetic on the upcast data.
+template <class E>
+struct DenseDataT {
+  const E* X;
   int64_t N;
   int32_t d;
   double inner(const SparseVec& r, int64_t id) const {  // Inner SVector DVector, :332-333
-    return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, X + id * d);
+    // innerSD, Internal.hs:369-382 (same loop as rpo_inner_sd)
+    const E* x = X + id * d;
+    const int64_t n1 = (int64_t)r.idx.size();
+    const int64_t m = n1 < d ? n1 : d;
+    double acc = 0.0;
+    for (int64_t j = m - 1; j >= 0; --j) acc = r.val[j] * (double)x[r.idx[j]] + acc;
+    return acc;
+  }
+  double metric(int64_t id, const double* q) const {  // metricDDL2, Internal.hs:403-406
+    const E* x = X + id * d;
+    double acc = 0.0;
+    for (int32_t j = 0; j < d; ++j) acc = acc + std::pow((double)x[j] - q[j], 2.0);
+    return std::sqrt(acc);
   }
 };
+using DenseData = DenseDataT<double>;
 struct CsrData {
   const int64_t* rowptr;
   const int32_t* col;
@@ -154,13 +174,19 @@ void build_node(const Data& D, const std::vector<SparseVec>& rvs /*L vectors of 
   build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 2, off + nh, rr, ft, proj_tree);  // :297
 }
 
+// threads > 1: the trees of a forest are independent (createMulti maps `create` over the IntMap,
+// Internal.hs:234-240), so they may be built concurrently; every tree is still built by the
+// sequential recursion above and the result does not depend on the thread count.  The
+// reference itself is single-threaded: threads = 1 is "the reference CPU path", more threads
+// are the courtesy all-core baseline of SURVEY 8(d).
 template <class Data>
 void forest_build(const Data& D, const double* R, int32_t T, int32_t L, int32_t minLeaf,
-                  int32_t* perm, double* thr, double* mglo, double* mghi, double* proj_out) {
+                  int32_t* perm, double* thr, double* mglo, double* mghi, double* proj_out,
+                  int32_t threads = 1) {
   const int64_t nodes = ((int64_t)1 << L) - 1;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   std::vector<SparseVec> all = sparsify(R, T, L, D.d);
-  for (int32_t t = 0; t < T; ++t) {  // createMulti, Internal.hs:234-240 (ascending key)
+  auto one_tree = [&](int32_t t) {  // create, Internal.hs:217-225
     for (int64_t h = 0; h < nodes; ++h)
       thr[t * nodes + h] = mglo[t * nodes + h] = mghi[t * nodes + h] = nan;
     std::vector<SparseVec> rvs(all.begin() + (size_t)t * L, all.begin() + (size_t)(t + 1) * L);
@@ -169,7 +195,18 @@ void forest_build(const Data& D, const double* R, int32_t T, int32_t L, int32_t 
     FlatTree ft{perm + (int64_t)t * D.N, thr + t * nodes, mglo + t * nodes, mghi + t * nodes};
     build_node(D, rvs, L, minLeaf, 0, 0, 0, ids, ft,
                proj_out ? proj_out + (int64_t)t * L * D.N : nullptr);
+  };
+  if (threads <= 1 || T <= 1) {
+    for (int32_t t = 0; t < T; ++t) one_tree(t);  // createMulti, ascending key
+    return;
   }
+  std::atomic<int32_t> next(0);
+  std::vector<std::thread> pool;
+  for (int32_t w = 0; w < std::min(threads, T); ++w)
+    pool.emplace_back([&] {
+      for (int32_t t = next.fetch_add(1); t < T; t = next.fetch_add(1)) one_tree(t);
+    });
+  for (std::thread& th : pool) th.join();
 }
 
 // RPTree.hs:297-314 `candidates`, on the flat layout.  projq[level] = r_level `inner` q.
@@ -802,6 +839,330 @@ void rpo_brute_knn_dense(const double* X, int64_t N, int32_t d, const double* q,
     out_ids[i] = ds[i].id;
     out_dist[i] = ds[i].dist;
   }
+}
+
+
+// ------------------------------- typed / threaded variants ---------------------------------
+// xdtype: 0 = double rows (the reference), 1 = float rows (upcast exactly on read).
+void rpo_forest_build_dense_ex(const void* X, int32_t xdtype, int64_t N, int32_t d,
+                               const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                               int32_t* perm, double* thr, double* mglo, double* mghi,
+                               double* proj_out, int32_t threads) {
+  if (xdtype == 1) {
+    DenseDataT<float> D{(const float*)X, N, d};
+    forest_build(D, R, T, L, minLeaf, perm, thr, mglo, mghi, proj_out, threads);
+  } else {
+    DenseDataT<double> D{(const double*)X, N, d};
+    forest_build(D, R, T, L, minLeaf, perm, thr, mglo, mghi, proj_out, threads);
+  }
+}
+void rpo_forest_build_csr_ex(const int64_t* rowptr, const int32_t* col, const double* val,
+                             int64_t N, int32_t d, const double* R, int32_t T, int32_t L,
+                             int32_t minLeaf, int32_t* perm, double* thr, double* mglo,
+                             double* mghi, double* proj_out, int32_t threads) {
+  CsrData D{rowptr, col, val, N, d};
+  forest_build(D, R, T, L, minLeaf, perm, thr, mglo, mghi, proj_out, threads);
+}
+
+// knn (RPTree.hs:168-176) for a batch of dense queries Q[nq][d] (double); queries are
+// independent, `threads` of them are answered concurrently.  out_ids/out_dist [nq][k], unused
+// slots -1 / +inf; out_count[nq].  vote_thr > 0: the candidate ids are first reduced by
+// keepCounts (see rpo_keep_counts) — an extension, the reference's knn never does that.
+}  // extern "C"
+namespace {
+template <class E>
+void knn_batch(const DenseDataT<E>& D, const double* Q, int64_t nq, const double* R, int32_t T,
+               int32_t L, int32_t minLeaf, const int32_t* perm, const double* thr,
+               const double* mglo, const double* mghi, int32_t k, int32_t dedup, int32_t vote_thr,
+               int32_t* out_ids, double* out_dist, int32_t* out_count, int32_t threads) {
+  std::vector<SparseVec> all = sparsify(R, T, L, D.d);
+  auto one = [&](int64_t i) {
+    const double* q = Q + i * D.d;
+    std::vector<int32_t> c;
+    for (int32_t t = 0; t < T; ++t)
+      tree_candidates(
+          [&](const SparseVec& r) {
+            return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), D.d, q);
+          },
+          all, L, minLeaf, D.N, perm, thr, mglo, mghi, t, c);
+    if (vote_thr > 0) {  // counts + keepCounts, RPTree.hs:464-478: ascending key order
+      std::map<int32_t, int32_t> mm;
+      for (int32_t id : c) mm[id] += 1;
+      c.clear();
+      for (const auto& kv : mm)
+        if (kv.second >= vote_thr) c.push_back(kv.first);
+    }
+    std::vector<DistId> cs(c.size());
+    for (size_t j = 0; j < c.size(); ++j) cs[j] = {D.metric(c[j], q), c[j]};
+    int32_t* oi = out_ids + i * k;
+    double* od = out_dist + i * k;
+    const int32_t m = topk_from(cs, k, dedup, oi, od);
+    for (int32_t j = m; j < k; ++j) {
+      oi[j] = -1;
+      od[j] = std::numeric_limits<double>::infinity();
+    }
+    out_count[i] = m;
+  };
+  if (threads <= 1 || nq <= 1) {
+    for (int64_t i = 0; i < nq; ++i) one(i);
+    return;
+  }
+  std::atomic<int64_t> next(0);
+  std::vector<std::thread> pool;
+  for (int32_t w = 0; w < threads; ++w)
+    pool.emplace_back([&] {
+      for (int64_t i = next.fetch_add(1); i < nq; i = next.fetch_add(1)) one(i);
+    });
+  for (std::thread& th : pool) th.join();
+}
+}  // namespace
+extern "C" {
+
+void rpo_knn_dense_batch(const void* X, int32_t xdtype, int64_t N, int32_t d, const double* Q,
+                         int64_t nq, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                         const int32_t* perm, const double* thr, const double* mglo,
+                         const double* mghi, int32_t k, int32_t dedup, int32_t vote_thr,
+                         int32_t* out_ids, double* out_dist, int32_t* out_count,
+                         int32_t threads) {
+  if (xdtype == 1) {
+    DenseDataT<float> D{(const float*)X, N, d};
+    knn_batch(D, Q, nq, R, T, L, minLeaf, perm, thr, mglo, mghi, k, dedup, vote_thr, out_ids,
+              out_dist, out_count, threads);
+  } else {
+    DenseDataT<double> D{(const double*)X, N, d};
+    knn_batch(D, Q, nq, R, T, L, minLeaf, perm, thr, mglo, mghi, k, dedup, vote_thr, out_ids,
+              out_dist, out_count, threads);
+  }
+}
+
+// RPTree.hs:464-478 (commented-out sketch in the reference): `counts` folds the candidate list
+// into a Map id -> occurrences, `keepCounts thr` keeps the entries with count >= thr via
+// M.foldrWithKey — i.e. in ASCENDING key order.  ids[n] in, (out_ids, out_counts) out; returns
+// the number kept.
+int64_t rpo_keep_counts(const int32_t* ids, int64_t n, int32_t thr, int32_t* out_ids,
+                        int32_t* out_counts) {
+  std::map<int32_t, int32_t> mm;  // count: M.insertWith mappend x (Sum 1)
+  for (int64_t i = 0; i < n; ++i) mm[ids[i]] += 1;
+  int64_t m = 0;
+  for (const auto& kv : mm)
+    if (kv.second >= thr) {  // v >= thr
+      out_ids[m] = kv.first;
+      out_counts[m] = kv.second;
+      ++m;
+    }
+  return m;
+}
+
+// recallWith (RPTree.hs:259-282) with the reference's VALUE semantics: `aa` and `kk` are
+// Data.Sets of `Embed` values (derived Ord: the vector's components, then the payload), so
+// points with identical coordinates — and, here, no payload (`Embed v ()`) — collapse to one
+// element in either set.  rpo_recall_with_dense compares point IDS (payload = the id); this
+// variant compares rows with Double's (==) (so -0.0 == 0.0).
+}  // extern "C"
+namespace {
+struct RowLess {
+  const double* X;
+  int32_t d;
+  bool operator()(int32_t a, int32_t b) const {
+    const double *x = X + (int64_t)a * d, *y = X + (int64_t)b * d;
+    for (int32_t j = 0; j < d; ++j) {
+      if (x[j] < y[j]) return true;
+      if (y[j] < x[j]) return false;
+    }
+    return false;
+  }
+};
+}  // namespace
+extern "C" {
+double rpo_recall_with_dense_values(const double* X, int64_t N, int32_t d, const double* q,
+                                    const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                                    const int32_t* perm, const double* thr, const double* mglo,
+                                    const double* mghi, int32_t k) {
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  double sum = 0.0;
+  RowLess less{X, d};
+  for (int32_t t = 0; t < T; ++t) {
+    std::vector<int32_t> c;
+    tree_candidates(
+        [&](const SparseVec& r) {
+          return rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+        },
+        all, L, minLeaf, N, perm, thr, mglo, mghi, t, c);
+    std::set<int32_t, RowLess> aa(c.begin(), c.end(), less);
+    std::vector<DistId> ds((size_t)N);
+    const int32_t* pt = perm + (int64_t)t * N;
+    for (int64_t i = 0; i < N; ++i) ds[i] = {rpo_metric_dd(d, X + (int64_t)pt[i] * d, q), pt[i]};
+    std::stable_sort(ds.begin(), ds.end(),
+                     [](const DistId& a, const DistId& b) { return a.dist < b.dist; });
+    std::set<int32_t, RowLess> kk(less);
+    for (int64_t i = 0; i < k && i < N; ++i) kk.insert(ds[i].id);
+    int64_t inter = 0;
+    for (int32_t id : kk) inter += aa.count(id);
+    sum += (double)inter / (double)k;
+  }
+  return sum / (double)T;
+}
+
+// ------------------------------- streaming insert ------------------------------------------
+// Conduit.hs:147-176 insertMultiC / chunkedAccum over Internal.hs:245-297 insertMulti / insert:
+// the source is cut into chunks of `chunk` points (C.chunksOf: the last one may be shorter) and
+// every chunk is folded into every tree with `insert`.  Unlike the batch build the topology is
+// data dependent, so the tree is returned as heap arrays of 2^(L+1)-1 slots:
+//   kind[h]   0 = absent, 1 = Bin, 2 = Tip
+//   thr/mglo/mghi[h] for Bins, leaf_off[h]..leaf_off[h]+leaf_len[h] into leaf_ids for Tips.
+// Returns, per tree, the number of points held (sum of the Tip sizes): less than N when the
+// data-loss branch of `insert` was taken (see stream_insert below).
+}  // extern "C"
+namespace {
+struct StreamNode {
+  int kind = 2;  // a fresh accumulator is `Tip () mempty`
+  double thr = 0, mglo = 0, mghi = 0;
+  std::vector<int32_t> xs;  // Tip payload, in the reference's order
+};
+struct StreamTree {
+  std::vector<StreamNode> nodes;  // heap order
+  int64_t dropped = 0;
+};
+
+template <class Data>
+bool partition_ids(const Data& D, const SparseVec& r, const std::vector<int32_t>& xs, double* thr,
+                   double* mgl, double* mgr, std::vector<int32_t>& ll, std::vector<int32_t>& rr) {
+  const int64_t n = (int64_t)xs.size();
+  if (n < 1) return false;  // Internal.hs:492 Nothing
+  std::vector<std::pair<double, int32_t>> projs((size_t)n);
+  for (int64_t i = 0; i < n; ++i) projs[i] = {D.inner(r, xs[i]), xs[i]};
+  std::stable_sort(projs.begin(), projs.end(),
+                   [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) {
+                     return a.first < b.first;
+                   });
+  const int64_t nh = n / 2;
+  if (n >= 3) {
+    *mgl = projs[nh - 1].first;
+    *mgr = projs[nh + 1].first;
+  } else if (n == 2) {
+    *mgl = projs[0].first;
+    *mgr = projs[1].first;
+  } else {
+    *mgl = *mgr = projs[0].first;
+  }
+  *thr = projs[nh].first;
+  ll.resize((size_t)nh);
+  rr.resize((size_t)(n - nh));
+  for (int64_t i = 0; i < nh; ++i) ll[i] = projs[i].second;
+  for (int64_t i = nh; i < n; ++i) rr[i - nh] = projs[i].second;
+  return true;
+}
+
+int64_t subtree_points(const StreamTree& st, int64_t h) {
+  if (h >= (int64_t)st.nodes.size()) return 0;
+  const StreamNode& nd = st.nodes[h];
+  if (nd.kind == 2) return (int64_t)nd.xs.size();
+  if (nd.kind == 1) return subtree_points(st, 2 * h + 1) + subtree_points(st, 2 * h + 2);
+  return 0;
+}
+void clear_subtree(StreamTree& st, int64_t h) {
+  if (h >= (int64_t)st.nodes.size()) return;
+  StreamNode& nd = st.nodes[h];
+  if (nd.kind == 1) {
+    clear_subtree(st, 2 * h + 1);
+    clear_subtree(st, 2 * h + 2);
+  }
+  nd.kind = 0;
+  nd.xs.clear();
+}
+
+// Internal.hs:258-297 `insert`'s loop, one chunk `xs` (consumed) into the subtree at heap h.
+template <class Data>
+void stream_insert(const Data& D, const std::vector<SparseVec>& rvs, int32_t maxDepth,
+                   int32_t minLeaf, StreamTree& st, int32_t ixLev, int64_t h,
+                   std::vector<int32_t>& xs) {
+  StreamNode& nd = st.nodes[h];
+  if (nd.kind == 1) {                    // :272 Bin _ thr0 margin0 tl0 tr0
+    if (ixLev >= maxDepth) return;       // :273-274 (unreachable for a fixed maxDepth)
+    double thr, mgl, mgr;
+    std::vector<int32_t> ll, rr;
+    if (!partition_ids(D, rvs[ixLev], xs, &thr, &mgl, &mgr, ll, rr)) {
+      // :277 Nothing -> Tip () mempty : an EMPTY chunk half reaching a Bin REPLACES the whole
+      // subtree — every point stored below it is lost.
+      st.dropped += subtree_points(st, h);
+      clear_subtree(st, h);
+      st.nodes[h].kind = 2;
+      return;
+    }
+    nd.mglo = nd.mglo >= mgl ? nd.mglo : mgl;  // :280 margin0 <> margin: (Max, Min), :86-87
+    nd.mghi = nd.mghi <= mgr ? nd.mghi : mgr;
+    nd.thr = (nd.thr + thr) / 2;               // :281
+    stream_insert(D, rvs, maxDepth, minLeaf, st, ixLev + 1, 2 * h + 1, ll);  // :282
+    stream_insert(D, rvs, maxDepth, minLeaf, st, ixLev + 1, 2 * h + 2, rr);  // :283
+    return;
+  }
+  // :285 Tip _ xs0   (kind 0 = never touched = the `z` of :268)
+  nd.kind = 2;
+  std::vector<int32_t> xs1;  // :286 xs' = xs <> xs0 : the new chunk goes FIRST
+  xs1.reserve(xs.size() + nd.xs.size());
+  xs1.insert(xs1.end(), xs.begin(), xs.end());
+  xs1.insert(xs1.end(), nd.xs.begin(), nd.xs.end());
+  if (ixLev >= maxDepth || (int64_t)xs1.size() <= (int64_t)minLeaf) {  // :287-288
+    nd.xs.swap(xs1);
+    return;
+  }
+  double thr, mgl, mgr;
+  std::vector<int32_t> ll, rr;
+  partition_ids(D, rvs[ixLev], xs1, &thr, &mgl, &mgr, ll, rr);  // :290 (xs' is not empty here)
+  nd.kind = 1;  // :292 Bin () thr margin tl tr
+  nd.thr = thr;
+  nd.mglo = mgl;
+  nd.mghi = mgr;
+  nd.xs.clear();
+  st.nodes[2 * h + 1] = StreamNode();  // :294-295 loop (ixLev + 1) z ..
+  st.nodes[2 * h + 2] = StreamNode();
+  stream_insert(D, rvs, maxDepth, minLeaf, st, ixLev + 1, 2 * h + 1, ll);
+  stream_insert(D, rvs, maxDepth, minLeaf, st, ixLev + 1, 2 * h + 2, rr);
+}
+
+template <class Data>
+void stream_forest(const Data& D, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                   int64_t chunk, int8_t* kind, double* thr, double* mglo, double* mghi,
+                   int64_t* leaf_off, int64_t* leaf_len, int32_t* leaf_ids, int64_t* held) {
+  const int64_t slots = ((int64_t)1 << (L + 1)) - 1;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  std::vector<SparseVec> all = sparsify(R, T, L, D.d);
+  for (int32_t t = 0; t < T; ++t) {
+    std::vector<SparseVec> rvs(all.begin() + (size_t)t * L, all.begin() + (size_t)(t + 1) * L);
+    StreamTree st;
+    st.nodes.assign((size_t)slots, StreamNode());
+    for (int64_t h = 1; h < slots; ++h) st.nodes[h].kind = 0;
+    for (int64_t c0 = 0; c0 < D.N; c0 += chunk) {  // C.chunksOf n .| C.foldl f z
+      std::vector<int32_t> xs;
+      for (int64_t i = c0; i < D.N && i < c0 + chunk; ++i) xs.push_back((int32_t)i);
+      stream_insert(D, rvs, L, minLeaf, st, 0, 0, xs);
+    }
+    int64_t w = 0;
+    for (int64_t h = 0; h < slots; ++h) {
+      const StreamNode& nd = st.nodes[h];
+      const int64_t o = t * slots + h;
+      kind[o] = (int8_t)nd.kind;
+      thr[o] = nd.kind == 1 ? nd.thr : nan;
+      mglo[o] = nd.kind == 1 ? nd.mglo : nan;
+      mghi[o] = nd.kind == 1 ? nd.mghi : nan;
+      leaf_off[o] = w;
+      leaf_len[o] = nd.kind == 2 ? (int64_t)nd.xs.size() : 0;
+      if (nd.kind == 2)
+        for (int32_t id : nd.xs) leaf_ids[(int64_t)t * D.N + w++] = id;
+    }
+    held[t] = w;
+  }
+}
+}  // namespace
+extern "C" {
+
+void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double* R, int32_t T,
+                             int32_t L, int32_t minLeaf, int64_t chunk, int8_t* kind, double* thr,
+                             double* mglo, double* mghi, int64_t* leaf_off, int64_t* leaf_len,
+                             int32_t* leaf_ids, int64_t* held) {
+  DenseData D{X, N, d};
+  stream_forest(D, R, T, L, minLeaf, chunk, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids,
+                held);
 }
 
 }  // extern "C"

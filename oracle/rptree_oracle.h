@@ -179,6 +179,55 @@ double rpo_recall_with_dense(const double* X, int64_t N, int32_t d, const double
 void rpo_brute_knn_dense(const double* X, int64_t N, int32_t d, const double* q, int32_t k,
                          int32_t* out_ids, double* out_dist);
 
+
+/* ---- typed / threaded variants (same arithmetic, same results) ----
+ * xdtype: 0 = double rows (the reference's type), 1 = float rows, converted to double on read
+ * (exact): the oracle then IS the reference's arithmetic on the exactly-upcast data — what the
+ * f32 / bf16 build extensions are compared with.  threads: trees (or queries) are independent;
+ * threads = 1 is the reference (single-threaded), more threads are the all-core
+ * courtesy baseline (8d-ii).  The result never depends on the thread count. */
+void rpo_forest_build_dense_ex(const void* X, int32_t xdtype, int64_t N, int32_t d,
+                               const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                               int32_t* perm, double* thr, double* mglo, double* mghi,
+                               double* proj_out, int32_t threads);
+void rpo_forest_build_csr_ex(const int64_t* rowptr, const int32_t* col, const double* val,
+                             int64_t N, int32_t d, const double* R, int32_t T, int32_t L,
+                             int32_t minLeaf, int32_t* perm, double* thr, double* mglo,
+                             double* mghi, double* proj_out, int32_t threads);
+/* knn for a batch Q[nq][d] of dense double queries; out_ids/out_dist [nq][k] (unused: -1/+inf),
+ * out_count[nq].  vote_thr > 0 first reduces the candidates with keepCounts (extension). */
+void rpo_knn_dense_batch(const void* X, int32_t xdtype, int64_t N, int32_t d, const double* Q,
+                         int64_t nq, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                         const int32_t* perm, const double* thr, const double* mglo,
+                         const double* mghi, int32_t k, int32_t dedup, int32_t vote_thr,
+                         int32_t* out_ids, double* out_dist, int32_t* out_count,
+                         int32_t threads);
+
+/* ---- counts / keepCounts, RPTree.hs:464-478 (a commented-out sketch in the reference) ----
+ * entries of the id multiset with count >= thr, ascending id (M.foldrWithKey order). */
+int64_t rpo_keep_counts(const int32_t* ids, int64_t n, int32_t thr, int32_t* out_ids,
+                        int32_t* out_counts);
+
+/* ---- recallWith with Set-of-VALUES semantics, RPTree.hs:276-282: points with equal
+ * coordinates (payload `()`) are ONE element of `aa` / `kk`.  rpo_recall_with_dense treats the
+ * point id as the payload (all points distinct). */
+double rpo_recall_with_dense_values(const double* X, int64_t N, int32_t d, const double* q,
+                                    const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                                    const int32_t* perm, const double* thr, const double* mglo,
+                                    const double* mghi, int32_t k);
+
+/* ---- streaming build: Conduit.hs:147-176 (chunkedAccum / insertMultiC) over
+ * Internal.hs:245-297 (insertMulti / insert incl. the Bin branch :272-283) ----
+ * Points 0..N-1 arrive in chunks of `chunk`.  The topology is data dependent: per tree the
+ * result is a heap array of S = 2^(L+1)-1 slots: kind[T][S] (0 absent, 1 Bin, 2 Tip),
+ * thr/mglo/mghi[T][S] (NaN unless Bin), leaf_off/leaf_len[T][S] into leaf_ids[T][N].
+ * held[T] = points actually stored; < N when an empty chunk half met a Bin (:277), which
+ * replaces the whole subtree by an empty Tip (the data-loss quirk). */
+void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double* R, int32_t T,
+                             int32_t L, int32_t minLeaf, int64_t chunk, int8_t* kind, double* thr,
+                             double* mglo, double* mghi, int64_t* leaf_off, int64_t* leaf_len,
+                             int32_t* leaf_ids, int64_t* held);
+
 #ifdef __cplusplus
 }
 #endif

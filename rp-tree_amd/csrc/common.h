@@ -108,7 +108,30 @@ struct rpt_prof_span {
   int which;
 };
 
+// Algorithm switches of a context (rpt_ctx_set_option / rpt_ctx_get_option).  They exist for
+// the parity tests of the fallback paths and for A/B timing; every default is the tuned path.
+// rpt_ctx_create initialises them ONCE from the environment (RPT_<NAME>, upper case); no entry
+// point reads the environment afterwards.
+struct rpt_options {
+  int64_t no_stream = 0;        // split: skip the streaming regime (general path from level 0)
+  int64_t stream_maxnodes = 0;  // split: nodes per tree up to which levels are streamed (0 = auto)
+  int64_t stream_minper = 32768;// split: points per histogram block
+  int64_t no_wmid = 0;          // split: pivot bins never take the one-wave bitonic path
+  int64_t no_midselect = 0;     // split: large pivot bins are sorted, not split by selection
+  int64_t stream_big_node = (int64_t)1 << 21;  // split: nodes above this get > 4096 value bins
+  int64_t no_wsub = 0;          // split: block-level subtree kernel instead of the wave kernel
+  int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only
+  int64_t proj_bf16_f32 = 0;    // projection: bf16 rows through the f32-MFMA kernels
+  int64_t knn_wave = -1;        // kNN: -1 auto, 0 workgroup-per-query, 1 wave-per-query kernel
+  int64_t knn_kp = 0;           // kNN: entries the f32 prefilter keeps (0 = k + max(6, k/2))
+  int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
+  int64_t knn_general = 0;      // kNN: unfused general path
+  int64_t debug_host = 0;       // stderr: host-side phase times of a build
+  int64_t debug_stamps = 0;     // device time stamps of the wave kernel
+};
+
 struct rpt_ctx {
+  rpt_options opt;
   int32_t device = 0;
   hipStream_t stream = nullptr;
   // pinned bump arena for small asynchronous host<->device transfers (api.hip: pin_alloc)

@@ -1400,6 +1400,7 @@ static int32_t launch_topk_dense(rpt_ctx* ctx, const rpt_dataset* data, const rp
   return RPT_OK;
 }
 
+constexpr int kMergeMax = 4096;  // entries of one merge launch (LDS)
 static inline int prefilter_keep(int k) { return k + (k / 2 > 6 ? k / 2 : 6); }
 
 // f32 shadow of a dense f64 dataset + its largest row norm (one wave per row)
@@ -1417,34 +1418,46 @@ __global__ __launch_bounds__(256) void shadow32_kernel(const double* __restrict_
       s += v * v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    mx = s > mx ? s : mx;
+    if (!(s <= mx)) mx = s == s ? s : __longlong_as_double(0x7ff0000000000000LL);  // NaN row -> +inf
   }
   if (lane == 0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));  // mx >= 0
 }
 
+// Builds the f32 shadow once per dataset.  The shadow is an optimisation: whenever it cannot be
+// had (no memory for it, a failed launch or copy, rows whose squares leave the f32 range, NaN
+// rows) the dataset is marked "tried, unusable" (max_norm = -2) and the caller continues on the
+// all-f64 path — never an error.
 static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
   if (data->shadow32 || data->max_norm == -2.0) return RPT_OK;
   void* p = nullptr;
-  if (dev_alloc(&p, (size_t)data->n * data->d * sizeof(float)) != hipSuccess)
-    return fail(RPT_E_NOMEM, "f32 shadow of the dataset");
   DevBuf<unsigned long long> mb;
-  RPT_TRY(mb.alloc(1));
-  RPT_HIP(hipMemsetAsync(mb.p, 0, 8, ctx->stream));
+  unsigned long long bits = 0;
+  auto give_up = [&]() {
+    if (p) dev_free(p);
+    (void)hipGetLastError();       // the exact path starts from a clean error state
+    data->max_norm = -2.0;
+    return RPT_OK;
+  };
+  if (dev_alloc(&p, (size_t)data->n * data->d * sizeof(float)) != hipSuccess) {
+    p = nullptr;
+    return give_up();
+  }
+  if (mb.alloc(1) != RPT_OK) return give_up();
+  if (hipMemsetAsync(mb.p, 0, 8, ctx->stream) != hipSuccess) return give_up();
   int64_t blocks = (data->n + 3) / 4;
   if (blocks > (int64_t)ctx->n_cu * 16) blocks = (int64_t)ctx->n_cu * 16;
   hipLaunchKernelGGL(shadow32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
                      (const double*)data->X, data->n, data->d, (float*)p, mb.p);
-  unsigned long long bits = 0;
-  RPT_HIP(hipMemcpyAsync(&bits, mb.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-  RPT_HIP(stream_sync(ctx->stream));
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (hipMemcpyAsync(&bits, mb.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
   double m2;
   std::memcpy(&m2, &bits, 8);
   data->max_norm = std::sqrt(m2) * (1.0 + 1e-12);
-  if (!(data->max_norm < 1e18)) {  // squares would leave the f32 range (or NaN rows): no shadow
-    dev_free(p);
-    data->max_norm = -2.0;         // tried, unusable
-    return RPT_OK;
-  }
+  // squares would leave the f32 range, or a row holds a NaN (the kernel folds a NaN sum into
+  // +inf, see shadow32_kernel): no shadow
+  if (!(data->max_norm < 1e18)) return give_up();
   data->shadow32 = (float*)p;
   return RPT_OK;
 }
@@ -1456,21 +1469,21 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                             unsigned long long* cand_total, bool rerun = false) {
   typedef typename AccOf<TD>::type TA;
   // small shards (few trees => a few hundred candidates per query): one wave per query
-  const char* force = getenv("RPT_KNN_WAVE");
+  const int64_t force = ctx->opt.knn_wave;  // -1 auto
   const size_t wbytes = fused_wave_bytes(data->d, sizeof(TA));
   bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 &&
               (int64_t)f->T * f->min_leaf <= kWaveCandidates;
-  if (force) wave = force[0] == '1' && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
+  if (force >= 0) wave = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
   ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
   // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
-  const int kp_env = getenv("RPT_KNN_KP") ? atoi(getenv("RPT_KNN_KP")) : 0;
+  const int kp_env = (int)ctx->opt.knn_kp;
   // entries the f32 pass keeps: every one costs a selection round per batch (16 of them: 0.75 ms
   // per 10 000 queries at C2), too few and cuts fail their certificate (re-run per query): k + 6
   // certifies 10 000 of 10 000 C2 queries
   const int kp = kp_env > k && kp_env < kFK ? kp_env : prefilter_keep(k);
   const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
-                     !getenv("RPT_KNN_NO_PRE32") && data->shadow32 && !rerun && !f->prefilter_off;
+                     !ctx->opt.knn_no_pre32 && data->shadow32 && !rerun && !f->prefilter_off;
   if (wave) {
     const size_t smem = 4 * wbytes;
     if constexpr (std::is_same<TD, double>::value) {
@@ -1577,7 +1590,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   RPT_ARG((size_t)data->d * 8 + (sizeof(Entry) + 4) * kBuf <= 150 * 1024, "d too large");
   RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
           "query dtype must have the forest's projection type (f64 vs f32/bf16)");
-  const bool fused = !data->csr && k <= kFK && f->T <= 1024 && !getenv("RPT_KNN_GENERAL") &&
+  const bool fused = !data->csr && k <= kFK && f->T <= 1024 && !ctx->opt.knn_general &&
                      (size_t)data->d * 8 <= 32 * 1024;
   if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
   const int64_t nq = q->n;
@@ -1596,7 +1609,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
-  if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !getenv("RPT_KNN_NO_PRE32") &&
+  if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !ctx->opt.knn_no_pre32 &&
       !f->prefilter_off)
     RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
   auto launch = [&](bool rerun) -> int32_t {
@@ -1753,24 +1766,59 @@ int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_da
   return RPT_OK;
 }
 
-int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
-                      const int32_t* count_dev, int64_t shard_stride, int32_t G, int64_t nq,
-                      int32_t k, int32_t flags, int32_t* out_ids, double* out_dist,
-                      int32_t* out_count) {
-  if (nq == 0) return RPT_OK;
+static int32_t launch_merge(rpt_ctx* ctx, const int32_t* ids, const double* dist,
+                            const int32_t* cnt, int64_t is, int64_t ds, int64_t cs, int32_t G,
+                            int64_t nq, int32_t k, int32_t flags, int32_t* out_ids,
+                            double* out_dist, int32_t* out_count) {
   int np = 1;
   while (np < G * k) np <<= 1;
   const size_t smem = (sizeof(Entry) + 4) * (size_t)np;
   if (smem > 64 * 1024)
     RPT_HIP(hipFuncSetAttribute((const void*)merge_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, ctx->stream, ids, dist,
+                     cnt, is, ds, cs, G, nq, k, flags & 3, out_ids, out_dist, out_count);
+  RPT_HIP(hipGetLastError());
+  return RPT_OK;
+}
+
+int32_t knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* dist_dev,
+                      const int32_t* count_dev, int64_t shard_stride, int32_t G, int64_t nq,
+                      int32_t k, int32_t flags, int32_t* out_ids, double* out_dist,
+                      int32_t* out_count) {
+  if (nq == 0) return RPT_OK;
   // shard_stride 0: three shard-major arrays [G][nq][k], [G][nq][k], [G][nq]
   const int64_t is = shard_stride ? shard_stride : nq * k * 4, ds = shard_stride ? shard_stride : nq * k * 8,
                 cs = shard_stride ? shard_stride : nq * 4;
-  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), smem, ctx->stream, ids_dev,
-                     dist_dev, count_dev, is, ds, cs, G, nq, k, flags & 3, out_ids, out_dist,
-                     out_count);
-  RPT_HIP(hipGetLastError());
+  // one launch holds all G * k entries of a query in LDS (20 bytes each: 4096 entries = 80 KB)
+  if ((int64_t)G * k <= kMergeMax)
+    return launch_merge(ctx, ids_dev, dist_dev, count_dev, is, ds, cs, G, nq, k, flags, out_ids,
+                        out_dist, out_count);
+  // larger merges (e.g. 8 shards x k = 1024) fold the shards in one at a time: the running
+  // result (shards < g, already in the final order) against shard g is a 2-way merge of 2k
+  // entries, and ties still prefer the earlier shard, so the order is that of the G-way merge.
+  // The kernel addresses "shard 1" as base + stride, so the pair need not be adjacent.
+  DevBuf<int32_t> ti[2], tc[2];
+  DevBuf<double> td[2];
+  for (int b = 0; b < 2 && G > 2; ++b) {
+    RPT_TRY(ti[b].alloc((size_t)nq * k));
+    RPT_TRY(td[b].alloc((size_t)nq * k));
+    RPT_TRY(tc[b].alloc((size_t)nq));
+  }
+  const char *ai = (const char*)ids_dev, *ad = (const char*)dist_dev, *ac = (const char*)count_dev;
+  for (int g = 1; g < G; ++g) {
+    const bool last = g == G - 1;
+    int32_t* oi = last ? out_ids : ti[g & 1].p;
+    double* od = last ? out_dist : td[g & 1].p;
+    int32_t* oc = last ? out_count : tc[g & 1].p;
+    const char *gi = (const char*)ids_dev + g * is, *gd = (const char*)dist_dev + g * ds,
+               *gc = (const char*)count_dev + g * cs;
+    RPT_TRY(launch_merge(ctx, (const int32_t*)ai, (const double*)ad, (const int32_t*)ac, gi - ai,
+                         gd - ad, gc - ac, 2, nq, k, flags, oi, od, oc));
+    ai = (const char*)oi;
+    ad = (const char*)od;
+    ac = (const char*)oc;
+  }
   return RPT_OK;
 }
 

@@ -964,7 +964,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
     std::vector<Pass> passes;
     constexpr int KS8 = sizeof(TC) == 8 ? 8 : 4;  // 8 tiles of 8-byte fragments are 128 KB of LDS
     {
-      const bool wide_ok = !getenv("RPT_PROJ_NARROW");
+      const bool wide_ok = !ctx->opt.proj_narrow;
       int c0 = 0;
       while (c0 < C) {
         const int left = C - c0;
@@ -1226,8 +1226,8 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
   if (ds->dtype == RPT_F64) return launch_mfma<double, double>(ctx, ds, R_dev, C, (double*)P_dev);
   if (ds->dtype == RPT_F32) return launch_mfma<float, float>(ctx, ds, R_dev, C, (float*)P_dev);
   // bf16: three bf16 MFMAs per tile against the split hyperplanes when the rows allow 16-byte
-  // fragment loads, else the f32-MFMA kernels on converted inputs (RPT_PROJ_BF16_F32: force them)
-  if (ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !getenv("RPT_PROJ_BF16_F32"))
+  // fragment loads, else the f32-MFMA kernels on converted inputs (option proj_bf16_f32: force them)
+  if (ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !ctx->opt.proj_bf16_f32)
     return launch_bf16x3(ctx, ds, R_dev, C, (float*)P_dev);
   return launch_mfma<__hip_bfloat16, float>(ctx, ds, R_dev, C, (float*)P_dev);
 }

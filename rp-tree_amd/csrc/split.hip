@@ -2770,7 +2770,7 @@ int32_t gsort(rpt_ctx* ctx, int32_t* buf, int32_t* tmp, int64_t N, const TK* P, 
 static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-#define HT(label) do { if (getenv("RPT_DEBUG_HOST")) { (void)stream_sync(ctx->stream); double t__ = now_ms(); fprintf(stderr, "host %-28s %8.3f ms\n", label, t__ - ht_last); ht_last = t__; } } while (0)
+#define HT(label) do { if (ctx->opt.debug_host) { (void)stream_sync(ctx->stream); double t__ = now_ms(); fprintf(stderr, "host %-28s %8.3f ms\n", label, t__ - ht_last); ht_last = t__; } } while (0)
 
 template <class TK>
 int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode,
@@ -2865,7 +2865,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   int32_t* F = f->perm.p;
   unsigned long long* dbgbuf = nullptr;
   DevBuf<unsigned long long> dbgdev;
-  if (getenv("RPT_DEBUG_STAMPS")) {
+  if (ctx->opt.debug_stamps) {
     RPT_TRY(dbgdev.alloc(256));
     RPT_HIP(hipMemsetAsync(dbgdev.p, 0, 256 * 8, st));
     dbgbuf = dbgdev.p;
@@ -2904,15 +2904,15 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   HT("alloc work buffers");
   // ---- streaming path for the leading levels ----
   int Lstream = 0;
-  if (N >= 2048 && !no_stream && !getenv("RPT_NO_STREAM"))
+  if (N >= 2048 && !no_stream && !ctx->opt.no_stream)
   {
     // measured at C2: with 32 bins per node (1024 nodes) an eighth of all points lands in pivot
     // bins and the exact resolution eats what the shorter wave phase saves -> 512 by default
     // (a level whose nodes would still be above the block kernel's 4096 points afterwards is
     // cheaper streamed with coarse bins — large pivot bins are split by selection — than on the
     // general path: 10 M-point shards stream one more level)
-    int max_nodes = getenv("RPT_STREAM_MAXNODES") ? atoi(getenv("RPT_STREAM_MAXNODES"))
-                                                  : (N / 1024 > kSmallCap ? 1024 : 512);
+    int max_nodes = ctx->opt.stream_maxnodes > 0 ? (int)ctx->opt.stream_maxnodes
+                                                 : (N / 1024 > kSmallCap ? 1024 : 512);
     if (max_nodes > kStreamMaxNodes) max_nodes = kStreamMaxNodes;
     while (Lstream < Lused && splits[(size_t)Lstream].size() == ((size_t)1 << Lstream) &&
            (1 << Lstream) <= max_nodes)
@@ -2926,7 +2926,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     DevBuf<unsigned long long> mm[4];  // cmin/cmax ping-pong
     // histogram pass: every block leaves a 64 KB partial that stream_pick reads back, so keep
     // >= min_per points per block; 16-bit LDS counters cap a block at 65535 points
-    const int64_t min_per = getenv("RPT_STREAM_MINPER") ? atoll(getenv("RPT_STREAM_MINPER")) : 32768;
+    const int64_t min_per = ctx->opt.stream_minper > 0 ? ctx->opt.stream_minper : 32768;
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblk > (N + min_per - 1) / min_per) nblk = (N + min_per - 1) / min_per;
     if (nblk < (N + 65533) / 65534) nblk = (N + 65533) / 65534;
@@ -2954,11 +2954,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     int32_t* pool = bufB.p;  // the ping-pong buffers are idle while nothing moves
     DevBuf<TK> poolkey;      // keys of the pivot-bin lists, same indexing as pool
     RPT_TRY(poolkey.alloc((size_t)T * N));
-    const int wave_max = getenv("RPT_NO_WMID") ? 0 : 128;
-    const int use_select = getenv("RPT_NO_MIDSELECT") ? 0 : 1;
-    // nodes above this size get more than 4096 bins (RPT_STREAM_BIG_NODE: test hook)
-    const int64_t big_node = getenv("RPT_STREAM_BIG_NODE") ? atoll(getenv("RPT_STREAM_BIG_NODE"))
-                                                           : ((int64_t)1 << 21);
+    const int wave_max = ctx->opt.no_wmid ? 0 : 128;
+    const int use_select = ctx->opt.no_midselect ? 0 : 1;
+    // nodes above this size get more than 4096 bins (option stream_big_node: test hook)
+    const int64_t big_node = ctx->opt.stream_big_node > 0 ? ctx->opt.stream_big_node
+                                                          : ((int64_t)1 << 21);
     {
       ProfScope ps(ctx, RPT_PROF_SPLIT);
       for (int level = 0; level < Lstream; ++level) {
@@ -3076,7 +3076,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   HT("stream to_perm + free");
   if (stream_unchecked) {
     // only wsub_kernel honours the abort flag: anything else waits for it
-    bool all_wave = getenv("RPT_NO_WSUB") == nullptr;
+    bool all_wave = !ctx->opt.no_wsub;
     for (const PNode& pn : pending[(size_t)streamed]) all_wave = all_wave && pn.seg.n <= kWCap;
     if (!all_wave) {
       RPT_HIP(ctx_sync(ctx));
@@ -3124,7 +3124,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
 
       // small nodes: n <= kWCap -> one wave per subtree; kWCap < n <= kSmallCap -> one block
       std::vector<Seg> wsmall, bsmall;
-      const bool no_wsub = getenv("RPT_NO_WSUB") != nullptr;
+      const bool no_wsub = ctx->opt.no_wsub != 0;
       for (const Seg& sgm : small) ((sgm.n <= kWCap && !no_wsub) ? wsmall : bsmall).push_back(sgm);
       if (!wsmall.empty()) {
         RPT_TRY(upload(wsmall, dsegs));

@@ -13,8 +13,10 @@ file:line in ocramz/rp-tree v0.7.1.
     SVector / DVector / Embed Internal.hs:56-59,92-133
     leaves / levels / points / treeSize / leafSizes   Internal.hs:199-208, RPTree.hs:362-367
 """
+import atexit
 import ctypes as C
 import math
+import weakref
 from collections import namedtuple
 
 import numpy as np
@@ -30,10 +32,25 @@ __all__ = [
     "candidates", "recallWith", "rpTreeCfg", "RPTreeConfig", "leaves", "levels", "points",
     "treeSize", "leafSizes", "metricL2", "inner", "project", "splitSegments", "topology",
     "bruteKnn", "RPTError", "forest", "tree", "saveForest", "loadForest", "importForest",
-    "knnH", "knnHBatch", "knnPQ", "candidatesBatch",
+    "knnH", "knnHBatch", "knnPQ", "candidatesBatch", "to_bf16", "from_bf16",
 ]
 
 _DT = {np.dtype(np.float64): RPT_F64, np.dtype(np.float32): RPT_F32}
+
+
+def to_bf16(a):
+    """float array -> bf16 bit patterns (uint16), round to nearest even (numpy has no bf16)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    out = ((u + r) >> 16).astype(np.uint16)
+    nan = (u & np.uint32(0x7FFFFFFF)) > np.uint32(0x7F800000)
+    out[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return out
+
+
+def from_bf16(u16):
+    """bf16 bit patterns (uint16) -> float32 (exact)."""
+    return (np.ascontiguousarray(u16, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
 def _vp(a):
@@ -92,6 +109,26 @@ def rpTreeCfg(minl, n, d):
 # ---------------------------------------------------------------------------------------
 # handles
 # ---------------------------------------------------------------------------------------
+# Handles still alive when the interpreter exits (e.g. kept by a traceback) are released HERE,
+# forests before datasets before contexts, while the HIP runtime is still up; a __del__ that
+# ran during interpreter teardown would call into a runtime whose static state is gone.
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    objs = list(_live)
+    for kind in ("ShardedForest", "RPForest", "Dataset", "Comm", "Context"):
+        for o in objs:
+            if type(o).__name__ == kind:
+                try:
+                    o.close()
+                except Exception:
+                    pass
+
+
+atexit.register(_close_all)
+
+
 class Context:
     """One MI355X device + stream (rpt_ctx).  Raises if there is no usable HIP device."""
 
@@ -100,9 +137,29 @@ class Context:
         check(lib().rpt_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._owns = True
+        _live.add(self)
+
+    @classmethod
+    def _borrowed(cls, handle, device):
+        """Wrap a ctx owned by someone else (rpt_comm_ctx): never destroyed from here."""
+        self = cls.__new__(cls)
+        self._h, self.device, self._owns = handle, int(device), False
+        return self
 
     def sync(self):
         check(lib().rpt_ctx_sync(self._h))
+
+    def set_option(self, name, value):
+        """Algorithm switch of this context (rpt_ctx_set_option); returns the previous value."""
+        old = self.get_option(name)
+        check(lib().rpt_ctx_set_option(self._h, name.encode(), int(value)))
+        return old
+
+    def get_option(self, name):
+        v = C.c_int64()
+        check(lib().rpt_ctx_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     @property
     def stream(self):
@@ -112,7 +169,8 @@ class Context:
 
     def close(self):
         if self._h is not None:
-            lib().rpt_ctx_destroy(self._h)
+            if self._owns:
+                lib().rpt_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -138,25 +196,50 @@ class Dataset:
     def __init__(self, ctx, handle, n, d, dtype, is_csr, keep=None):
         self.ctx, self._h, self.n, self.d, self.dtype, self.is_csr = ctx, handle, n, d, dtype, is_csr
         self._keep = keep
+        self._host = None
+        _live.add(self)
 
     @staticmethod
-    def dense(ctx, X):
+    def dense(ctx, X, dtype=None):
+        """Row-major host array -> HBM.  float64 / float32 arrays keep their type; a uint16 array
+        with dtype=RPT_BF16 holds bf16 bit patterns (see to_bf16)."""
         X = np.ascontiguousarray(X)
         if X.ndim != 2:
             raise ValueError("dense data must be a 2-D array [n][d]")
-        if X.dtype not in _DT:
-            X = X.astype(np.float64)
+        if dtype == RPT_BF16:
+            if X.dtype != np.uint16:
+                X = to_bf16(X)
+            dt = RPT_BF16
+        else:
+            if X.dtype not in _DT:
+                X = X.astype(np.float64)
+            dt = _DT[X.dtype]
         h = C.c_void_p()
-        check(lib().rpt_dataset_dense_host(ctx._h, _vp(X), X.shape[0], X.shape[1], _DT[X.dtype],
-                                           C.byref(h)))
-        return Dataset(ctx, h, X.shape[0], X.shape[1], _DT[X.dtype], False)
+        check(lib().rpt_dataset_dense_host(ctx._h, _vp(X), X.shape[0], X.shape[1], dt, C.byref(h)))
+        ds = Dataset(ctx, h, X.shape[0], X.shape[1], dt, False)
+        ds._host = X if dt == RPT_F64 else None     # recallWith's value semantics read rows back
+        return ds
 
     @staticmethod
     def dense_device(ctx, ptr, n, d, dtype, keep=None):
-        """Borrow device memory (e.g. a torch tensor's data_ptr()); `keep` pins the owner."""
+        """Borrow device memory (e.g. a torch tensor's data_ptr()); `keep` pins the owner.
+        The ctx stream is NOT ordered against whatever stream produced that memory: the caller
+        must have synchronised the producer (Dataset.from_torch does)."""
         h = C.c_void_p()
         check(lib().rpt_dataset_dense_dev(ctx._h, C.c_void_p(ptr), n, d, dtype, C.byref(h)))
         return Dataset(ctx, h, n, d, dtype, False, keep)
+
+    @staticmethod
+    def from_torch(ctx, t):
+        """Borrow a contiguous 2-D torch tensor on ctx's device (float64 / float32 / bfloat16).
+        torch's current stream is synchronised first: the library enqueues on its own
+        non-blocking stream, which nothing else orders behind the kernels that filled `t`."""
+        import torch
+        dt = {torch.float64: RPT_F64, torch.float32: RPT_F32, torch.bfloat16: RPT_BF16}[t.dtype]
+        if t.dim() != 2 or not t.is_contiguous() or t.device.index != ctx.device:
+            raise ValueError("need a contiguous 2-D tensor on cuda:%d" % ctx.device)
+        torch.cuda.current_stream(t.device).synchronize()
+        return Dataset.dense_device(ctx, t.data_ptr(), t.shape[0], t.shape[1], dt, keep=t)
 
     @staticmethod
     def csr(ctx, rowptr, col, val, d):
@@ -225,6 +308,13 @@ def _query_dataset(ctx, like, q):
         return Dataset.csr(ctx, rowptr, col, val, like.d), len(q)
     if isinstance(q, DVector):
         q = q.dvVec
+    if like.dtype == RPT_BF16:       # data and queries share one element type on the device
+        a = np.asarray(q)
+        if a.dtype != np.uint16:
+            a = to_bf16(a)
+        if a.ndim == 1:
+            a = a[None, :]
+        return Dataset.dense(ctx, a, dtype=RPT_BF16), a.shape[0]
     a = np.asarray(q, dtype=npdt)
     if a.ndim == 1:
         a = a[None, :]
@@ -254,14 +344,16 @@ class RPForest:
     """`RPForest d a` = IntMap of trees keyed 0..T-1 (Internal.hs:182), held in HBM in the flat
     layout of include/rptree_hip.h; `perm`, `thr`, `mglo`, `mghi` copy it out."""
 
-    def __init__(self, ctx, handle, data, R, max_depth, min_leaf):
+    def __init__(self, ctx, handle, data, R, max_depth, min_leaf, owns=True):
         self.ctx, self._h, self.data = ctx, handle, data
+        self._owns = owns           # False: a shard borrowed from an rpt_sharded_forest
         self.R = R
         self.T, self.L, self.d = R.shape
         assert self.L == max_depth
         self.min_leaf = int(min_leaf)
         self.N = data.n
         self._perm = self._nodes = None
+        _live.add(self)
 
     # IntMap-like access
     def __len__(self):
@@ -304,6 +396,12 @@ class RPForest:
         check(lib().rpt_forest_get_proj(self._h, _vp(p)))
         return p
 
+    @property
+    def mode(self):
+        m = C.c_int32()
+        check(lib().rpt_forest_get_mode(self._h, C.byref(m)))
+        return m.value
+
     def stats(self):
         a, b = C.c_int64(), C.c_int64()
         check(lib().rpt_forest_stats(self._h, C.byref(a), C.byref(b)))
@@ -314,7 +412,8 @@ class RPForest:
 
     def close(self):
         if self._h is not None:
-            lib().rpt_forest_free(self._h)
+            if self._owns:
+                lib().rpt_forest_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -388,7 +487,8 @@ def saveForest(path, forest_):
     a 10M-point forest needs no boxed `Embed`s.  The counterpart of serialiseRPForest
     (Internal.hs:185-188) for the flat layout; the data itself is not stored."""
     np.savez_compressed(path, R=forest_.R, min_leaf=forest_.min_leaf, N=forest_.N,
-                        perm=forest_.perm, thr=forest_.thr, mglo=forest_.mglo, mghi=forest_.mghi)
+                        perm=forest_.perm, thr=forest_.thr, mglo=forest_.mglo, mghi=forest_.mghi,
+                        mode=forest_.mode)
 
 
 def loadForest(path, data, ctx=None):
@@ -399,11 +499,14 @@ def loadForest(path, data, ctx=None):
     ds = Dataset.of(ctx, data)
     if int(z["N"]) != ds.n:
         raise ValueError("forest was built on %d points, data has %d" % (int(z["N"]), ds.n))
-    return importForest(ctx, ds, z["R"], int(z["min_leaf"]), z["perm"], z["thr"], z["mglo"], z["mghi"])
+    mode = int(z["mode"]) if "mode" in z.files else RPT_PROJ_AUTO
+    return importForest(ctx, ds, z["R"], int(z["min_leaf"]), z["perm"], z["thr"], z["mglo"],
+                        z["mghi"], mode=mode)
 
 
-def importForest(ctx, data, R, min_leaf, perm, thr, mglo, mghi):
-    """Rebuild a device forest from flat arrays (e.g. after deserialiseRPForest)."""
+def importForest(ctx, data, R, min_leaf, perm, thr, mglo, mghi, mode=RPT_PROJ_AUTO):
+    """Rebuild a device forest from flat arrays (e.g. after deserialiseRPForest).  mode: the
+    projection mode the thresholds were computed with (queries project the same way)."""
     ds = Dataset.of(ctx, data)
     R = np.ascontiguousarray(R, dtype=np.float64)
     T, L, _ = R.shape
@@ -412,6 +515,7 @@ def importForest(ctx, data, R, min_leaf, perm, thr, mglo, mghi):
     a = [np.ascontiguousarray(x, dtype=np.float64) for x in (thr, mglo, mghi)]
     check(lib().rpt_forest_import(ctx._h, ds._h, _vp(R), T, L, int(min_leaf), _vp(perm),
                                   _vp(a[0]), _vp(a[1]), _vp(a[2]), C.byref(h)))
+    check(lib().rpt_forest_set_mode(h, int(mode)))
     return RPForest(ctx, h, ds, R, L, min_leaf)
 
 

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("RPTREE_HIP_LIB") or os.path.join(PKG_ROOT, "librptree
 RPT_F64, RPT_F32, RPT_BF16 = 0, 1, 2
 RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA = 0, 1, 2
 RPT_KNN_KEEP_DUPLICATES, RPT_KNN_DEDUP, RPT_KNN_DEDUP_DISTANCE = 0, 1, 2
+RPT_COMM_UID_BYTES = 128
 
 i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
 p_i32, p_i64, p_f64 = C.POINTER(i32), C.POINTER(i64), C.POINTER(f64)
@@ -29,6 +30,8 @@ SYMBOLS = {
     "rpt_ctx_sync": (i32, [vp]),
     "rpt_ctx_trim": (i32, [vp]),
     "rpt_ctx_stream": (i32, [vp, C.POINTER(vp)]),
+    "rpt_ctx_set_option": (i32, [vp, C.c_char_p, i64]),
+    "rpt_ctx_get_option": (i32, [vp, C.c_char_p, p_i64]),
     "rpt_prof_enable": (i32, [vp, i32]),
     "rpt_prof_reset": (i32, [vp]),
     "rpt_prof_get": (i32, [vp, i32, p_f64, p_i64]),
@@ -47,6 +50,8 @@ SYMBOLS = {
     "rpt_forest_get_nodes": (i32, [vp, vp, vp, vp]),
     "rpt_forest_get_proj": (i32, [vp, vp]),
     "rpt_forest_import": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),
+    "rpt_forest_get_mode": (i32, [vp, p_i32]),
+    "rpt_forest_set_mode": (i32, [vp, i32]),
     "rpt_forest_stats": (i32, [vp, p_i64, p_i64]),
     "rpt_split_segments": (i32, [vp, vp, i64, vp, vp, vp, i32, vp]),
     "rpt_candidates": (i32, [vp, vp, vp, vp, vp, i64, p_i64]),
@@ -58,6 +63,18 @@ SYMBOLS = {
     "rpt_knn_merge_dev": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp]),
     "rpt_knn_record_layout": (i32, [i64, i32, vp, vp, vp, vp]),
     "rpt_knn_merge_records_dev": (i32, [vp, vp, i64, i32, i64, i32, i32, vp, vp, vp]),
+    "rpt_comm_init": (i32, [i32, C.POINTER(vp)]),
+    "rpt_comm_unique_id": (i32, [vp]),
+    "rpt_comm_init_rank": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
+    "rpt_comm_destroy": (i32, [vp]),
+    "rpt_comm_info": (i32, [vp, p_i32, p_i32, p_i32]),
+    "rpt_comm_ctx": (i32, [vp, i32, C.POINTER(vp)]),
+    "rpt_comm_sync": (i32, [vp]),
+    "rpt_forest_build_sharded": (i32, [vp, vp, vp, i32, i32, i32, i32, C.POINTER(vp)]),
+    "rpt_sharded_forest_free": (i32, [vp]),
+    "rpt_sharded_forest_local": (i32, [vp, i32, C.POINTER(vp), p_i32, p_i32]),
+    "rpt_knn_sharded_dev": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "rpt_knn_sharded": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "rpt_brute_knn_host": (i32, [vp, vp, vp, i32, vp, vp]),
 }
 

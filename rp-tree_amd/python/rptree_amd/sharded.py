@@ -1,65 +1,210 @@
-"""Multi-GPU sharding of the hot path: one process per GPU (torch.distributed, backend "nccl" =
-RCCL over xGMI), a contiguous block of trees per rank, X replicated.
+"""Multi-GPU sharding of the hot path over the C ABI's multi-GPU entry points
+(include/rptree_hip.h: rpt_comm_* / rpt_forest_build_sharded / rpt_knn_sharded*, implemented
+on librccl in csrc/comm.hip): a contiguous block of trees per GPU, X replicated.
 
 Trees are independent (createMulti maps over the IntMap, Internal.hs:234-240) and `knn` only
 concatenates per-tree candidates (RPTree.hs:176), so the build needs NO communication and a
-query needs exactly one exchange step: ONE all-gather of every rank's exchange record — its
+query needs exactly one exchange step: ONE ncclAllGather of every rank's exchange record — its
 local top-k distances, ids and counts packed back to back (rpt_knn_record_layout:
-nq * k * (8 + 4) + nq * 4 bytes per rank) — followed by a k-way merge
-(rpt_knn_merge_records_dev).  The kernels that fill the record, the collective and the merge
-are ordered on the device (the ctx stream is handed to torch as an ExternalStream), so a
-query costs a single host synchronisation at the end.  Top-k of a union is a
-subset of the union of per-shard top-ks, and because shard g holds trees [g*T/G, (g+1)*T/G)
-the stable order (distance, shard, rank-in-shard) equals the reference's (distance, candidate
-position) order.
+nq * k * (8 + 4) + nq * 4 bytes per rank) — followed by a k-way merge.  The kernels that fill
+the record, the collective and the merge are enqueued on the same ctx stream, so they are
+ordered on the device and a query costs one host synchronisation at the end.  Top-k of a union
+is a subset of the union of per-shard top-ks, and because shard g holds trees
+[g*T/G, (g+1)*T/G) the stable order (distance, shard, rank-in-shard) equals the reference's
+(distance, candidate position) order.
+
+Two launch styles, same data path:
+  Comm.local(n)                    one process drives n GPUs (rpt_comm_init)
+  Comm.from_process_group(ctx)     one process per GPU under torch.distributed.run: the RCCL id
+                                   made by rank 0 travels through the process group's store
+                                   (rpt_comm_unique_id / rpt_comm_init_rank)
+torch.distributed is only the control plane there (rendezvous, barriers); the exchange of the
+data path is this library's own RCCL communicator.
 """
+import ctypes as C
+
 import numpy as np
-import torch
-import torch.distributed as dist
 
 from . import _lib
-from . import (RPT_KNN_DEDUP, RPT_KNN_KEEP_DUPLICATES, RPT_PROJ_AUTO, Dataset, _build, gen)
+from . import (RPT_KNN_DEDUP, RPT_KNN_KEEP_DUPLICATES, RPT_PROJ_AUTO, Context, Dataset, RPForest,
+               _live)
 
 
 def tree_shard(T, world, rank):
-    """Contiguous block of trees of `rank` -> (lo, hi).  T must be divisible by world."""
-    if T % world != 0:
-        raise ValueError("number of trees (%d) must be divisible by the world size (%d)" % (T, world))
-    per = T // world
-    return rank * per, (rank + 1) * per
-
-
-def gather_topk(ids, dist_, cnt, group=None):
-    """All-gather per-rank top-k lists -> shard-major tensors [G][nq][k], [G][nq][k], [G][nq].
-    Works on CUDA tensors (RCCL) and on CPU tensors (gloo)."""
-    world = dist.get_world_size(group)
-    outs = []
-    for x in (ids, dist_, cnt):
-        x = x.contiguous()
-        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        try:
-            dist.all_gather_into_tensor(out, x, group=group)
-        except (RuntimeError, NotImplementedError):
-            parts = [torch.empty_like(x) for _ in range(world)]
-            dist.all_gather(parts, x, group=group)
-            out = torch.stack(parts)
-        outs.append(out)
-    return tuple(outs)
+    """Contiguous block of trees of `rank` -> (lo, hi) = (rank*T // world, (rank+1)*T // world),
+    the split rpt_forest_build_sharded uses.  Every rank needs at least one tree."""
+    if T < world:
+        raise ValueError("%d trees cannot be sharded over %d ranks" % (T, world))
+    return rank * T // world, (rank + 1) * T // world
 
 
 def record_layout(nq, k):
     """(bytes, off_dist, off_ids, off_count) of one shard's exchange record (C ABI)."""
-    import ctypes as C
     v = [C.c_int64() for _ in range(4)]
     _lib.check(_lib.lib().rpt_knn_record_layout(nq, k, *[C.byref(x) for x in v]))
     return tuple(x.value for x in v)
 
 
+def _ptr_array(handles):
+    arr = (C.c_void_p * len(handles))()
+    for i, h in enumerate(handles):
+        arr[i] = h if isinstance(h, int) or h is None else h.value
+    return arr
+
+
+class Comm:
+    """rpt_comm: the devices this process drives + their RCCL communicators."""
+
+    def __init__(self, handle):
+        self._h = handle
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().rpt_comm_info(handle, C.byref(a), C.byref(b), C.byref(c)))
+        self.nranks, self.nlocal, self.first_rank = a.value, b.value, c.value
+        self._ctx = []
+        for g in range(self.nlocal):
+            h = C.c_void_p()
+            _lib.check(_lib.lib().rpt_comm_ctx(handle, g, C.byref(h)))
+            self._ctx.append(h)
+        _live.add(self)             # released at interpreter exit in dependency order
+
+    @staticmethod
+    def local(n_gpus):
+        """One process, n_gpus devices (ncclCommInitAll); the contexts belong to the comm."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().rpt_comm_init(int(n_gpus), C.byref(h)))
+        c = Comm(h)
+        c.contexts = [Context._borrowed(x, g) for g, x in enumerate(c._ctx)]
+        return c
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_lib.RPT_COMM_UID_BYTES)
+        _lib.check(_lib.lib().rpt_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def rank(ctx, nranks, rank, uid):
+        """One process per GPU: this process is `rank` of `nranks` (ncclCommInitRank)."""
+        if len(uid) != _lib.RPT_COMM_UID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.RPT_COMM_UID_BYTES)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().rpt_comm_init_rank(ctx._h, int(nranks), int(rank), uid, C.byref(h)))
+        c = Comm(h)
+        c.contexts = [ctx]
+        return c
+
+    @staticmethod
+    def from_process_group(ctx, group=None):
+        """Under torch.distributed.run: rank 0 makes the RCCL id, the group's object broadcast
+        carries its bytes, every rank joins with its own ctx."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return Comm.rank(ctx, world, rank, box[0])
+
+    def sync(self):
+        _lib.check(_lib.lib().rpt_comm_sync(self._h))
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().rpt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedForest:
+    """rpt_sharded_forest: this process's tree shards of a T-tree forest + the collective query.
+    `datasets`: one replica of the point set per local device (Dataset on comm.contexts[g])."""
+
+    def __init__(self, comm, datasets, R, maxd, minl, mode=RPT_PROJ_AUTO):
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        T, L, d = R.shape
+        if L != maxd:
+            raise ValueError("hyperplane block has %d levels, maxDepth is %d" % (L, maxd))
+        if len(datasets) != comm.nlocal:
+            raise ValueError("need one dataset replica per local device (%d)" % comm.nlocal)
+        self.comm, self.datasets, self.R, self.T, self.L, self.min_leaf = comm, list(datasets), R, T, L, minl
+        h = C.c_void_p()
+        _lib.check(_lib.lib().rpt_forest_build_sharded(
+            comm._h, _ptr_array([x._h for x in datasets]), C.c_void_p(R.ctypes.data), T, L,
+            int(minl), int(mode), C.byref(h)))
+        self._h = h
+        _live.add(self)
+
+    def local(self, g=0):
+        """(forest, first_tree, n_trees) of local device g; the forest handle is borrowed."""
+        f, lo, nt = C.c_void_p(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().rpt_sharded_forest_local(self._h, g, C.byref(f), C.byref(lo), C.byref(nt)))
+        fr = RPForest(self.comm.contexts[g], f, self.datasets[g],
+                      np.ascontiguousarray(self.R[lo.value:lo.value + nt.value]), self.L,
+                      self.min_leaf, owns=False)
+        fr._keep_alive = self
+        return fr, lo.value, nt.value
+
+    def knn_dev(self, queries, k, flags, ids_ptrs, dist_ptrs, count_ptrs):
+        """queries: one replica per local device; *_ptrs: device addresses of the per-device
+        outputs.  Enqueued on the ctx streams: comm.sync() before reading."""
+        _lib.check(_lib.lib().rpt_knn_sharded_dev(
+            self.comm._h, self._h, _ptr_array([x._h for x in self.datasets]),
+            _ptr_array([x._h for x in queries]), int(k), int(flags), _ptr_array(ids_ptrs),
+            _ptr_array(dist_ptrs), _ptr_array(count_ptrs)))
+
+    def knn(self, queries, k, dedup=False):
+        """-> host arrays (ids[nq][k], dist[nq][k], count[nq]) of the merged answer."""
+        nq = queries[0].n
+        ids = np.empty((nq, k), dtype=np.int32)
+        dist = np.empty((nq, k), dtype=np.float64)
+        cnt = np.empty(nq, dtype=np.int32)
+        flags = RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES
+        _lib.check(_lib.lib().rpt_knn_sharded(
+            self.comm._h, self._h, _ptr_array([x._h for x in self.datasets]),
+            _ptr_array([x._h for x in queries]), int(k), flags, C.c_void_p(ids.ctypes.data),
+            C.c_void_p(dist.ctypes.data), C.c_void_p(cnt.ctypes.data)))
+        return ids, dist, cnt
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().rpt_sharded_forest_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU rehearsal of the exchange protocol (tests/test_sharded_gloo.py: world size 2 over gloo, the
+# shards answered by the oracle): the record layout, the shard-major gather and the merge order
+# are the C ABI's; only the transport differs (gloo instead of RCCL).
+# ---------------------------------------------------------------------------------------------
+def gather_topk(ids, dist_, cnt, group=None):
+    """All-gather per-rank top-k lists -> shard-major tensors [G][nq][k], [G][nq][k], [G][nq]."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    outs = []
+    for x in (ids, dist_, cnt):
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)     # concatenation along dim 0
+        outs.append(out.view((world,) + tuple(x.shape)))
+    return tuple(outs)
+
+
 class ExchangeRecord:
     """One shard's kNN result as a single byte buffer + typed views into it (dist [nq][k] f64,
-    ids [nq][k] i32, count [nq] i32).  device: torch device (CPU for the gloo rehearsal)."""
+    ids [nq][k] i32, count [nq] i32), in the layout of rpt_knn_record_layout."""
 
     def __init__(self, nq, k, device):
+        import torch
         self.nq, self.k = nq, k
         self.bytes, od, oi, oc = record_layout(nq, k)
         self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)
@@ -70,6 +215,7 @@ class ExchangeRecord:
     @staticmethod
     def views_of(gathered, g, nq, k):
         """(ids, dist, count) views of shard g inside an all-gathered [G][bytes] tensor."""
+        import torch
         _, od, oi, oc = record_layout(nq, k)
         row = gathered[g]
         return (row[oi:oi + nq * k * 4].view(torch.int32).view(nq, k),
@@ -77,74 +223,12 @@ class ExchangeRecord:
                 row[oc:oc + nq * 4].view(torch.int32))
 
 
-def gather_records(rec, group=None, out=None, via_host=False):
-    """All-gather the ranks' exchange records -> uint8 tensor [G][bytes] (one collective).
-    via_host: stage through host memory (rehearsal of several ranks on ONE GPU over gloo, which
-    has no device all-gather; never used on a multi-GPU node)."""
+def gather_records(rec, group=None, out=None):
+    """All-gather the ranks' exchange records -> uint8 tensor [G][bytes] (one collective)."""
+    import torch
+    import torch.distributed as dist
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty((world, rec.bytes), dtype=torch.uint8, device=rec.buf.device)
-    if via_host:
-        parts = [torch.empty(rec.bytes, dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(parts, rec.buf.cpu(), group=group)
-        out.copy_(torch.stack(parts))
-        return out
-    try:
-        dist.all_gather_into_tensor(out, rec.buf, group=group)
-    except (RuntimeError, NotImplementedError):
-        parts = [torch.empty_like(rec.buf) for _ in range(world)]
-        dist.all_gather(parts, rec.buf, group=group)
-        out.copy_(torch.stack(parts))
+    dist.all_gather_into_tensor(out.view(-1), rec.buf, group=group)
     return out
-
-
-class ShardedForest:
-    """This rank's tree shard of a T-tree forest + the collective query."""
-
-    def __init__(self, ctx, data, seed, maxd, minl, ntrees, pnz, dim, mode=RPT_PROJ_AUTO,
-                 group=None, hyperplanes=None):
-        self.ctx, self.group = ctx, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.data = Dataset.of(ctx, data)
-        if hyperplanes is None:
-            _, R = gen.forest_hyperplanes(seed, ntrees, maxd, pnz, dim)   # identical on all ranks
-        else:
-            R = np.asarray(hyperplanes, dtype=np.float64)
-        lo, hi = tree_shard(ntrees, self.world, self.rank)
-        self.R = R
-        self.local = _build(ctx, self.data, np.ascontiguousarray(R[lo:hi]), maxd, minl, mode)
-        self._stream = torch.cuda.ExternalStream(ctx.stream, device=ctx.device)
-        self._bufs = {}
-
-    def _buffers(self, nq, k):
-        key = (nq, k)
-        if key not in self._bufs:
-            dev = torch.device("cuda", self.ctx.device)
-            rec = ExchangeRecord(nq, k, dev)
-            gathered = torch.empty((self.world, rec.bytes), dtype=torch.uint8, device=dev)
-            out = (torch.empty((nq, k), dtype=torch.int32, device=dev),
-                   torch.empty((nq, k), dtype=torch.float64, device=dev),
-                   torch.empty((nq,), dtype=torch.int32, device=dev))
-            self._bufs = {key: (rec, gathered, out)}   # one shape at a time stays resident
-        return self._bufs[key]
-
-    def knn(self, queries, k, dedup=False):
-        """queries: Dataset (same on every rank).  Returns device tensors (ids, dist, count),
-        valid until the next call with the same shape.  One host synchronisation."""
-        L = _lib.lib()
-        nq = queries.n
-        flags = RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES
-        rec, gathered, (oi, od, oc) = self._buffers(nq, k)
-        _lib.check(L.rpt_knn_dev(self.ctx._h, self.local._h, self.data._h, queries._h, k, flags,
-                                 rec.ids.data_ptr(), rec.dist.data_ptr(), rec.count.data_ptr()))
-        if self.world == 1:
-            self.ctx.sync()
-            return rec.ids, rec.dist, rec.count
-        with torch.cuda.stream(self._stream):   # the collective waits for / is waited on by the
-            gather_records(rec, self.group, out=gathered)   # ctx stream: no host sync in between
-        _lib.check(L.rpt_knn_merge_records_dev(self.ctx._h, gathered.data_ptr(), rec.bytes,
-                                               self.world, nq, k, flags, oi.data_ptr(),
-                                               od.data_ptr(), oc.data_ptr()))
-        self.ctx.sync()
-        return oi, od, oc

@@ -1,0 +1,231 @@
+"""GPU tests of the C-ABI additions of round 2: the multi-GPU entry points (rpt_comm_* /
+rpt_forest_build_sharded / rpt_knn_sharded*, csrc/comm.hip on librccl) on the one GPU a test
+box has, context options, shard merges beyond one launch's capacity, and the import of a forest
+built ELSEWHERE (the oracle plays deserialiseRPForest's part, Internal.hs:185-196)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rp():
+    import rptree_amd
+    return rptree_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(rp):
+    return rp.default_context()
+
+
+@pytest.fixture(scope="module")
+def case(oracle):
+    n, d, T, ml = 30000, 24, 6, 50
+    X = oracle.data_normal_dense2(1234, n, d)
+    Q = oracle.data_normal_dense2(4321, 300, d)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(1235137, T, L, pnz, d)
+    return X, Q, R, L, ml
+
+
+# --------------------------------------------------------------------------- multi-GPU entry points
+def test_sharded_entry_points_one_gpu_equal_the_plain_ones(rp, ctx, case, oracle):
+    """rpt_comm_init(1) + rpt_forest_build_sharded + rpt_knn_sharded(_dev) == rpt_forest_build +
+    rpt_knn_* on the same device, bit for bit, and == the oracle (Internal.hs:234-240,
+    RPTree.hs:174-176)."""
+    import torch
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    k = 10
+    plain = rp.forestBatch(0, L, ml, R.shape[0], 0, X.shape[1], X, ctx=ctx, hyperplanes=R)
+    pi, pd, pc = rp.knnBatch(k, plain, Q)
+    comm = sharded.Comm.local(1)
+    assert (comm.nranks, comm.nlocal, comm.first_rank) == (1, 1, 0)
+    c0 = comm.contexts[0]
+    ds = rp.Dataset.dense(c0, X)
+    qs = rp.Dataset.dense(c0, Q)
+    sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+    loc, lo, nt = sf.local(0)
+    assert (lo, nt) == (0, R.shape[0])
+    assert np.array_equal(loc.perm, plain.perm)
+    assert np.array_equal(loc.thr, plain.thr, equal_nan=True)
+    si, sd, sc = sf.knn([qs], k)                                   # host variant
+    assert np.array_equal(si, pi) and np.array_equal(sd, pd) and np.array_equal(sc, pc)
+    oi = torch.empty((len(Q), k), dtype=torch.int32, device="cuda")
+    od = torch.empty((len(Q), k), dtype=torch.float64, device="cuda")
+    oc = torch.empty((len(Q),), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for flags in (rp.RPT_KNN_KEEP_DUPLICATES, rp.RPT_KNN_DEDUP):
+        sf.knn_dev([qs], k, flags, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+        comm.sync()
+        wi, wd, wc = rp.knnBatch(k, plain, Q, dedup=bool(flags))
+        assert np.array_equal(oi.cpu().numpy(), wi) and np.array_equal(od.cpu().numpy(), wd)
+        assert np.array_equal(oc.cpu().numpy(), wc)
+    fo = oracle.forest_build_dense(X, R, ml)
+    wi, wd, wc = oracle.knn_dense_batch(fo, X, Q, k, threads=4)
+    assert np.array_equal(si, wi) and np.array_equal(sc, wc)
+    sf.close()
+    ds.close()
+    qs.close()
+    comm.close()
+
+
+def test_comm_init_rank_with_a_unique_id(rp, ctx, case):
+    """The one-process-per-GPU route: rpt_comm_unique_id + rpt_comm_init_rank (world of one)."""
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    uid = sharded.Comm.unique_id()
+    assert len(uid) == 128 and uid != bytes(128)
+    comm = sharded.Comm.rank(ctx, 1, 0, uid)
+    assert (comm.nranks, comm.nlocal, comm.first_rank) == (1, 1, 0)
+    ds = rp.Dataset.dense(ctx, X)
+    qs = rp.Dataset.dense(ctx, Q[:50])
+    sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+    si, sd, sc = sf.knn([qs], 5)
+    plain, _, _ = sf.local(0)
+    pi, pd, pc = rp.knnBatch(5, plain, Q[:50])
+    assert np.array_equal(si, pi) and np.array_equal(sd, pd) and np.array_equal(sc, pc)
+    sf.close()
+    comm.close()
+    # the ctx was borrowed: still usable
+    assert rp.project(X[:10], R[0, :1], ctx=ctx).shape == (1, 10)
+
+
+def test_comm_argument_errors(rp, ctx, case):
+    from rptree_amd import _lib, sharded
+    L_ = _lib.lib()
+    h = C.c_void_p()
+    assert L_.rpt_comm_init(0, C.byref(h)) == -1
+    have = C.c_int32()
+    _lib.check(L_.rpt_device_count(C.byref(have)))
+    assert L_.rpt_comm_init(have.value + 1, C.byref(h)) == -1
+    assert b"visible" in L_.rpt_last_error()
+    X, Q, R, L, ml = case
+    comm = sharded.Comm.local(1)
+    ds_other = rp.Dataset.dense(ctx, X[:1000])                     # lives on ANOTHER context
+    with pytest.raises(rp.RPTError, match="communicator's"):
+        sharded.ShardedForest(comm, [ds_other], R, L, ml)
+    comm.close()
+
+
+# --------------------------------------------------------------------------- merges
+def merge_reference(gi, gd, gc, k, dedup):
+    G, nq, _ = gi.shape
+    oi = np.full((nq, k), -1, dtype=np.int32)
+    od = np.full((nq, k), np.inf)
+    oc = np.zeros(nq, dtype=np.int32)
+    for q in range(nq):
+        ent = [(gd[g, q, r], g, r, gi[g, q, r]) for g in range(G) for r in range(gc[g, q])]
+        ent.sort(key=lambda e: (e[0], e[1], e[2]))
+        seen, m = set(), 0
+        for dd, _, _, i in ent:
+            if m == k:
+                break
+            if dedup and i in seen:
+                continue
+            seen.add(i)
+            oi[q, m], od[q, m] = i, dd
+            m += 1
+        oc[q] = m
+    return oi, od, oc
+
+
+@pytest.mark.parametrize("G,k", [(8, 1024), (3, 1024), (5, 700), (4, 1024), (8, 512)])
+def test_merge_beyond_one_launch(rp, ctx, G, k):
+    """G * k > 4096 entries per query: the shards are folded in one at a time; same order as the
+    one-launch merge (distance, shard, rank), duplicates kept or dropped."""
+    import torch
+    from rptree_amd import _lib
+    rng = np.random.default_rng(G * k)
+    nq = 7
+    gi = rng.integers(0, 3000, size=(G, nq, k)).astype(np.int32)
+    gd = np.sort(np.round(rng.random((G, nq, k)) * 50, 1), axis=2)        # many equal distances
+    gc = rng.integers(k // 2, k + 1, size=(G, nq)).astype(np.int32)
+    gc[0, 0] = 0
+    ti, td, tc = (torch.from_numpy(a).cuda() for a in (gi, gd, gc))
+    oi = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+    oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for flags in (0, 1):
+        _lib.check(_lib.lib().rpt_knn_merge_dev(ctx._h, ti.data_ptr(), td.data_ptr(), tc.data_ptr(),
+                                                G, nq, k, flags, oi.data_ptr(), od.data_ptr(),
+                                                oc.data_ptr()))
+        ctx.sync()
+        wi, wd, wc = merge_reference(gi, gd, gc, k, bool(flags))
+        assert np.array_equal(oc.cpu().numpy(), wc)
+        for q in range(nq):
+            m = wc[q]
+            assert np.array_equal(oi.cpu().numpy()[q, :m], wi[q, :m])
+            assert np.array_equal(od.cpu().numpy()[q, :m], wd[q, :m])
+
+
+# --------------------------------------------------------------------------- options
+def test_context_options(rp, ctx):
+    assert ctx.get_option("knn_wave") == -1 and ctx.get_option("no_wsub") == 0
+    old = ctx.set_option("no_wsub", 1)
+    assert old == 0 and ctx.get_option("no_wsub") == 1
+    ctx.set_option("no_wsub", 0)
+    with pytest.raises(rp.RPTError, match="unknown option"):
+        ctx.set_option("no_such_switch", 1)
+
+
+def test_every_fallback_option_keeps_the_forest_identical(rp, ctx, oracle):
+    n, d, T, ml = 50000, 10, 3, 30
+    X = oracle.data_normal_dense2(5, n, d)
+    X[:4000] = np.round(X[:4000], 1)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(8, T, L, pnz, d)
+    fo = oracle.forest_build_dense(X, R, ml)
+    for name in ("no_stream", "no_wsub", "no_wmid", "no_midselect", "proj_narrow"):
+        old = ctx.set_option(name, 1)
+        try:
+            f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R)
+        finally:
+            ctx.set_option(name, old)
+        assert np.array_equal(f.perm, fo.perm), name
+        assert np.array_equal(f.thr, fo.thr, equal_nan=True), name
+
+
+# --------------------------------------------------------------------------- import (8f-1)
+def test_import_of_an_oracle_built_forest(rp, ctx, case, oracle):
+    """rpt_forest_import fed with arrays the DEVICE never produced (the oracle's = what a Haskell
+    host would flatten out of deserialiseRPForest): candidates and kNN must be the oracle's."""
+    X, Q, R, L, ml = case
+    fo = oracle.forest_build_dense(X, R, ml)
+    f = rp.importForest(ctx, X, R, ml, fo.perm, fo.thr, fo.mglo, fo.mghi, mode=rp.RPT_PROJ_EXACT)
+    assert f.mode == rp.RPT_PROJ_EXACT
+    T = R.shape[0]
+    off, cids = rp.candidatesBatch(f, Q[:60])
+    for i in range(60):
+        for t in range(T):
+            assert np.array_equal(cids[off[i * T + t]:off[i * T + t + 1]],
+                                  oracle.candidates_dense(fo, Q[i], t))
+    for k, dedup in ((10, False), (3, True)):
+        ids, dist, cnt = rp.knnBatch(k, f, Q, dedup=dedup)
+        wi, wd, wc = oracle.knn_dense_batch(fo, X, Q, k, dedup=int(dedup), threads=4)
+        assert np.array_equal(ids, wi) and np.array_equal(cnt, wc)
+        assert np.allclose(dist, wd, rtol=1e-12)
+    off_h, ids_h, dist_h = rp.knnHBatch(5, f, Q[:20])
+    for i in range(20):
+        wi, wd = oracle.knn_h_dense(fo, X, Q[i], 5)
+        assert np.array_equal(ids_h[off_h[i]:off_h[i + 1]], wi)
+    with pytest.raises(rp.RPTError):
+        f.proj()                                   # an imported forest holds no projections
+
+
+def test_save_load_keeps_the_projection_mode(rp, ctx, case, tmp_path):
+    X, Q, R, L, ml = case
+    f = rp.forestBatch(0, L, ml, R.shape[0], 0, X.shape[1], X, ctx=ctx, hyperplanes=R,
+                       mode=rp.RPT_PROJ_MFMA)
+    assert f.mode == rp.RPT_PROJ_MFMA
+    path = str(tmp_path / "f.npz")
+    rp.saveForest(path, f)
+    g = rp.loadForest(path, X, ctx=ctx)
+    assert g.mode == rp.RPT_PROJ_MFMA
+    a, b = rp.knnBatch(7, f, Q), rp.knnBatch(7, g, Q)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

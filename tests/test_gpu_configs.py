@@ -1,0 +1,329 @@
+"""The five BASELINE.json configurations (C1..C5) through the C ABI on one MI355X,
+each against the CPU oracle at the configuration's own shape.
+
+  C1  10 000 x 16 f64, 1 tree, k = 10, 1 000 queries      everything bit-identical
+  C2  1 M x 128 f64, 32 trees, k = 10                     oracle identity on two full trees,
+                                                          permutation / cut properties on all 32,
+                                                          kNN ids vs the oracle on the 32-tree forest
+  C3  1 M x 784 CSR f64 (density 0.19), depth 13          exact build == oracle (innerSS order,
+                                                          Internal.hs:351-366), candidates, kNN
+  C4  10 M x 128 f32 shard (trees of one GPU), depth 17   oracle on the exactly-upcast rows:
+                                                          leaf flips < 1e-3, cut properties, kNN
+  C5  2 M x 768 bf16 shard, k = 50                        same scheme (bf16 -> f64 is exact)
+
+C4 / C5 are multi-GPU configurations: a GPU holds 8 (16) of the trees and ALL points of C4
+(10 M), so the per-GPU work is what is tested here, with 2 trees; C5's point set is cut to 2 M
+(its per-tree depth is then 13 instead of 16).  Integer / index results must be identical where
+the arithmetic is the reference's (f64, exact-order projections); f32 / bf16 data and the MFMA
+projections are build extensions checked through the north-star tolerances (projection values
+within 1e-5 |x||r|, leaf assignment flips < 1e-3)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NCPU = max(1, min(16, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def rp():
+    import rptree_amd
+    return rptree_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def leaf_index(perm_row, leaf_off):
+    """leaf number of every point from one tree's perm row"""
+    n = perm_row.shape[0]
+    pos = np.empty(n, dtype=np.int64)
+    pos[perm_row] = np.arange(n)
+    return np.searchsorted(leaf_off, pos, side="right")
+
+
+def assert_permutation(perm_row):
+    n = perm_row.shape[0]
+    assert np.array_equal(np.bincount(perm_row, minlength=n), np.ones(n, dtype=np.int64))
+
+
+def check_cuts(f, P, rng, n_nodes=24, trees=None):
+    """Internal.hs:496-501 on the device's own projections: left half <= thr == min(right), the
+    margins are the neighbours of the cut in sorted order."""
+    topo = [r for r in f.topology() if not r[4]]
+    for idx in rng.choice(len(topo), size=min(n_nodes, len(topo)), replace=False):
+        level, heap, off, m, _ = (int(v) for v in topo[idx])
+        for t in (range(f.T) if trees is None else trees):
+            nh = m // 2
+            p = P[t, level]
+            left = p[f.perm[t, off:off + nh]]
+            right = np.sort(p[f.perm[t, off + nh:off + m]])
+            assert left.max() <= f.thr[t, heap] == right[0]
+            assert f.mglo[t, heap] == left.max()
+            assert f.mghi[t, heap] == right[1]
+
+
+def flip_rate(perm_a, perm_b, leaf_off):
+    return float((leaf_index(perm_a, leaf_off) != leaf_index(perm_b, leaf_off)).mean())
+
+
+def knn_agreement(ids, dist, cnt, wi, wd, wc, k, rel_gap, extra=8):
+    """device (ids, dist, cnt) vs oracle lists that hold k + extra entries (f64 arithmetic on the
+    upcast rows; the device ranks f32 distances).  For EVERY query: the distances agree to
+    rel_gap; every oracle entry clearly inside the cut (distance < d_k (1 - rel_gap)) is
+    returned, and nothing is returned that is not within d_k (1 + rel_gap) — as multisets, the
+    reference keeps duplicates (a point found in two trees appears twice).  Queries whose oracle
+    entries are separated by more than rel_gap wherever neighbours are different points are also
+    compared position by position; their number is returned."""
+    from collections import Counter
+    compared = 0
+    for i in range(ids.shape[0]):
+        n_or = int(wc[i])
+        m = min(n_or, k)
+        assert cnt[i] == m
+        assert np.allclose(dist[i, :m], wd[i, :m], rtol=rel_gap, atol=1e-30)
+        w, wid = wd[i, :n_or], wi[i, :n_or]
+        got = Counter(ids[i, :m].tolist())
+        if m == k and n_or == k + extra and w[-1] <= w[k - 1] * (1 + rel_gap):
+            continue                                  # the tie group at the cut is not closed
+        dk = w[m - 1]
+        must = Counter(wid[:m][w[:m] < dk * (1 - rel_gap)].tolist())
+        allowed = Counter(wid[w <= dk * (1 + rel_gap)].tolist())
+        assert not (must - got), "query %d: a clear neighbour is missing" % i
+        assert not (got - allowed), "query %d: an entry beyond the cut was returned" % i
+        if len(w) > 1 and ((np.diff(w) <= rel_gap * w[1:]) & (wid[1:] != wid[:-1])).any():
+            continue
+        assert np.array_equal(ids[i, :m], wi[i, :m]), "query %d" % i
+        compared += 1
+    return compared
+
+
+# ------------------------------------------------------------------------------------ C1
+def test_c1_10k_x16_one_tree_everything_identical(rp, oracle):
+    n, d, min_leaf, k, nq = 10_000, 16, 20, 10, 1_000
+    X = oracle.data_normal_dense2(1234, n, d)
+    Q = oracle.data_normal_dense2(4321, nq, d)
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    assert cfg.fpMaxTreeDepth == 9 and abs(cfg.fpProjNzDensity - 0.8305) < 1e-4
+    f = rp.treeBatch(1235137, cfg.fpMaxTreeDepth, min_leaf, cfg.fpProjNzDensity, d, X)
+    fo = oracle.forest_build_dense(X, f.R, min_leaf, want_proj=True)
+    assert np.array_equal(f.perm, fo.perm)
+    for name in ("thr", "mglo", "mghi"):
+        assert np.array_equal(getattr(f, name), getattr(fo, name), equal_nan=True), name
+    P = f.proj()
+    assert np.array_equal(P[0, 0], fo.proj[0, 0])          # every point meets the root's vector
+    ids, dist, cnt = rp.knnBatch(k, f, Q)
+    wi, wd, wc = oracle.knn_dense_batch(fo, X, Q, k, threads=NCPU)
+    assert np.array_equal(cnt, wc) and np.array_equal(ids, wi)
+    assert np.allclose(dist, wd, rtol=1e-12)
+    off, cids = rp.candidatesBatch(f, Q[:200])
+    for i in range(200):
+        assert np.array_equal(cids[off[i]:off[i + 1]], oracle.candidates_dense(fo, Q[i], 0))
+    for i in range(5):
+        assert rp.recallWith(rp.metricL2, f, k, Q[i]) == oracle.recall_with_dense(fo, X, Q[i], k)
+
+
+# ------------------------------------------------------------------------------------ C2
+def test_c2_1m_x128_32_trees(rp, oracle):
+    n, d, T, min_leaf, k, nq = 1_000_000, 128, 32, 128, 10, 256
+    X = oracle.data_normal_dense2(1234, n, d)
+    Q = oracle.data_normal_dense2(4321, nq, d)
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    assert cfg.fpMaxTreeDepth == 13 and abs(cfg.fpProjNzDensity - 0.4746) < 1e-4
+    f = rp.forestBatch(1235137, cfg.fpMaxTreeDepth, min_leaf, T, cfg.fpProjNzDensity, d, X)
+    # (i) two full trees against the oracle, bit for bit (first and last of the forest)
+    fo = oracle.forest_build_dense(X, f.R[[0, T - 1]], min_leaf, threads=2)
+    for j, t in enumerate((0, T - 1)):
+        assert np.array_equal(f.perm[t], fo.perm[j]), "tree %d" % t
+        for name in ("thr", "mglo", "mghi"):
+            assert np.array_equal(getattr(f, name)[t], getattr(fo, name)[j], equal_nan=True)
+    # (ii) every tree: a permutation, cuts consistent with the tree's own projections
+    for t in range(T):
+        assert_permutation(f.perm[t])
+    P = f.proj()
+    check_cuts(f, P, np.random.default_rng(0), n_nodes=16)
+    # (iii) kNN over the whole 32-tree forest: the oracle walks the device-built flat forest
+    ids, dist, cnt = rp.knnBatch(k, f, Q)
+    ff = oracle.Forest(n, d, f.R, f.L, min_leaf, f.perm, f.thr, f.mglo, f.mghi)
+    wi, wd, wc = oracle.knn_dense_batch(ff, X, Q, k, threads=NCPU)
+    assert np.array_equal(cnt, wc) and np.array_equal(ids, wi)
+    assert np.allclose(dist, wd, rtol=1e-12)
+    # (iv) the timed mode (RPT_PROJ_MFMA): values within 1e-5 |x||r|, leaf flips < 1e-3 on all trees
+    g = rp.forestBatch(1235137, cfg.fpMaxTreeDepth, min_leaf, T, cfg.fpProjNzDensity, d, f.data,
+                       mode=rp.RPT_PROJ_MFMA)
+    leaf_off = np.array([o for (_, _, o, m, lf) in f.topology() if lf])
+    flips = np.mean([flip_rate(f.perm[t], g.perm[t], leaf_off) for t in range(T)])
+    assert flips < 1e-3, flips
+    for t in range(T):
+        assert_permutation(g.perm[t])
+    Pg = g.proj()
+    scale = np.linalg.norm(X[:2000], axis=1)[None, None, :] * np.linalg.norm(f.R, axis=2)[:, :, None]
+    assert (np.abs(Pg[:, :, :2000] - P[:, :, :2000]) <= 1e-5 * scale).all()
+    check_cuts(g, Pg, np.random.default_rng(1), n_nodes=8)
+
+
+# ------------------------------------------------------------------------------------ C3
+def sparse_uniform_csr(torch, n, d, density, seed):
+    """Bernoulli support + U(0,1] values, generated on the GPU for speed"""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    cols, counts = [], []
+    for r0 in range(0, n, 100_000):
+        m = torch.rand((min(100_000, n - r0), d), device="cuda", generator=g) < density
+        counts.append(m.sum(dim=1).cpu().numpy())
+        cols.append(m.nonzero()[:, 1].to(torch.int32).cpu().numpy())
+    col = np.concatenate(cols)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(np.concatenate(counts))
+    val = 1.0 - np.random.default_rng(seed).random(int(rowptr[-1]))
+    return rowptr, col, val
+
+
+def test_c3_1m_x784_sparse(rp, oracle, torch):
+    n, d, T, min_leaf, k, nq = 1_000_000, 784, 2, 128, 10, 32
+    rowptr, col, val = sparse_uniform_csr(torch, n, d, 0.19, 1234)
+    assert 0.185 < rowptr[-1] / (n * d) < 0.195
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    assert cfg.fpMaxTreeDepth == 13 and abs(cfg.fpProjNzDensity - 0.3455) < 1e-4
+    f = rp.forestBatch(1235137, cfg.fpMaxTreeDepth, min_leaf, T, cfg.fpProjNzDensity, d,
+                       (rowptr, col, val, d))
+    fo = oracle.forest_build_csr(rowptr, col, val, d, f.R, min_leaf, threads=T)
+    assert np.array_equal(f.perm, fo.perm)
+    for name in ("thr", "mglo", "mghi"):
+        assert np.array_equal(getattr(f, name), getattr(fo, name), equal_nan=True), name
+    # queries: fresh sparse rows of the same distribution
+    qr, qc, qv = sparse_uniform_csr(torch, nq, d, 0.19, 4321)
+    off, cids = rp.candidatesBatch(f, (qr, qc, qv, d))
+    ids, dist, cnt = rp.knnBatch(k, f, (qr, qc, qv, d))
+    compared = 0
+    for i in range(nq):
+        a, b = qr[i], qr[i + 1]
+        for t in range(T):
+            want = oracle.candidates_sparse(fo, qc[a:b], qv[a:b], t)
+            assert np.array_equal(cids[off[i * T + t]:off[i * T + t + 1]], want)
+        wi, wd = oracle.knn_csr(fo, rowptr, col, val, qc[a:b], qv[a:b], k + 1, true_l2=True)
+        m = min(len(wi), k)
+        assert cnt[i] == m
+        assert np.allclose(dist[i, :m], wd[:m], rtol=1e-9, atol=1e-12)
+        if (np.diff(wd) > 1e-9 * wd[1:]).all():      # ids wherever the distances separate
+            assert np.array_equal(ids[i, :m], wi[:m])
+            compared += 1
+    assert compared >= nq // 2
+
+
+# ------------------------------------------------------------------------------------ C4
+def shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, seed, rel_gap, min_same_cands):
+    """Common part of C4 / C5: Xd = device tensor (f32 or bf16), Xh = the same rows on the host
+    as float32 (exact).  Builds T trees in the default mode of the element type (MFMA) and checks
+    them against the oracle on the upcast rows."""
+    n, d = Xh.shape
+    ctx = rp.default_context()
+    ds = rp.Dataset.from_torch(ctx, Xd)
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    _, R = rp.gen.forest_hyperplanes(seed, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
+    f = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)
+    for t in range(T):
+        assert_permutation(f.perm[t])
+    P = f.proj()
+    assert P.dtype == np.float32
+    check_cuts(f, P, np.random.default_rng(seed), n_nodes=12)
+    # projection values against the f64 contraction of the upcast rows: 1e-5 |x||r| (north star)
+    rows = np.random.default_rng(seed + 1).choice(n, size=2048, replace=False)
+    Xs = Xh[rows].astype(np.float64)
+    want = np.einsum("nd,tld->tln", Xs, R)
+    scale = np.linalg.norm(Xs, axis=1)[None, None, :] * np.linalg.norm(R, axis=2)[:, :, None]
+    assert (np.abs(P[:, :, rows] - want) <= 1e-5 * scale).all()
+    # the reference's arithmetic on the exactly-upcast rows
+    fo = oracle.forest_build_dense(Xh, R, min_leaf, threads=T)
+    leaf_off = np.array([o for (_, _, o, m, lf) in f.topology() if lf])
+    for t in range(T):
+        fl = flip_rate(f.perm[t], fo.perm[t], leaf_off)
+        assert fl < 1e-3, (t, fl)
+    # thresholds: f32 projections of the same median point wherever no flipped point moved the
+    # node's median rank (a moved rank shifts thr by one inter-point gap)
+    tt = ~np.isnan(fo.thr)
+    assert np.array_equal(tt, ~np.isnan(f.thr))
+    rn = np.repeat(np.linalg.norm(R, axis=2), [1 << l for l in range(f.L)], axis=1)
+    xmax = float(np.linalg.norm(Xs, axis=1).max())
+    close = np.abs(f.thr - fo.thr)[tt] <= 1e-5 * (xmax * rn)[tt]
+    assert close.mean() >= 0.97, close.mean()
+    # queries: data points moved a little, in the data's element type
+    qi = np.random.default_rng(seed + 2).choice(n, size=nq, replace=False)
+    Qd = (Xd[torch.from_numpy(qi).cuda()].float() * 1.001 + 0.003).to(Xd.dtype).contiguous()
+    Qh = Qd.float().cpu().numpy()
+    qs = rp.Dataset.from_torch(ctx, Qd)
+    ids, dist, cnt = rp.knnBatch(k, f, qs)
+    # the oracle walks the DEVICE-built forest (f64 query projections, f64 distances)
+    ff = oracle.Forest(n, d, R, f.L, min_leaf, f.perm, f.thr, f.mglo, f.mghi)
+    off, cids = rp.candidatesBatch(f, qs)
+    same = []
+    for i in range(nq):
+        want = np.concatenate([oracle.candidates_dense(ff, Qh[i].astype(np.float64), t)
+                               for t in range(T)])
+        same.append(np.array_equal(cids[off[i * T]:off[(i + 1) * T]], want))
+    same = np.array(same)
+    assert same.mean() >= min_same_cands, same.mean()
+    wi, wd, wc = oracle.knn_dense_batch(ff, Xh, Qh.astype(np.float64), k + 8, threads=NCPU)
+    sel = np.nonzero(same)[0]
+    compared = knn_agreement(ids[sel], dist[sel], cnt[sel], wi[sel], wd[sel], wc[sel], k, rel_gap)
+    assert compared >= len(sel) // 8          # (k = 50 of ~500 candidates: near-ties are common)
+    return f
+
+
+def test_c4_10m_x128_f32_shard(rp, oracle, torch):
+    n, d, T, min_leaf, k, nq = 10_000_000, 128, 2, 128, 10, 64
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    coin = (torch.rand(n, 1, device="cuda", generator=g) < 0.5).float() * 2.0
+    Xd = torch.randn(n, d, device="cuda", dtype=torch.float32, generator=g) * 0.5 + coin
+    del coin
+    Xh = Xd.cpu().numpy()
+    assert rp.rpTreeCfg(min_leaf, n, d).fpMaxTreeDepth == 17
+    shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, 1235137, 1e-5, 0.9)
+
+
+# ------------------------------------------------------------------------------------ C5
+def test_c5_2m_x768_bf16_shard_k50(rp, oracle, torch):
+    n, d, T, min_leaf, k, nq = 2_000_000, 768, 2, 256, 50, 64
+    g = torch.Generator(device="cuda").manual_seed(99)
+    Xd = torch.randn(n, d, device="cuda", dtype=torch.float32, generator=g)
+    Xd = (Xd / Xd.norm(dim=1, keepdim=True)).to(torch.bfloat16).contiguous()
+    Xh = Xd.float().cpu().numpy()
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    assert cfg.fpMaxTreeDepth == 13 and abs(cfg.fpProjNzDensity - 0.3466) < 1e-4
+    shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, 1235137, 1e-5, 0.9)
+
+
+def test_bf16_forest_and_knn_small_all_paths(rp, oracle, torch):
+    """bf16 data from HOST buffers (uint16 bit patterns through rpt_dataset_dense_host): build,
+    candidates and kNN against the oracle on the upcast rows, small enough to enumerate."""
+    n, d, T, min_leaf, k = 20_000, 64, 4, 40, 10
+    rng = np.random.default_rng(3)
+    Xb = rp.to_bf16(rng.standard_normal((n, d)).astype(np.float32))
+    Xh = rp.from_bf16(Xb)
+    ctx = rp.default_context()
+    ds = rp.Dataset.dense(ctx, Xb, dtype=rp.RPT_BF16)
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    _, R = rp.gen.forest_hyperplanes(5, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
+    f = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)
+    fo = oracle.forest_build_dense(Xh, R, min_leaf)
+    leaf_off = np.array([o for (_, _, o, m, lf) in f.topology() if lf])
+    for t in range(T):
+        assert_permutation(f.perm[t])
+        assert flip_rate(f.perm[t], fo.perm[t], leaf_off) < 2e-3
+    Q = Xh[:100] * 1.01
+    ids, dist, cnt = rp.knnBatch(k, f, Q)                  # queries are rounded to bf16 on the way
+    Qh = rp.from_bf16(rp.to_bf16(Q)).astype(np.float64)
+    ff = oracle.Forest(n, d, R, f.L, min_leaf, f.perm, f.thr, f.mglo, f.mghi)
+    wi, wd, wc = oracle.knn_dense_batch(ff, Xh, Qh, k + 8, threads=NCPU)
+    off, cids = rp.candidatesBatch(f, Q)
+    same = np.array([np.array_equal(
+        cids[off[i * T]:off[(i + 1) * T]],
+        np.concatenate([oracle.candidates_dense(ff, Qh[i], t) for t in range(T)]))
+        for i in range(100)])
+    assert same.mean() >= 0.9
+    sel = np.nonzero(same)[0]
+    assert knn_agreement(ids[sel], dist[sel], cnt[sel], wi[sel], wd[sel], wc[sel], k, 1e-5) >= 40

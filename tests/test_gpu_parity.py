@@ -19,6 +19,22 @@ def ctx(rp):
     return rp.default_context()
 
 
+@pytest.fixture
+def option(ctx):
+    """option(name, value): context manager switching one algorithm option of the context
+    (rpt_ctx_set_option) for the enclosed calls — the fallback paths must stay exact too."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def switch(name, value):
+        old = ctx.set_option(name, value)
+        try:
+            yield
+        finally:
+            ctx.set_option(name, old)
+    return switch
+
+
 def ref_inner_exact(X, r):
     """innerSD order (Internal.hs:382): acc = x_k*r_k + acc from the last index to the first,
     separate multiply and add (numpy element-wise ops are IEEE exact)."""
@@ -103,7 +119,7 @@ def test_project_mfma_bf16_input(rp, ctx, n, d, C):
         assert (np.abs(P.T - want) <= 2e-6 * scale).all()
 
 
-def test_project_bf16_both_kernels_agree(rp, ctx, monkeypatch):
+def test_project_bf16_both_kernels_agree(rp, ctx, option):
     """bf16 data: the bf16x3 matrix-pipe kernel and the f32-MFMA kernel on converted inputs
     compute the same contraction (both within 1e-5 |x||r|; here against each other), and a
     forest built on either has the same leaf assignment up to points within rounding of a median."""
@@ -115,9 +131,8 @@ def test_project_bf16_both_kernels_agree(rp, ctx, monkeypatch):
     ds = rp.Dataset.dense_device(ctx, xb.data_ptr(), n, d, rp.RPT_BF16, keep=xb)
     R = sparse_R(rng, C, d, 0.4)
     Pa = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
-    monkeypatch.setenv("RPT_PROJ_BF16_F32", "1")
-    Pb = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
-    monkeypatch.delenv("RPT_PROJ_BF16_F32")
+    with option("proj_bf16_f32", 1):
+        Pb = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
     Xr = xb.to(torch.float32).cpu().numpy().astype(np.float64)
     scale = np.linalg.norm(Xr, axis=1)[None, :] * np.linalg.norm(R, axis=1)[:, None]
     assert (np.abs(Pa.astype(np.float64) - Pb) <= 2e-6 * scale).all()
@@ -448,7 +463,7 @@ def test_knn_merge_records_equals_merge(rp, ctx, small_forest):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_knn_wave_and_workgroup_variants_agree_with_oracle(rp, ctx, oracle, monkeypatch, dtype):
+def test_knn_wave_and_workgroup_variants_agree_with_oracle(rp, ctx, oracle, option, dtype):
     """The fused query kernel has a one-wave-per-query variant (small shards) and a
     one-workgroup-per-query variant; both must give the oracle's ids/distances, including
     batches beyond the per-wave capacity (512 candidates), trees that outgrow their range
@@ -463,9 +478,8 @@ def test_knn_wave_and_workgroup_variants_agree_with_oracle(rp, ctx, oracle, monk
     f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
     res = {}
     for force in ("1", "0"):
-        monkeypatch.setenv("RPT_KNN_WAVE", force)
-        res[force] = [rp.knnBatch(k, f, Q, dedup=m) for m in (0, 1, 2)]
-    monkeypatch.delenv("RPT_KNN_WAVE")
+        with option("knn_wave", int(force)):
+            res[force] = [rp.knnBatch(k, f, Q, dedup=m) for m in (0, 1, 2)]
     for m in range(3):
         for a, b in zip(res["1"][m], res["0"][m]):
             assert np.array_equal(a, b)
@@ -486,15 +500,14 @@ def test_knn_wave_and_workgroup_variants_agree_with_oracle(rp, ctx, oracle, monk
     Q2 = X2[:64] * 1.0001
     out = {}
     for force in ("1", "0"):
-        monkeypatch.setenv("RPT_KNN_WAVE", force)
-        out[force] = rp.knnBatch(5, f2, Q2)
-    monkeypatch.delenv("RPT_KNN_WAVE")
+        with option("knn_wave", int(force)):
+            out[force] = rp.knnBatch(5, f2, Q2)
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("decimals", [None, 3, 1])
-def test_large_pivot_bins_selection_path(rp, ctx, oracle, monkeypatch, decimals):
+def test_large_pivot_bins_selection_path(rp, ctx, oracle, option, decimals):
     """Pivot bins above 128 points at the first levels (400 000 points: ~250 per bin) are split
     by SELECTION (sub-histogram of the bin, exact sort of the one sub-bin around the threshold);
     continuous keys, keys with moderate ties (3 decimals: ties inside the sorted sub-bin, decided
@@ -513,15 +526,14 @@ def test_large_pivot_bins_selection_path(rp, ctx, oracle, monkeypatch, decimals)
     fo = oracle.forest_build_dense(X, R, ml)
     f = rp.forestBatch(0, L, ml, T, 1.0, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
     assert_forest_equal(f, fo)
-    monkeypatch.setenv("RPT_NO_MIDSELECT", "1")
-    g = rp.forestBatch(0, L, ml, T, 1.0, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
-    monkeypatch.delenv("RPT_NO_MIDSELECT")
+    with option("no_midselect", 1):
+        g = rp.forestBatch(0, L, ml, T, 1.0, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
     assert_forest_equal(g, fo)
 
 
 @pytest.mark.parametrize("kind", ["cont", "ties", "dups"])
 @pytest.mark.parametrize("k", [1, 10, 24])
-def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
+def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, option, kind, k):
     """f64 data, duplicates kept: the fused kernel ranks the candidates on an f32 shadow of X,
     computes exact distances for the best k + max(6, k/2) only and certifies the cut per query
     (falling back to the exact path when it cannot: heavy ties).  ids, distances and counts must
@@ -549,9 +561,8 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, monkeypatch, kind, k):
         assert unc.value == 0                   # every cut certified
     # (k = 1: a query is a data point + 0.003, its source is found once per tree, and a cut inside
     # that group of equal distances cannot be certified: those queries are re-run in f64)
-    monkeypatch.setenv("RPT_KNN_NO_PRE32", "1")
-    ref = rp.knnBatch(k, f, Q)
-    monkeypatch.delenv("RPT_KNN_NO_PRE32")
+    with option("knn_no_pre32", 1):
+        ref = rp.knnBatch(k, f, Q)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
     fo = oracle.forest_build_dense(X, R, ml)
@@ -612,7 +623,7 @@ def test_knn_f32_prefilter_switches_itself_off_on_self_queries(rp, ctx, oracle):
     assert seen[0] > len(Q) // 4 and seen[1] == 0
 
 
-def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle, monkeypatch):
+def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle):
     """Values whose squares leave the f32 range (the shadow would hold inf): no prefilter, the
     all-f64 kernel answers; tiny values (f32 subnormals): certified or sent to the exact path —
     the oracle's result either way."""
@@ -783,15 +794,15 @@ def test_random_shapes_short_sweep(rp, ctx):
     assert mod.run(15.0, 20261003, ctx=ctx, verbose=False) > 20
 
 
-def test_more_than_4096_bins_per_node(rp, ctx, oracle, monkeypatch):
+def test_more_than_4096_bins_per_node(rp, ctx, oracle, option):
     """Very large nodes get up to 32768 value bins on the first streaming levels (two-stage
-    pick); RPT_STREAM_BIG_NODE lowers the node size that triggers it."""
-    monkeypatch.setenv("RPT_STREAM_BIG_NODE", "1000")
+    pick); the option stream_big_node lowers the node size that triggers it."""
     n, d, T, min_leaf = 70000, 5, 3, 30
     X = oracle.data_normal_dense2(99, n, d)
     X[:5000] = np.round(X[:5000])                      # some ties as well
     L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
     R, _ = oracle.forest_hyperplanes(5, T, L, 1.0, d)
     fo = oracle.forest_build_dense(X, R, min_leaf)
-    f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R)
+    with option("stream_big_node", 1000):
+        f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R)
     assert_forest_equal(f, fo)

@@ -31,10 +31,7 @@ ds = rp.Dataset.dense_device(ctx, X.data_ptr(), N, d, rp.RPT_BF16, keep=X)
 Rc = np.ascontiguousarray(R)
 res = {}
 for name, env in (("bf16x3", None), ("f32-mfma", "1")):
-    if env:
-        os.environ["RPT_PROJ_BF16_F32"] = env
-    else:
-        os.environ.pop("RPT_PROJ_BF16_F32", None)
+    ctx.set_option("proj_bf16_f32", 1 if env else 0)
     best = 1e9
     for it in range(4):
         ctx.sync()
@@ -87,10 +84,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "build":
     qs = rp.Dataset.dense_device(ctx, Q.data_ptr(), nq, d, rp.RPT_BF16, keep=Q)
     torch.cuda.synchronize()
     for name, env in (("bf16x3", None), ("f32-mfma", "1")):
-        if env:
-            os.environ["RPT_PROJ_BF16_F32"] = env
-        else:
-            os.environ.pop("RPT_PROJ_BF16_F32", None)
+        ctx.set_option("proj_bf16_f32", 1 if env else 0)
         for it in range(3):
             ctx.sync()
             t0 = time.perf_counter()
