@@ -305,7 +305,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         Xh = X.cpu().numpy()
-        ncores = os.cpu_count() or 1
+        # threads actually used by the all-core leg: the CPUs this process may run on, at most
+        # one per tree (trees are the unit of parallelism)
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        ncores = max(1, min(ncores, T))
         # (i) the reference is single-threaded: 1 thread, a few trees, scaled to the forest
         nt = 3 if N >= 500_000 else min(T, 8)
         t0 = time.perf_counter()

@@ -120,6 +120,7 @@ struct rpt_options {
   int64_t no_midselect = 0;     // split: large pivot bins are sorted, not split by selection
   int64_t stream_big_node = (int64_t)1 << 21;  // split: nodes above this get > 4096 value bins
   int64_t no_wsub = 0;          // split: block-level subtree kernel instead of the wave kernel
+  int64_t no_codes = 0;         // split: stream on the keys themselves, no 16-bit codes
   int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only
   int64_t proj_bf16_f32 = 0;    // projection: bf16 rows through the f32-MFMA kernels
   int64_t knn_wave = -1;        // kNN: -1 auto, 0 workgroup-per-query, 1 wave-per-query kernel
@@ -221,8 +222,13 @@ hipError_t ctx_sync(rpt_ctx* ctx);
 // ---- projection (project.hip) -----------------------------------------------------------
 // P_dev[C][n] (compute type) = R_dev[C][d] applied to every row of ds.  R_dev is a device
 // copy of the dense-ified hyperplanes (double).
+struct CodeOut;  // codes.h: optional 16-bit codes next to the projections
+bool project_writes_codes(const rpt_ctx* ctx, const rpt_dataset* ds, int32_t mode);
+// co != null: the kernels that support it also write codes (codes.h) and set *codes_written;
+// the others (CSR, rows that are not 16-byte granular, bf16 on the bf16 pipe) leave it false.
 int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
-                        int32_t mode, void* P_dev);
+                        int32_t mode, void* P_dev, const CodeOut* co = nullptr,
+                        bool* codes_written = nullptr);
 
 // ---- split / build (split.hip) ----------------------------------------------------------
 int32_t build_forest(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode);

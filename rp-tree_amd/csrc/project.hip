@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "codes.h"
 
 namespace rpt {
 namespace {
@@ -133,9 +134,16 @@ template <class T, int D, int KC>
 __global__ __launch_bounds__(256, 1) void proj_exact_lds(const T* __restrict__ X, int64_t n,
                                                          const T* __restrict__ Rt /*[D][32]*/,
                                                          T* __restrict__ P, int64_t ldp, int ncol,
-                                                         int64_t ntiles) {
+                                                         int64_t ntiles,
+                                                         uint16_t* __restrict__ Cd /* codes of the
+                                                            same columns (codes.h) or null */,
+                                                         int64_t ldc,
+                                                         const unsigned long long* __restrict__ cmm,
+                                                         unsigned int cmask /* columns with codes */) {
   constexpr int CB = 32;
   constexpr int ROWS = 128;
+  CodeGeo<T> cg{(T)1, (T)0};
+  if (Cd) cg = code_geo<T>(cmm[0], cmm[1]);
   constexpr int PIECE = 16 / (int)sizeof(T);
   constexpr int PPR = KC / PIECE;                  // pieces per row per chunk
   constexpr int NPX = ROWS * PPR / 64;             // X pieces per lane per chunk
@@ -220,6 +228,10 @@ __global__ __launch_bounds__(256, 1) void proj_exact_lds(const T* __restrict__ X
         if (c < ncol) {
           if (row0 < n) P[(int64_t)c * ldp + row0] = acc0[c];
           if (row1 < n) P[(int64_t)c * ldp + row1] = acc1[c];
+          if (Cd && ((cmask >> c) & 1u)) {
+            if (row0 < n) Cd[(int64_t)c * ldc + row0] = code_of(acc0[c], cg);
+            if (row1 < n) Cd[(int64_t)c * ldc + row1] = code_of(acc1[c], cg);
+          }
         }
 #pragma unroll
       for (int c = 0; c < CB; ++c) {
@@ -253,6 +265,9 @@ struct Mfma<double> {
   }
   // v_mfma_f64_16x16x4_f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg
   __device__ static int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+  // point-major tiles (proj_mfma_fast / _wide): M index m carries point 4 * (m & 3) + (m >> 2) of
+  // the tile, so that a lane's four accumulators (rows q, q+4, q+8, q+12) are CONSECUTIVE points
+  __device__ static int point_of_m(int m) { return 4 * (m & 3) + (m >> 2); }
 };
 template <>
 struct Mfma<float> {
@@ -262,6 +277,7 @@ struct Mfma<float> {
   }
   // v_mfma_f32_16x16x4_f32 C/D map: col = lane&15, row = 4*(lane>>4) + reg
   __device__ static int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+  __device__ static int point_of_m(int m) { return m; }  // rows 4q .. 4q+3 are consecutive already
 };
 
 template <class TIn>
@@ -270,6 +286,107 @@ template <>
 __device__ inline float to_f32<float>(float v) { return v; }
 template <>
 __device__ inline float to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+// Codes of a wave's finished tile (codes.h), after its projections have been stored.  The main
+// loops of the MFMA kernels run at the register limit: the geometry of each column is fetched
+// from LDS four values at a time, behind scheduling barriers, so that the epilogue's temporaries
+// never overlap the loop's (the compiler would otherwise hoist all 4*CBT LDS reads).
+template <class TC>
+struct CodeCtl {   // kept in LDS: its registers would otherwise live through the main loop
+  uint16_t* base;  // codes of column c0, point 0
+  int64_t ld;
+  TC s, b;         // the geometry (codes.h)
+};
+// Point-major tiles (proj_mfma_fast / _wide): D[m = point][n = hyperplane], i.e. the X tile is
+// the MFMA's first operand and the hyperplane fragments the second.  A lane then holds FOUR
+// CONSECUTIVE POINTS (row0 + 4 q + 0..3, q = lane >> 4) of ONE hyperplane (h * 16 + (lane & 15))
+// per column tile h: its projections are one 32-byte (f64) run and its codes one 8-byte run —
+// CBT code stores and 2 CBT (f64) projection stores per tile instead of 4 CBT + 4 CBT.  (The
+// hyperplane-major form stored one point of four hyperplanes per lane: 2-byte code stores, one
+// instruction per value, cost the f64 kernel 12 % whatever the arithmetic in front of them.)
+template <class TC>
+struct Vec4;
+template <>
+struct Vec4<double> { typedef double type __attribute__((ext_vector_type(4), aligned(16))); };
+template <>
+struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4), aligned(16))); };
+typedef unsigned short code4_t __attribute__((ext_vector_type(4), aligned(8)));
+
+// bit h of a lane's mask: column h * 16 + (lane & 15) of the pass gets codes (its level is streamed)
+template <int CBT>
+__device__ inline unsigned int code_lane_mask(int lane, int c0, int ncol, int L, int Lc) {
+  unsigned int m = 0;
+#pragma unroll
+  for (int h = 0; h < CBT; ++h) {
+    const int col = h * 16 + (lane & 15);
+    if (col < ncol && (c0 + col) % L < Lc) m |= 1u << h;
+  }
+  return m;
+}
+
+template <class TC, int CBT>
+__device__ __forceinline__ void tile_load(typename Mfma<TC>::acc_t (&acc)[CBT], const TC* __restrict__ P,
+                                          int64_t ldp, int c0, int ncol, int64_t row0, int64_t n,
+                                          int lane) {
+  const int64_t r4 = row0 + 4 * (lane >> 4);
+#pragma unroll
+  for (int h = 0; h < CBT; ++h) {
+    const int col = h * 16 + (lane & 15);
+    if (col < ncol) {
+      const TC* p = P + (int64_t)(c0 + col) * ldp + r4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r4 + r < n) acc[h][r] = p[r];
+    }
+  }
+}
+
+template <class TC, int CBT, bool CODES>
+__device__ __forceinline__ void tile_store(const typename Mfma<TC>::acc_t (&acc)[CBT], TC* __restrict__ P,
+                                           int64_t ldp, int c0, int ncol, int64_t row0, int64_t n,
+                                           int lane, const CodeCtl<TC>* ctl, unsigned int cmask) {
+  const int64_t r4 = row0 + 4 * (lane >> 4);
+  if (r4 >= n) return;
+  const bool vec = r4 + 3 < n && (ldp & 3) == 0;  // whole, 16-byte aligned runs
+#pragma unroll
+  for (int h = 0; h < CBT; ++h) {
+    const int col = h * 16 + (lane & 15);
+    if (col < ncol) {
+      TC* p = P + (int64_t)(c0 + col) * ldp + r4;
+      if (vec) {
+        typename Vec4<TC>::type v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[h][r];
+        *reinterpret_cast<typename Vec4<TC>::type*>(p) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r4 + r < n) p[r] = acc[h][r];
+      }
+    }
+  }
+  if constexpr (CODES) {
+    if (cmask == 0) return;
+    const CodeCtl<TC> cc = *ctl;
+    const CodeGeo<TC> g{cc.s, cc.b};
+    const bool cvec = r4 + 3 < n && (cc.ld & 3) == 0;
+#pragma unroll
+    for (int h = 0; h < CBT; ++h)
+      if ((cmask >> h) & 1u) {
+        uint16_t* q = cc.base + (int64_t)(h * 16 + (lane & 15)) * cc.ld + r4;
+        if (cvec) {
+          code4_t v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = code_of(acc[h][r], g);
+          *reinterpret_cast<code4_t*>(q) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r4 + r < n) q[r] = code_of(acc[h][r], g);
+        }
+      }
+  }
+}
 
 template <class TIn, class TC, int CBT, int KCH, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void proj_mfma(const TIn* __restrict__ X, int64_t n,
@@ -400,7 +517,7 @@ __global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, 
   }
 }
 
-template <class TIn, class TC, int D, int CBT>
+template <class TIn, class TC, int D, int CBT, bool CODES = false>
 __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0,
                                                          int ncol, TC* __restrict__ P,
@@ -408,10 +525,26 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
                                                          int64_t ldx /* row stride of X */,
                                                          int accumulate /* P += instead of = */,
                                                          int kvalid /* elements of the K chunk that
-                                                                       exist (the rest reads as 0) */) {
+                                                                       exist (the rest reads as 0) */,
+                                                         uint16_t* __restrict__ Cd /* codes.h; null
+                                                            unless this pass completes the sums */,
+                                                         int64_t ldc,
+                                                         const unsigned long long* __restrict__ cmm,
+                                                         int cL, int cLc /* codes for the columns
+                                                            whose level (column % cL) is < cLc */) {
   constexpr int STEPS = D / 4;
   constexpr int PIECE = 16 / (int)sizeof(TIn);            // elements per 16-B piece
   constexpr int PIECES_PER_ROW = D / PIECE;
+  __shared__ CodeCtl<TC> cctl;
+  unsigned int cmask = 0;
+  if constexpr (CODES) {
+    if (threadIdx.x == 0) {
+      const CodeGeo<TC> g = code_geo<TC>(cmm[0], cmm[1]);
+      cctl = CodeCtl<TC>{Cd + (int64_t)c0 * ldc, ldc, g.s, g.b};
+    }
+    cmask = code_lane_mask<CBT>(threadIdx.x & 63, c0, ncol, cL, cLc);
+    __syncthreads();
+  }
   constexpr int NP = 16 * PIECES_PER_ROW / 64;            // pieces per lane per tile
   constexpr int LDW = D + 16 / (int)sizeof(TC);           // LDS row stride (elements of TC)
   static_assert((16 * PIECES_PER_ROW) % 64 == 0, "tile must be a multiple of 64 pieces");
@@ -466,34 +599,19 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
     commit();                                   // waits for the staged pieces, writes LDS
     const int64_t tn = t + wave_stride;
     if (tn < ntiles) issue(tn);                 // in flight during the MFMA phase
-    const int64_t row = t * 16 + m;             // D col = lane&15 = point
     acc_t acc[CBT];
 #pragma unroll
     for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
-    if (accumulate && row < n) {  // a later K chunk of rows longer than D: continue the sum
-#pragma unroll
-      for (int h = 0; h < CBT; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
-          if (col < ncol) acc[h][r] = P[(int64_t)(c0 + col) * ldp + row];
-        }
-    }
+    // a later K chunk of rows longer than D: continue the sum
+    if (accumulate) tile_load<TC, CBT>(acc, P, ldp, c0, ncol, t * 16, n, lane);
+    const int mp = Mfma<TC>::point_of_m(m);  // the tile row this lane feeds (point-major tiles)
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      const TC b = my[m * LDW + 4 * s + q];
+      const TC b = my[mp * LDW + 4 * s + q];
 #pragma unroll
-      for (int h = 0; h < CBT; ++h) acc[h] = Mfma<TC>::run(a[h][s], b, acc[h]);
+      for (int h = 0; h < CBT; ++h) acc[h] = Mfma<TC>::run(b, a[h][s], acc[h]);
     }
-    if (row < n) {
-#pragma unroll
-      for (int h = 0; h < CBT; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
-          if (col < ncol) P[(int64_t)(c0 + col) * ldp + row] = acc[h][r];
-        }
-    }
+    tile_store<TC, CBT, CODES>(acc, P, ldp, c0, ncol, t * 16, n, lane, &cctl, cmask);
     t = tn;
   }
 }
@@ -514,10 +632,11 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
 // ---------------------------------------------------------------------------------------
 template <class TC, int D, int CBT, int KS, int WPB>
 constexpr size_t wide_smem_bytes() {
-  return ((size_t)CBT * (D / 4) * 64 + (size_t)WPB * 16 * (D / KS + 16 / sizeof(TC))) * sizeof(TC);
+  return ((size_t)CBT * (D / 4) * 64 + (size_t)WPB * 16 * (D / KS + 16 / sizeof(TC))) * sizeof(TC) +
+         sizeof(CodeCtl<TC>);  // + code destination and geometry
 }
 
-template <class TIn, class TC, int D, int CBT, int KS, int WPB>
+template <class TIn, class TC, int D, int CBT, int KS, int WPB, bool CODES = false>
 __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0,
                                                          int ncol, TC* __restrict__ P,
@@ -525,7 +644,13 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
                                                          int64_t ldx /* row stride of X */,
                                                          int accumulate /* P += instead of = */,
                                                          int kvalid /* elements of the K chunk that
-                                                                       exist (the rest reads as 0) */) {
+                                                                       exist (the rest reads as 0) */,
+                                                         uint16_t* __restrict__ Cd /* codes.h; null
+                                                            unless this pass completes the sums */,
+                                                         int64_t ldc,
+                                                         const unsigned long long* __restrict__ cmm,
+                                                         int cL, int cLc /* codes for the columns
+                                                            whose level (column % cL) is < cLc */) {
   constexpr int STEPS = D / 4, SSTEPS = STEPS / KS, KW = D / KS;
   constexpr int PIECE = 16 / (int)sizeof(TIn);  // elements per 16-B piece
   constexpr int PPR = KW / PIECE;               // pieces per row slice
@@ -536,6 +661,7 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
   TC* As = reinterpret_cast<TC*>(wide_smem);                   // [CBT][STEPS][64]
   TC* tiles = As + (size_t)CBT * STEPS * 64;                   // [WPB][16 * LDW]
+  CodeCtl<TC>* cctl = reinterpret_cast<CodeCtl<TC>*>(tiles + (size_t)WPB * 16 * LDW);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
@@ -544,6 +670,14 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
   struct alignas(16) Raw { TIn v[PIECE]; };
 
   for (int i = threadIdx.x; i < CBT * STEPS * 64; i += WPB * 64) As[i] = Apad[i];
+  unsigned int cmask = 0;
+  if constexpr (CODES) {
+    if (threadIdx.x == 0) {
+      const CodeGeo<TC> g = code_geo<TC>(cmm[0], cmm[1]);
+      *cctl = CodeCtl<TC>{Cd + (int64_t)c0 * ldc, ldc, g.s, g.b};
+    }
+    cmask = code_lane_mask<CBT>(lane, c0, ncol, cL, cLc);
+  }
   __syncthreads();
 
   const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave;
@@ -584,19 +718,12 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
   }
   while (t < ntiles) {
     const int64_t tn = t + wave_stride;
-    const int64_t row = t * 16 + m;  // D col = lane&15 = point
     acc_t acc[CBT];
 #pragma unroll
     for (int h = 0; h < CBT; ++h) acc[h] = acc_t{0, 0, 0, 0};
-    if (accumulate && row < n) {  // a later K chunk of rows longer than D: continue the sum
-#pragma unroll
-      for (int h = 0; h < CBT; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
-          if (col < ncol) acc[h][r] = P[(int64_t)(c0 + col) * ldp + row];
-        }
-    }
+    // a later K chunk of rows longer than D: continue the sum
+    if (accumulate) tile_load<TC, CBT>(acc, P, ldp, c0, ncol, t * 16, n, lane);
+    const int mp = Mfma<TC>::point_of_m(m);  // the tile row this lane feeds (point-major tiles)
 #pragma unroll
     for (int sl = 0; sl < KS; ++sl) {
       // slice sl -> LDS, then request the slice two ahead into the stage just freed
@@ -612,22 +739,14 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
       if (sl * KW < kvalid) {  // a slice beyond a short row holds zeros only
 #pragma unroll
         for (int s = 0; s < SSTEPS; ++s) {
-          const TC b = my[m * LDW + 4 * s + q];
+          const TC b = my[mp * LDW + 4 * s + q];
 #pragma unroll
           for (int h = 0; h < CBT; ++h)
-            acc[h] = Mfma<TC>::run(As[(h * STEPS + sl * SSTEPS + s) * 64 + lane], b, acc[h]);
+            acc[h] = Mfma<TC>::run(b, As[(h * STEPS + sl * SSTEPS + s) * 64 + lane], acc[h]);
         }
       }
     }
-    if (row < n) {
-#pragma unroll
-      for (int h = 0; h < CBT; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = h * 16 + Mfma<TC>::row_of(lane, r);
-          if (col < ncol) P[(int64_t)(c0 + col) * ldp + row] = acc[h][r];
-        }
-    }
+    tile_store<TC, CBT, CODES>(acc, P, ldp, c0, ncol, t * 16, n, lane, cctl, cmask);
     t = tn;
   }
 }
@@ -923,25 +1042,36 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
 // CBT*16 hyperplanes padded into fragment order at Ab
 template <class TIn, class TC, int D, int CBT, int KS>
 int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int kvalid, int accumulate, int c0,
-                    int ncol, const TC* Ab, TC* P, int64_t ntiles, int64_t blocks) {
+                    int ncol, const TC* Ab, TC* P, int64_t ntiles, int64_t blocks,
+                    const CodeOut* co /* null: no codes from this pass */) {
   constexpr int WPB = 8;
   constexpr size_t smem = wide_smem_bytes<TC, D, CBT, KS, WPB>();
   static bool attr_done = false;
   if (!attr_done) {
     RPT_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB>),
+        reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    RPT_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB>), dim3((unsigned)blocks),
-                     dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X + k0, ds->n, Ab, c0, ncol,
-                     P, ds->n, ntiles, (int64_t)ds->d, accumulate, kvalid);
+  if (co)
+    hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, true>), dim3((unsigned)blocks),
+                       dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X + k0, ds->n, Ab, c0,
+                       ncol, P, ds->n, ntiles, (int64_t)ds->d, accumulate, kvalid, co->codes, co->ld,
+                       co->mm, co->L, co->Lc);
+  else
+    hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, false>), dim3((unsigned)blocks),
+                       dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X + k0, ds->n, Ab, c0,
+                       ncol, P, ds->n, ntiles, (int64_t)ds->d, accumulate, kvalid,
+                       (uint16_t*)nullptr, (int64_t)0, (const unsigned long long*)nullptr, 1, 0);
   return RPT_OK;
 }
 
 template <class TIn, class TC>
 int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
-                    TC* P) {
+                    TC* P, const CodeOut* co, bool* codes_written) {
   const int64_t n = ds->n;
   const int64_t ntiles = (n + 15) / 16;
   constexpr int kPiece = 16 / (int)sizeof(TIn);
@@ -1014,6 +1144,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
     for (int kc = 0; kc < nkc; ++kc) {
       const int k0 = kc * D, accumulate = kc > 0;
       const int kvalid = ds->d - k0 < D ? ds->d - k0 : D;
+      const CodeOut* cop = (co && kc == nkc - 1) ? co : nullptr;  // codes of the COMPLETE sums
       for (const Pass& ps : passes) {
         const TC* Ab = Afrag.p + off;
         off += (size_t)(ps.tiles ? ps.tiles : 2) * frag;
@@ -1022,30 +1153,37 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
           switch (ps.tiles) {
             case 8:
               RPT_TRY((launch_wide<TIn, TC, D, 8, KS8>(ctx, ds, k0, kvalid, accumulate, ps.c0,
-                                                       ps.ncol, Ab, P, ntiles, wblocks)));
+                                                       ps.ncol, Ab, P, ntiles, wblocks, cop)));
               break;
             case 6:
               RPT_TRY((launch_wide<TIn, TC, D, 6, 4>(ctx, ds, k0, kvalid, accumulate, ps.c0,
-                                                     ps.ncol, Ab, P, ntiles, wblocks)));
+                                                     ps.ncol, Ab, P, ntiles, wblocks, cop)));
               break;
             default:
               RPT_TRY((launch_wide<TIn, TC, D, 4, 2>(ctx, ds, k0, kvalid, accumulate, ps.c0,
-                                                     ps.ncol, Ab, P, ntiles, wblocks)));
+                                                     ps.ncol, Ab, P, ntiles, wblocks, cop)));
           }
         } else {
           ProfScope pn(ctx, RPT_PROF_PROJECT);
-          if (ps.ncol > 16)
-            hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2>), dim3((unsigned)blocks), dim3(256), 0,
-                               ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n,
-                               ntiles, (int64_t)ds->d, accumulate, kvalid);
-          else
-            hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 1>), dim3((unsigned)blocks), dim3(256), 0,
-                               ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n,
-                               ntiles, (int64_t)ds->d, accumulate, kvalid);
+#define RPT_FAST(CBT_, CODES_)                                                                  \
+  hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, CBT_, CODES_>), dim3((unsigned)blocks), dim3(256), \
+                     0, ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n, ntiles,  \
+                     (int64_t)ds->d, accumulate, kvalid, cop ? cop->codes : (uint16_t*)nullptr,    \
+                     cop ? cop->ld : (int64_t)0, cop ? cop->mm : (const unsigned long long*)nullptr, \
+                     cop ? cop->L : 1, cop ? cop->Lc : 0)
+          if (ps.ncol > 16) {
+            if (cop) RPT_FAST(2, true);
+            else RPT_FAST(2, false);
+          } else {
+            if (cop) RPT_FAST(1, true);
+            else RPT_FAST(1, false);
+          }
+#undef RPT_FAST
         }
       }
     }
     RPT_HIP(hipGetLastError());
+    if (co && codes_written) *codes_written = true;
     return RPT_OK;  // the fragment buffer returns to the allocator, which recycles it only after
                     // the stream has been synchronised
   }
@@ -1143,7 +1281,7 @@ int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, 
 
 template <class T>
 int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
-                           T* P) {
+                           T* P, const CodeOut* co, bool* codes_written) {
   const int64_t n = ds->n;
   const int d = ds->d;
   constexpr int CB = 32;
@@ -1156,13 +1294,19 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
     const int c0 = b * CB;
     const int ncol = C - c0 < CB ? C - c0 : CB;
     ProfScope ps(ctx, RPT_PROF_PROJECT);
+    unsigned int cmask = 0;  // columns of this block whose level is streamed (codes.h)
+    if (co)
+      for (int c = 0; c < ncol; ++c)
+        if ((c0 + c) % co->L < co->Lc) cmask |= 1u << c;
     if (d == 128) {
       const int64_t nt128 = (n + 127) / 128;
       int64_t lb = (nt128 + 3) / 4;
       if (lb > (int64_t)ctx->n_cu * 2) lb = (int64_t)ctx->n_cu * 2;
       hipLaunchKernelGGL((proj_exact_lds<T, 128, 8>), dim3((unsigned)lb), dim3(256), 0, ctx->stream,
                          (const T*)ds->X, n, Rt.p + (size_t)b * d * CB, P + (int64_t)c0 * n, n, ncol,
-                         nt128);
+                         nt128, co ? co->codes + (int64_t)c0 * co->ld : (uint16_t*)nullptr,
+                         co ? co->ld : (int64_t)0, co ? co->mm : (const unsigned long long*)nullptr,
+                         cmask);
     } else {
       hipLaunchKernelGGL((proj_exact<T, CB, 32>), dim3((unsigned)blocks), dim3(256), 0,
                          ctx->stream, (const T*)ds->X, n, d, Rt.p + (size_t)b * d * CB,
@@ -1170,6 +1314,7 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
     }
   }
   RPT_HIP(hipGetLastError());
+  if (co && codes_written && d == 128) *codes_written = true;
   return RPT_OK;  // Rt returns to the stream-ordered allocator
 }
 
@@ -1207,8 +1352,22 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
 
 }  // namespace
 
+// whether project_columns(.., co) would write codes for this dataset in this mode (the callers
+// skip the sample pass otherwise): the pipelined dense kernels only
+bool project_writes_codes(const rpt_ctx* ctx, const rpt_dataset* ds, int32_t mode) {
+  if (ds->csr) return false;
+  if (mode == RPT_PROJ_AUTO) mode = ds->dtype == RPT_F64 ? RPT_PROJ_EXACT : RPT_PROJ_MFMA;
+  if (mode == RPT_PROJ_EXACT) return ds->dtype != RPT_BF16 && ds->d == 128;
+  const int piece = 16 / (int)dtype_size(ds->dtype);
+  if (ds->d % piece != 0) return false;
+  if (ds->dtype == RPT_BF16)  // the bf16x3 kernel has no code epilogue (yet)
+    return !(ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !ctx->opt.proj_bf16_f32);
+  return true;
+}
+
 int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C,
-                        int32_t mode, void* P_dev) {
+                        int32_t mode, void* P_dev, const CodeOut* co, bool* codes_written) {
+  if (codes_written) *codes_written = false;
   RPT_ARG(mode == RPT_PROJ_AUTO || mode == RPT_PROJ_EXACT || mode == RPT_PROJ_MFMA,
           "unknown projection mode");
   if (ds->n == 0) return RPT_OK;
@@ -1219,17 +1378,21 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
     return launch_csr<float>(ctx, ds, R_dev, C, (float*)P_dev);
   }
   if (mode == RPT_PROJ_EXACT) {
-    if (ds->dtype == RPT_F64) return launch_exact_dense<double>(ctx, ds, R_dev, C, (double*)P_dev);
-    if (ds->dtype == RPT_F32) return launch_exact_dense<float>(ctx, ds, R_dev, C, (float*)P_dev);
+    if (ds->dtype == RPT_F64)
+      return launch_exact_dense<double>(ctx, ds, R_dev, C, (double*)P_dev, co, codes_written);
+    if (ds->dtype == RPT_F32)
+      return launch_exact_dense<float>(ctx, ds, R_dev, C, (float*)P_dev, co, codes_written);
     return fail(RPT_E_UNSUPPORTED, "exact-order projection is defined for f64/f32 data");
   }
-  if (ds->dtype == RPT_F64) return launch_mfma<double, double>(ctx, ds, R_dev, C, (double*)P_dev);
-  if (ds->dtype == RPT_F32) return launch_mfma<float, float>(ctx, ds, R_dev, C, (float*)P_dev);
+  if (ds->dtype == RPT_F64)
+    return launch_mfma<double, double>(ctx, ds, R_dev, C, (double*)P_dev, co, codes_written);
+  if (ds->dtype == RPT_F32)
+    return launch_mfma<float, float>(ctx, ds, R_dev, C, (float*)P_dev, co, codes_written);
   // bf16: three bf16 MFMAs per tile against the split hyperplanes when the rows allow 16-byte
   // fragment loads, else the f32-MFMA kernels on converted inputs (option proj_bf16_f32: force them)
   if (ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !ctx->opt.proj_bf16_f32)
     return launch_bf16x3(ctx, ds, R_dev, C, (float*)P_dev);
-  return launch_mfma<__hip_bfloat16, float>(ctx, ds, R_dev, C, (float*)P_dev);
+  return launch_mfma<__hip_bfloat16, float>(ctx, ds, R_dev, C, (float*)P_dev, co, codes_written);
 }
 
 }  // namespace rpt

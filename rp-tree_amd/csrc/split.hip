@@ -36,6 +36,7 @@
 #include <list>
 
 #include "common.h"
+#include "codes.h"
 
 namespace rpt {
 namespace {
@@ -46,26 +47,6 @@ constexpr int kSample = 1024;     // samples per big node
 constexpr int kDelta = 80;        // splitter half-width in sample ranks (5 sigma: sd = 16)
 constexpr int kChunk = 4096;      // elements per block in hist / scatter
 constexpr int kPad = 0x7fffffff;  // id of bitonic padding entries
-
-// ---- ordered-integer image of a floating key (for atomicMax / atomicMin) ----------------
-__device__ inline unsigned long long ord_of(double v) {
-  unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
-}
-__device__ inline double ord_to(unsigned long long u, double) {
-  u = (u >> 63) ? (u & 0x7fffffffffffffffULL) : ~u;
-  return __longlong_as_double((long long)u);
-}
-__device__ inline unsigned long long ord_of(float v) {
-  unsigned int u = __float_as_uint(v);
-  u = (u >> 31) ? ~u : (u | 0x80000000u);
-  return (unsigned long long)u;
-}
-__device__ inline float ord_to(unsigned long long w, float) {
-  unsigned int u = (unsigned int)w;
-  u = (u >> 31) ? (u & 0x7fffffffu) : ~u;
-  return __uint_as_float(u);
-}
 
 // Projections of one tree: P[level][N].  tie_less: a precedes b when their primary keys at
 // `level` are equal = lexicographic order on the earlier levels, then id (or tb[] when the
@@ -1565,13 +1546,19 @@ inline int stream_bins(int M, int64_t node_points, int64_t big_node) {
 }
 
 // min / max of one level's keys over the whole tree (root geometry). grid = (nblk, T)
+// In CODE mode (Cd != null, codes.h) the streaming kernels histogram and classify the 16-bit
+// codes of the keys, converted to TK: every formula below (geometry, bins, min/max) works on
+// those integer-valued keys unchanged, and exact keys are fetched only for the points that need
+// them (pivot bins, margins).
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __restrict__ P,
+                                                                 const uint16_t* __restrict__ Cd,
                                                                  int64_t N, int L, int64_t per,
                                                                  unsigned long long* cmin,
                                                                  unsigned long long* cmax) {
   const int t = blockIdx.y;
   const TK* Pl = P + (int64_t)t * L * N;
+  const uint16_t* Cl = Cd ? Cd + (int64_t)t * L * N : nullptr;
   const int64_t i0 = (int64_t)blockIdx.x * per;
   int64_t i1 = i0 + per < N ? i0 + per : N;
   // the range only shapes the root's bins (keys outside clamp to the edge bins): an eighth of
@@ -1579,7 +1566,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_minmax0(const TK* __res
   if (N >= 65536) i1 = i0 + ((i1 - i0 + 7) >> 3);
   unsigned long long mn = ~0ULL, mx = 0ULL;
   for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) {
-    const unsigned long long o = ord_of(Pl[i]);
+    const unsigned long long o = ord_of(Cl ? (TK)Cl[i] : Pl[i]);
     mn = o < mn ? o : mn;
     mx = o > mx ? o : mx;
   }
@@ -1642,9 +1629,10 @@ __device__ inline int stream_bin(TK key, TK lo, TK scale, int B) {
 // points when a rank holds few trees).  grid = (nblk, T)
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_hist(
-    const TK* __restrict__ P, const uint16_t* __restrict__ node_of, int64_t N, int L, int level,
-    int M, int B, int64_t per, const unsigned long long* __restrict__ cmin,
-    const unsigned long long* __restrict__ cmax, unsigned int* __restrict__ part) {
+    const TK* __restrict__ P, const uint16_t* __restrict__ Cd, const uint16_t* __restrict__ node_of,
+    int64_t N, int L, int level, int M, int B, int64_t per,
+    const unsigned long long* __restrict__ cmin, const unsigned long long* __restrict__ cmax,
+    unsigned int* __restrict__ part) {
   __shared__ unsigned int hist[kStreamBins / 2];  // two 16-bit counters per word
   __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
   const int t = blockIdx.y;
@@ -1664,7 +1652,27 @@ __global__ __launch_bounds__(kStreamThreads) void stream_hist(
     atomicAdd(&hist[e >> 1], 1u << ((e & 1) * 16));  // per < 65536: no carry between halves
   };
   typedef TK key2_t __attribute__((ext_vector_type(2)));
-  if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {  // 16-byte key loads, 4-byte node loads
+  if (Cd) {  // code mode: 4 bytes per point; eight points per thread and step (16-byte loads)
+    const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
+    if (((N | i0 | per) & 7) == 0) {
+      const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)7);
+      for (int64_t i = i0 + 8 * (int64_t)threadIdx.x; i < ie; i += 8 * kStreamThreads) {
+        const uint4 jj = *reinterpret_cast<const uint4*>(no + i);
+        const uint4 cc = *reinterpret_cast<const uint4*>(Cl + i);
+        one((int)(jj.x & 0xffffu), (TK)(cc.x & 0xffffu));
+        one((int)(jj.x >> 16), (TK)(cc.x >> 16));
+        one((int)(jj.y & 0xffffu), (TK)(cc.y & 0xffffu));
+        one((int)(jj.y >> 16), (TK)(cc.y >> 16));
+        one((int)(jj.z & 0xffffu), (TK)(cc.z & 0xffffu));
+        one((int)(jj.z >> 16), (TK)(cc.z >> 16));
+        one((int)(jj.w & 0xffffu), (TK)(cc.w & 0xffffu));
+        one((int)(jj.w >> 16), (TK)(cc.w >> 16));
+      }
+      for (int64_t i = ie + threadIdx.x; i < i1; i += kStreamThreads) one(no[i], (TK)Cl[i]);
+    } else {
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) one(no[i], (TK)Cl[i]);
+    }
+  } else if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {  // 16-byte key loads, 4-byte node loads
     const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)1);
     for (int64_t i = i0 + 2 * (int64_t)threadIdx.x; i < ie; i += 2 * kStreamThreads) {
       const unsigned int jj = *reinterpret_cast<const unsigned int*>(no + i);
@@ -1952,9 +1960,10 @@ __global__ __launch_bounds__(256) void stream_pick_big(int64_t N, int level, int
 
 template <class TK>
 __global__ __launch_bounds__(kStreamThreads) void stream_assign(
-    const TK* __restrict__ P, uint16_t* __restrict__ node_of, int64_t N, int L, int level, int M,
-    int B, int64_t per, int has_next, SNode<TK>* nd, int32_t* __restrict__ pool,
-    TK* __restrict__ poolkey, unsigned long long* cmin_next, unsigned long long* cmax_next) {
+    const TK* __restrict__ P, const uint16_t* __restrict__ Cd, uint16_t* __restrict__ node_of,
+    int64_t N, int L, int level, int M, int B, int64_t per, int has_next, SNode<TK>* nd,
+    int32_t* __restrict__ pool, TK* __restrict__ poolkey, unsigned long long* cmin_next,
+    unsigned long long* cmax_next) {
   __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
   __shared__ __attribute__((aligned(16))) ABins nbin[kStreamMaxNodes];
   __shared__ int nmidoff[kStreamMaxNodes];
@@ -1981,7 +1990,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   // The children's min/max of the NEXT level's key only shape that level's bins (keys outside
   // the range are clamped into the edge bins), so a sample is enough: the first quarter of the
   // block's points — every point while nodes are small.
-  const int64_t isamp = (N >> level) < 1024 ? i1 : (i0 + ((i1 - i0 + 3) >> 2) + 1) & ~(int64_t)1;
+  const int64_t isamp = (N >> level) < 1024 ? i1 : (i0 + ((i1 - i0 + 3) >> 2) + 7) & ~(int64_t)7;
   // few nodes: a per-thread running min/max per child avoids hammering one LDS word
   const bool few = M <= 4;
   unsigned long long tmn[8], tmx[8];
@@ -1990,20 +1999,22 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     tmn[c] = ~0ULL;
     tmx[c] = 0ULL;
   }
-  // classify one point: child node index, or -1 when it went to the node's pivot-bin list
-  auto classify = [&](int64_t i, int j, TK key) -> int {
+  // classify one point: child node index, or -1 when it went to the node's pivot-bin list.
+  // kb = the value that is binned: the key itself, or (code mode) the key's 16-bit code; the
+  // exact key is then read only where it decides something — pivot bin, margin bins.
+  auto classify = [&](int64_t i, int j, TK kb) -> int {
     const AGeom<TK> g = ngeo[j];
     const ABins nb = nbin[j];
-    const int b = stream_bin(key, g.lo, g.sc, B);
+    const int b = stream_bin(kb, g.lo, g.sc, B);
     const int pb = nb.pb;
     if (b == pb) {
       const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
       pl[nmidoff[j] + p] = (int32_t)i;
-      pk[nmidoff[j] + p] = key;
+      pk[nmidoff[j] + p] = Cd ? Pl[i] : kb;
       return -1;
     }
-    if (b == nb.lowb) atomicMax(&ndt[j].maxL, ord_of(key));
-    if (b == nb.highb) atomicMin(&ndt[j].minR, ord_of(key));
+    if (b == nb.lowb) atomicMax(&ndt[j].maxL, ord_of(Cd ? Pl[i] : kb));
+    if (b == nb.highb) atomicMin(&ndt[j].minR, ord_of(Cd ? Pl[i] : kb));
     return 2 * j + (b > pb);
   };
   auto sample = [&](int child, TK knext) {
@@ -2023,7 +2034,49 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   // two consecutive points per thread and step: 16-byte key loads, 4-byte node loads/stores
   // (the key rows are 16-byte aligned when N is even and the block ranges start on even offsets)
   typedef TK key2_t __attribute__((ext_vector_type(2)));
-  if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {
+  if (Cd) {  // code mode: eight points per thread and step, 16-byte code and node loads / stores
+    const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
+    const uint16_t* Cn = has_next ? Cl + N : Cl;
+    auto one = [&](int64_t i) {
+      const int c = classify(i, no[i], (TK)Cl[i]);
+      if (c >= 0) {
+        no[i] = (uint16_t)c;
+        if (has_next && i < isamp) sample(c, (TK)Cn[i]);
+      }
+    };
+    if (((N | i0 | per) & 7) == 0) {
+      const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)7);
+      for (int64_t i = i0 + 8 * (int64_t)threadIdx.x; i < ie; i += 8 * kStreamThreads) {
+        const uint4 jj = *reinterpret_cast<const uint4*>(no + i);
+        const uint4 cc = *reinterpret_cast<const uint4*>(Cl + i);
+        const unsigned int jw[4] = {jj.x, jj.y, jj.z, jj.w}, cw[4] = {cc.x, cc.y, cc.z, cc.w};
+        int ch[8];
+        unsigned int ow[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int ja = (int)(jw[w] & 0xffffu), jb = (int)(jw[w] >> 16);
+          ch[2 * w] = classify(i + 2 * w, ja, (TK)(cw[w] & 0xffffu));
+          ch[2 * w + 1] = classify(i + 2 * w + 1, jb, (TK)(cw[w] >> 16));
+          // a pivot-bin point keeps its node until stream_mid has ordered the bin
+          ow[w] = (unsigned int)(ch[2 * w] >= 0 ? ch[2 * w] : ja) |
+                  ((unsigned int)(ch[2 * w + 1] >= 0 ? ch[2 * w + 1] : jb) << 16);
+        }
+        *reinterpret_cast<uint4*>(no + i) = uint4{ow[0], ow[1], ow[2], ow[3]};
+        if (has_next && i < isamp) {
+          const uint4 nn = *reinterpret_cast<const uint4*>(Cn + i);
+          const unsigned int nw[4] = {nn.x, nn.y, nn.z, nn.w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            if (ch[2 * w] >= 0) sample(ch[2 * w], (TK)(nw[w] & 0xffffu));
+            if (ch[2 * w + 1] >= 0) sample(ch[2 * w + 1], (TK)(nw[w] >> 16));
+          }
+        }
+      }
+      for (int64_t i = ie + threadIdx.x; i < i1; i += kStreamThreads) one(i);
+    } else {
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) one(i);
+    }
+  } else if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {
     const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)1);
     for (int64_t i = i0 + 2 * (int64_t)threadIdx.x; i < ie; i += 2 * kStreamThreads) {
       const unsigned int jj = *reinterpret_cast<const unsigned int*>(no + i);
@@ -2089,6 +2142,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
 template <class TK>
 struct MidArgs {
   const TK* P;
+  const uint16_t* Cd;  // code mode: the children's range of the next level is a range of CODES
   uint16_t* node_of;
   int64_t N;
   int L, level, M, has_next;
@@ -2100,6 +2154,13 @@ struct MidArgs {
   double *thr, *mglo, *mghi;
   unsigned long long* tie_count;
 };
+
+// the value whose range shapes the next level's bins: the next level's key, or its code
+template <class TK>
+__device__ inline TK mid_next_key(const MidArgs<TK>& A, int t, int id) {
+  const int64_t o = ((int64_t)t * A.L + A.level + 1) * A.N + id;
+  return A.Cd ? (TK)A.Cd[o] : A.P[o];
+}
 
 template <class TK>
 __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, int t, int j,
@@ -2130,7 +2191,6 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
   }
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
   uint16_t* no = A.node_of + (int64_t)t * N;
-  const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
   const int n = a.n, nh = a.nh;
   // the children's range of the next level's key comes from stream_assign's sample; the
@@ -2146,7 +2206,7 @@ __device__ inline void mid_wave_path(const MidArgs<TK>& A, const SNode<TK>& a, i
       const int side = i >= kk;
       no[id[r]] = (uint16_t)(2 * j + side);
       if (feed_next) {
-        const unsigned long long o = ord_of(Pn[id[r]]);
+        const unsigned long long o = ord_of(mid_next_key(A, t, id[r]));
         mn[side] = o < mn[side] ? o : mn[side];
         mx[side] = o > mx[side] ? o : mx[side];
       }
@@ -2226,14 +2286,13 @@ __device__ inline void mid_lds_path(const MidArgs<TK>& A, const SNode<TK>& a, in
   }
   const int kk = a.nh - a.cL;  // the first kk points of the sorted pivot bin go left
   uint16_t* no = A.node_of + (int64_t)t * N;
-  const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
   const bool feed_next = A.has_next && cMid * 4 >= a.n;  // see mid_wave_path
   for (int i = tid; i < cMid; i += nthr) {
     const int side = i >= kk;
     no[sid[i]] = (uint16_t)(2 * j + side);
     if (feed_next) {
-      const unsigned long long o = ord_of(Pn[sid[i]]);
+      const unsigned long long o = ord_of(mid_next_key(A, t, sid[i]));
       mn[side] = o < mn[side] ? o : mn[side];
       mx[side] = o > mx[side] ? o : mx[side];
     }
@@ -2376,13 +2435,12 @@ __device__ inline bool mid_select_path(const MidArgs<TK>& A, const SNode<TK>& a,
   }
   __syncthreads();
   uint16_t* no = A.node_of + (int64_t)t * N;
-  const TK* Pn = A.P + ((int64_t)t * A.L + A.level + 1) * N;
   unsigned long long mn[2] = {~0ULL, ~0ULL}, mx[2] = {0ULL, 0ULL};
   const bool feed_next = A.has_next && cMid * 4 >= a.n;  // see mid_wave_path
   auto place = [&](int id, int side) {
     no[id] = (uint16_t)(2 * j + side);
     if (feed_next) {
-      const unsigned long long o = ord_of(Pn[id]);
+      const unsigned long long o = ord_of(mid_next_key(A, t, id));
       mn[side] = o < mn[side] ? o : mn[side];
       mx[side] = o > mx[side] ? o : mx[side];
     }
@@ -2591,6 +2649,50 @@ __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
     __syncthreads();
     for (int k = threadIdx.x; k < cn; k += kStreamThreads) pm[gb[sj[k]] + k] = sid[k];
     __syncthreads();
+  }
+}
+
+// ---- code geometry (codes.h): a strided sample of the rows, projected like the data; the
+// minimum and maximum of every column that the streaming levels will histogram ----
+template <class TIn>
+__global__ void gather_rows_kernel(const TIn* __restrict__ X, int64_t n, int d, int64_t stride,
+                                   int S, TIn* __restrict__ Xs) {
+  const int64_t total = (int64_t)S * d;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / d;
+    int64_t row = r * stride;
+    row = row < n ? row : n - 1;
+    Xs[i] = X[row * d + (i - r * d)];
+  }
+}
+
+// mm[0..1] = (ord(min), ord(max)) over the sampled values Ps[c][0..S) of the columns whose level
+// (c % L) is below Lc: ONE code geometry for the whole batch (codes.h).  mm starts as (~0, 0).
+// One wave per column.  grid = ceil(C / 4), 256 threads
+template <class TK>
+__global__ __launch_bounds__(256) void code_minmax_kernel(const TK* __restrict__ Ps, int S, int C,
+                                                          int L, int Lc,
+                                                          unsigned long long* __restrict__ mm) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C || c % L >= Lc) return;
+  unsigned long long mn = ~0ULL, mx = 0ULL;
+  for (int i = lane; i < S; i += 64) {
+    const TK v = Ps[(int64_t)c * S + i];
+    if (v == v) {  // NaN samples do not shape anything
+      const unsigned long long o = ord_of(v);
+      mn = o < mn ? o : mn;
+      mx = o > mx ? o : mx;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (lane == 0 && mn <= mx) {
+    atomicMin(&mm[0], mn);
+    atomicMax(&mm[1], mx);
   }
 }
 
@@ -2807,7 +2909,73 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   // split while the device projects ----
   RPT_TRY(f->proj.alloc((size_t)T * L * N * sizeof(TK)));
   TK* P = reinterpret_cast<TK*>(f->proj.p);
-  if (Lused == L) {
+  // 16-bit codes of the keys of the levels the streaming path will handle (codes.h): worth
+  // their sample pass from a few hundred thousand points on; dense rows only.  The number of
+  // streamed levels is a function of (N, minLeaf, L): every node of level l is a Bin while the
+  // smallest one, floor-halved l times, is above minLeaf (the topology loop below agrees).
+  const int stream_cap = ctx->opt.stream_maxnodes > 0
+                             ? (int)(ctx->opt.stream_maxnodes < kStreamMaxNodes ? ctx->opt.stream_maxnodes
+                                                                                : kStreamMaxNodes)
+                             : (N / 1024 > kSmallCap ? 1024 : 512);
+  int Lc = 0;
+  if (N >= 2048 && !no_stream && !ctx->opt.no_stream) {
+    int64_t nmin = N;
+    while (Lc < Lused && nmin > (int64_t)f->min_leaf && (1 << Lc) <= stream_cap) {
+      ++Lc;
+      nmin /= 2;
+    }
+  }
+  DevBuf<uint16_t> codes;
+  DevBuf<unsigned long long> code_mm;
+  uint16_t* Cd = nullptr;  // [T][L][N], the columns of levels < Lc only
+  if (Lc > 0 && Lused == L && N >= ((int64_t)1 << 17) && !ctx->opt.no_codes &&
+      project_writes_codes(ctx, ds, mode)) {
+    // geometry: the range of ALL streamed columns over a strided sample of the rows (a few
+    // columns are not enough: on clustered data a hyperplane's range depends on how it separates
+    // the clusters, and a column that leaves the range clamps half its points into one code),
+    // through the MFMA kernels whatever the build's mode (the range only shapes bins)
+    constexpr int S = 4096;
+    DevBuf<char> Xs;
+    DevBuf<TK> Psamp;
+    const int C = T * L;
+    const int Cs = C;
+    RPT_TRY(Xs.alloc((size_t)S * f->d * dtype_size(ds->dtype)));
+    RPT_TRY(Psamp.alloc((size_t)Cs * S));
+    RPT_TRY(code_mm.alloc(2));
+    hipLaunchKernelGGL(stream_init_kernel, dim3(1), dim3(64), 0, st, code_mm.p, code_mm.p + 1, 1,
+                       (unsigned int*)nullptr, 0);  // (~0, 0)
+    const int64_t stride = N / S;
+    const unsigned gb = (unsigned)(((int64_t)S * f->d + 255) / 256 < 2048 ? ((int64_t)S * f->d + 255) / 256 : 2048);
+    if (ds->dtype == RPT_F64)
+      hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(gb), dim3(256), 0, st, (const double*)ds->X,
+                         N, f->d, stride, S, (double*)Xs.p);
+    else if (ds->dtype == RPT_F32)
+      hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(gb), dim3(256), 0, st, (const float*)ds->X, N,
+                         f->d, stride, S, (float*)Xs.p);
+    else
+      hipLaunchKernelGGL(gather_rows_kernel<uint16_t>, dim3(gb), dim3(256), 0, st,
+                         (const uint16_t*)ds->X, N, f->d, stride, S, (uint16_t*)Xs.p);
+    rpt_dataset samp;
+    samp.ctx = ctx;
+    samp.n = S;
+    samp.d = ds->d;
+    samp.dtype = ds->dtype;
+    samp.X = Xs.p;
+    RPT_TRY(project_columns(ctx, &samp, f->R.p, Cs, RPT_PROJ_MFMA, Psamp.p));
+    hipLaunchKernelGGL(code_minmax_kernel<TK>, dim3((unsigned)((Cs + 3) / 4)), dim3(256), 0, st,
+                       Psamp.p, S, Cs, L, Lc, code_mm.p);
+    RPT_TRY(codes.alloc((size_t)T * L * N));
+    CodeOut co;
+    co.codes = codes.p;
+    co.mm = code_mm.p;
+    co.ld = N;
+    co.L = L;
+    co.Lc = Lc;
+    bool written = false;
+    RPT_TRY(project_columns(ctx, ds, f->R.p, C, mode, P, &co, &written));
+    if (written) Cd = codes.p;
+    else codes.release();
+  } else if (Lused == L) {
     RPT_TRY(project_columns(ctx, ds, f->R.p, T * L, mode, P));
   } else {  // levels >= Lused are never reached (Internal.hs:270: rvs ! ixLev is lazy)
     for (int t = 0; t < T; ++t)
@@ -2929,15 +3097,15 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     const int64_t min_per = ctx->opt.stream_minper > 0 ? ctx->opt.stream_minper : 32768;
     int64_t nblk = (2 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblk > (N + min_per - 1) / min_per) nblk = (N + min_per - 1) / min_per;
-    if (nblk < (N + 65533) / 65534) nblk = (N + 65533) / 65534;
+    if (nblk < (N + 65519) / 65520) nblk = (N + 65519) / 65520;
     if (nblk < 1) nblk = 1;
-    const int64_t per = (((N + nblk - 1) / nblk) + 1) & ~(int64_t)1;  // even, <= 65534
+    const int64_t per = (((N + nblk - 1) / nblk) + 7) & ~(int64_t)7;  // multiple of 8, <= 65534
     const dim3 sgrid((unsigned)nblk, (unsigned)T);
     // assign pass: no per-block table to flush, fill the chip
     int64_t nblkA = (4 * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblkA > (N + 8191) / 8192) nblkA = (N + 8191) / 8192;
     if (nblkA < 1) nblkA = 1;
-    const int64_t perA = (((N + nblkA - 1) / nblkA) + 1) & ~(int64_t)1;  // even: 16-byte key loads
+    const int64_t perA = (((N + nblkA - 1) / nblkA) + 7) & ~(int64_t)7;  // 16-byte key / code loads
     const dim3 agrid((unsigned)nblkA, (unsigned)T);
     RPT_TRY(node_of.alloc((size_t)T * N));
     RPT_TRY(part.alloc((size_t)T * nblk * (kStreamBins / 2)));
@@ -2948,7 +3116,10 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     unsigned long long *cmin = mm[0].p, *cmax = mm[1].p, *cminN = mm[2].p, *cmaxN = mm[3].p;
     hipLaunchKernelGGL(stream_init_kernel, dim3(4), dim3(256), 0, st, cmin, cmax, T, poolcur.p,
                        T * Lstream);
-    hipLaunchKernelGGL(stream_minmax0<TK>, sgrid, dim3(kStreamThreads), 0, st, P, N, L, per, cmin,
+    // code mode only for the levels that have codes (the estimate above covers them all unless
+    // an option changed the plan in between)
+    const uint16_t* Cs = (Cd && Lstream <= Lc) ? Cd : nullptr;
+    hipLaunchKernelGGL(stream_minmax0<TK>, sgrid, dim3(kStreamThreads), 0, st, P, Cs, N, L, per, cmin,
                        cmax);
     HT("stream alloc+minmax0");
     int32_t* pool = bufB.p;  // the ping-pong buffers are idle while nothing moves
@@ -2965,8 +3136,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         const int M = 1 << level;
         const int has_next = level + 1 < Lstream ? 1 : 0;
         const int B = stream_bins(M, N >> level, big_node);
-        hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, node_of.p, N, L,
-                           level, M, B, per, cmin, cmax, part.p);
+        hipLaunchKernelGGL(stream_hist<TK>, sgrid, dim3(kStreamThreads), 0, st, P, Cs, node_of.p, N,
+                           L, level, M, B, per, cmin, cmax, part.p);
         unsigned int* pc = poolcur.p + (size_t)level * T;
 #define RPT_PICK(BPT, G)                                                                       \
   hipLaunchKernelGGL((stream_pick<TK, BPT, G>), dim3((unsigned)((M + 256 / G - 1) / (256 / G)), \
@@ -2992,11 +3163,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           }
         }
 #undef RPT_PICK
-        hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, node_of.p, N,
+        hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, Cs, node_of.p, N,
                            L, level, M, B, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
         const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
         const int npb = M >= 16 ? 4 : 1;
-        MidArgs<TK> ma{P,     node_of.p, N,     L,        level,    M,
+        MidArgs<TK> ma{P,     Cs,   node_of.p, N,     L,        level,    M,
                        has_next, snodes.p, pool, poolkey.p, cminN, cmaxN, (int64_t)M - 1, f->nodes,
                        f->thr.p, f->mglo.p, f->mghi.p, tie_count};
         hipLaunchKernelGGL(stream_mid<TK>, dim3((unsigned)((M + npb - 1) / npb), (unsigned)T),

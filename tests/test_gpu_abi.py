@@ -141,8 +141,14 @@ def test_merge_beyond_one_launch(rp, ctx, G, k):
     from rptree_amd import _lib
     rng = np.random.default_rng(G * k)
     nq = 7
+    # a point has ONE distance to a query (the de-duplicating merge relies on it): distances
+    # are a function of (query, id), rounded so that many different points tie
+    table = np.round(rng.random((nq, 3000)) * 50, 1)
     gi = rng.integers(0, 3000, size=(G, nq, k)).astype(np.int32)
-    gd = np.sort(np.round(rng.random((G, nq, k)) * 50, 1), axis=2)        # many equal distances
+    gd = np.take_along_axis(np.broadcast_to(table, (G, nq, 3000)), gi.astype(np.int64), axis=2)
+    order = np.argsort(gd, axis=2, kind="stable")
+    gi = np.take_along_axis(gi, order, axis=2)
+    gd = np.take_along_axis(gd, order, axis=2)
     gc = rng.integers(k // 2, k + 1, size=(G, nq)).astype(np.int32)
     gc[0, 0] = 0
     ti, td, tc = (torch.from_numpy(a).cuda() for a in (gi, gd, gc))
@@ -188,6 +194,41 @@ def test_every_fallback_option_keeps_the_forest_identical(rp, ctx, oracle):
             ctx.set_option(name, old)
         assert np.array_equal(f.perm, fo.perm), name
         assert np.array_equal(f.thr, fo.thr, equal_nan=True), name
+
+
+@pytest.mark.parametrize("kind", ["cont", "ties", "heavy", "constcol"])
+@pytest.mark.parametrize("mode", ["exact", "mfma"])
+def test_streaming_on_16bit_codes_is_exact(rp, ctx, oracle, kind, mode):
+    """From 131 072 points on the streaming levels histogram 16-bit codes of the keys (csrc/
+    codes.h) and read exact keys only for pivot bins and margins.  Exact mode: the forest must be
+    the oracle's on continuous data, on data with ties, on heavy ties (a few distinct values: pivot
+    bins outgrow everything, the general path takes over) and with a constant column; MFMA mode:
+    identical to the build that streams on the keys themselves (option no_codes)."""
+    n, d, T, ml = 200_000, 128, 3, 40
+    X = oracle.data_normal_dense2(77, n, d)
+    if kind == "ties":
+        X = np.round(X, 1)
+    elif kind == "heavy":
+        X = np.round(X * 0.7)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(3, T, L, pnz, d)
+    if kind == "constcol":
+        R[1, 2] = 0.0                                    # every projection of that level is 0.0
+        R[2, 0, :] = 0.0
+        R[2, 0, 5] = 1e-300                              # denormal-range keys
+    m = rp.RPT_PROJ_EXACT if mode == "exact" else rp.RPT_PROJ_MFMA
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=m)
+    old = ctx.set_option("no_codes", 1)
+    try:
+        g = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=m)
+    finally:
+        ctx.set_option("no_codes", old)
+    for name in ("perm", "thr", "mglo", "mghi"):
+        assert np.array_equal(getattr(f, name), getattr(g, name), equal_nan=True), name
+    if mode == "exact":
+        fo = oracle.forest_build_dense(X, R, ml, threads=T)
+        for name in ("perm", "thr", "mglo", "mghi"):
+            assert np.array_equal(getattr(f, name), getattr(fo, name), equal_nan=True), name
 
 
 # --------------------------------------------------------------------------- import (8f-1)
