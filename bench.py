@@ -72,6 +72,11 @@ def main():
     if world < 1:
         raise SystemExit("--gpus must be >= 1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries exactly ONE line, the JSON result: native libraries (RCCL prints a version
+    # banner on stdout when its first communicator is made) and stray prints go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -530,8 +535,8 @@ def main():
                         "flips are points whose projection is within rounding of a median"},
             "forest_stats": f_loc.stats(),
         }
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     forest.close()
     if launcher:
         dist.barrier()

@@ -8,14 +8,13 @@
 -- rp-tree_amd/host/rptree.hpp.
 module Data.RPTree.HIP (forestBatchHIP, knnHIP, FlatForest(..)) where
 
-import Control.Exception (Exception, throwIO)
+import Control.Exception (Exception, bracket, throwIO)
 import Control.Monad (when)
 import Data.Int (Int32, Int64)
 import Data.Word (Word64)
 import Foreign.C.String (CString, peekCString)
-import Foreign.ForeignPtr (ForeignPtr, newForeignPtr, withForeignPtr)
 import Foreign.Marshal.Alloc (alloca)
-import Foreign.Ptr (FunPtr, Ptr, castPtr, nullPtr)
+import Foreign.Ptr (Ptr)
 import Foreign.Storable (peek)
 import System.IO.Unsafe (unsafePerformIO)
 import qualified Data.IntMap.Strict as IM
@@ -29,20 +28,29 @@ import Data.RPTree.Gen (sparse)
 import Data.RPTree.Internal (Embed(..), DVector(..), SVector(..), RPForest, RPTree(..), RPT(..), Margin(..))
 import Data.Semigroup (Max(..), Min(..))
 
-data Ctx; data Dataset; data Forest
+data Ctx; data Dataset; data Forest; data Comm; data ShardedForest
 
 -- `safe`: every call may launch kernels and synchronise; do not block the RTS.
 foreign import ccall safe "rpt_ctx_create"          c_ctx_create     :: Int32 -> Ptr (Ptr Ctx) -> IO Int32
+foreign import ccall safe "rpt_ctx_destroy"         c_ctx_destroy    :: Ptr Ctx -> IO Int32
 foreign import ccall safe "rpt_dataset_dense_host"  c_dataset_dense  :: Ptr Ctx -> Ptr Double -> Int64 -> Int32 -> Int32 -> Ptr (Ptr Dataset) -> IO Int32
+foreign import ccall safe "rpt_dataset_free"        c_dataset_free   :: Ptr Dataset -> IO Int32
 foreign import ccall safe "rpt_forest_build"        c_forest_build   :: Ptr Ctx -> Ptr Dataset -> Ptr Double -> Int32 -> Int32 -> Int32 -> Int32 -> Ptr (Ptr Forest) -> IO Int32
+foreign import ccall safe "rpt_forest_free"         c_forest_free    :: Ptr Forest -> IO Int32
 foreign import ccall safe "rpt_forest_get_perm"     c_forest_perm    :: Ptr Forest -> Ptr Int32 -> IO Int32
 foreign import ccall safe "rpt_forest_get_nodes"    c_forest_nodes   :: Ptr Forest -> Ptr Double -> Ptr Double -> Ptr Double -> IO Int32
 foreign import ccall safe "rpt_knn_host"            c_knn_host       :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Int32 -> Ptr Int32 -> Ptr Double -> Ptr Int32 -> IO Int32
 -- knnH (RPTree.hs:199-217): two calls, the first with null outputs returns the result size
 foreign import ccall safe "rpt_knnh_host"           c_knnh_host      :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Ptr Int64 -> Ptr Int32 -> Ptr Double -> Int64 -> Ptr Int64 -> IO Int32
 foreign import ccall unsafe "rpt_last_error"        c_last_error     :: IO CString
-foreign import ccall "&rpt_forest_free"             p_forest_free    :: FunPtr (Ptr Forest -> IO ())
-foreign import ccall "&rpt_dataset_free"            p_dataset_free   :: FunPtr (Ptr Dataset -> IO ())
+-- multi-GPU (csrc/comm.hip on librccl): one process drives n devices; per-device arguments are
+-- arrays with one entry per device (Foreign.Marshal.Array.withArray)
+foreign import ccall safe "rpt_comm_init"            c_comm_init      :: Int32 -> Ptr (Ptr Comm) -> IO Int32
+foreign import ccall safe "rpt_comm_destroy"         c_comm_destroy   :: Ptr Comm -> IO Int32
+foreign import ccall safe "rpt_comm_ctx"             c_comm_ctx       :: Ptr Comm -> Int32 -> Ptr (Ptr Ctx) -> IO Int32
+foreign import ccall safe "rpt_forest_build_sharded" c_build_sharded  :: Ptr Comm -> Ptr (Ptr Dataset) -> Ptr Double -> Int32 -> Int32 -> Int32 -> Int32 -> Ptr (Ptr ShardedForest) -> IO Int32
+foreign import ccall safe "rpt_sharded_forest_free"  c_sharded_free   :: Ptr ShardedForest -> IO Int32
+foreign import ccall safe "rpt_knn_sharded"          c_knn_sharded    :: Ptr Comm -> Ptr ShardedForest -> Ptr (Ptr Dataset) -> Ptr (Ptr Dataset) -> Int32 -> Int32 -> Ptr Int32 -> Ptr Double -> Ptr Int32 -> IO Int32
 
 newtype RPTHipError = RPTHipError String deriving Show
 instance Exception RPTHipError          -- next to RPTError (Internal.hs:66-72)
@@ -56,27 +64,34 @@ data FlatForest = FlatForest
   { ffPerm :: VS.Vector Int32, ffThr, ffLo, ffHi :: VS.Vector Double
   , ffN, ffTrees, ffDepth, ffMinLeaf :: Int }
 
--- | Drop-in for 'Data.RPTree.Batch.forestBatch' (Batch.hs:48-63) on dense data.
+-- | Dense-ify one hyperplane in O(d + nnz): zeros where the sparse vector has no component.
+denseOf :: Int -> SVector Double -> VS.Vector Double
+denseOf dim (SV _ vv) = VS.replicate dim 0 VS.// VU.toList vv
+
+-- | Drop-in for 'Data.RPTree.Batch.forestBatch' (Batch.hs:48-63) on dense data.  Everything the
+-- result needs is copied out, so the device objects are released before returning (bracket:
+-- also when a call fails) — nothing is left to finalisers.
 forestBatchHIP :: Word64 -> Int -> Int -> Int -> Double -> Int
                -> V.Vector (Embed DVector Double x)
                -> RPForest Double (V.Vector (Embed DVector Double x))
 forestBatchHIP seed maxd minl ntrees pnz dim src = unsafePerformIO $ do
   -- hyperplanes: sampled by the HOST exactly as Batch.hs:59-61 does
   let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))
-      dense (SV _ vv) = VS.fromList [ maybe 0 id (lookup i (VU.toList vv)) | i <- [0 .. dim - 1] ]
-      rflat = VS.concat [ dense r | rvs <- V.toList rvss, r <- V.toList rvs ]          -- R[T][L][d]
+      rflat = VS.concat [ denseOf dim r | rvs <- V.toList rvss, r <- V.toList rvs ]     -- R[T][L][d]
       xflat = VS.concat [ VS.convert v | Embed (DV v) _ <- V.toList src ]                -- X[N][d]
       n = V.length src
       nodes = 2 ^ maxd - 1
-  ctx <- alloca $ \pp -> c_ctx_create 0 pp >>= check >> peek pp
-  ds  <- alloca $ \pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral n) (fromIntegral dim) 0 pp) >>= check >> peek pp
-  f   <- alloca $ \pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) 0 pp) >>= check >> peek pp
-  perm <- VSM.new (ntrees * n); thr <- VSM.new (ntrees * nodes); lo <- VSM.new (ntrees * nodes); hi <- VSM.new (ntrees * nodes)
-  VSM.unsafeWith perm (c_forest_perm f) >>= check
-  VSM.unsafeWith thr (\a -> VSM.unsafeWith lo (\b -> VSM.unsafeWith hi (c_forest_nodes f a b))) >>= check
-  ff <- FlatForest <$> VS.freeze perm <*> VS.freeze thr <*> VS.freeze lo <*> VS.freeze hi
-                   <*> pure n <*> pure ntrees <*> pure maxd <*> pure minl
-  _ <- newForeignPtr p_forest_free f; _ <- newForeignPtr p_dataset_free ds
+      acquire mk = alloca $ \pp -> mk pp >>= check >> peek pp
+  ff <- bracket (acquire (c_ctx_create 0)) c_ctx_destroy $ \ctx ->
+        bracket (acquire (\pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral n) (fromIntegral dim) 0 pp)))
+                c_dataset_free $ \ds ->
+        bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) 0 pp)))
+                c_forest_free $ \f -> do
+          perm <- VSM.new (ntrees * n); thr <- VSM.new (ntrees * nodes); lo <- VSM.new (ntrees * nodes); hi <- VSM.new (ntrees * nodes)
+          VSM.unsafeWith perm (c_forest_perm f) >>= check
+          VSM.unsafeWith thr (\a -> VSM.unsafeWith lo (\b -> VSM.unsafeWith hi (c_forest_nodes f a b))) >>= check
+          FlatForest <$> VS.freeze perm <*> VS.freeze thr <*> VS.freeze lo <*> VS.freeze hi
+                     <*> pure n <*> pure ntrees <*> pure maxd <*> pure minl
   pure $ IM.fromList [ (t, RPTree (rvss V.! t) (rebuild ff src t)) | t <- [0 .. ntrees - 1] ]
 
 -- | Rebuild the lazy 'RPT' (Internal.hs:139-149) of tree t from the flat arrays: topology is a

@@ -67,6 +67,12 @@ extern "C" {
 #define RPT_KNN_KEEP_DUPLICATES 0 /* the reference: RPTree.hs:174-176 never de-duplicates */
 #define RPT_KNN_DEDUP 1           /* extension: each point id at most once */
 #define RPT_KNN_DEDUP_DISTANCE 2  /* knnPQ (RPTree.hs:181-194): `nub` keeps one entry per DISTANCE */
+/* Voting (the MRPT vote threshold; the reference carries it as the commented-out `counts` /
+ * `keepCounts` sketch, RPTree.hs:464-478): only the points found in at least v of the trees'
+ * candidate lists get a distance; they are taken in ascending id order (the order of
+ * M.foldrWithKey in keepCounts), each once, and the k best by (distance, id) are returned.
+ * Dense data, k <= 64; or-ed into the knn flags: RPT_KNN_VOTE(v), v in [1, 65535]. */
+#define RPT_KNN_VOTE(v) ((int32_t)(v) << 8)
 
 typedef struct rpt_ctx rpt_ctx;
 typedef struct rpt_dataset rpt_dataset;

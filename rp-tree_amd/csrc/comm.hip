@@ -398,7 +398,7 @@ int32_t rpt_knn_sharded_dev(rpt_comm* comm, rpt_sharded_forest* sf,
     RPT_ARG(comm && sf && data && queries && ids_dev && dist_dev && count_dev, "NULL argument");
     RPT_ARG(sf->comm == comm, "forest belongs to another communicator");
     RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
-    RPT_ARG(flags >= 0 && flags <= 2, "unknown knn flags");
+    RPT_ARG(flags >= 0 && flags <= 2, "unknown knn flags (voting is per device: rpt_knn_*)");
     const int64_t nq = queries[0] ? queries[0]->n : -1;
     for (int g = 0; g < comm->nlocal; ++g) {
       RPT_ARG(data[g] && queries[g] && ids_dev[g] && dist_dev[g] && count_dev[g],

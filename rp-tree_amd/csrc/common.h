@@ -127,6 +127,7 @@ struct rpt_options {
   int64_t knn_kp = 0;           // kNN: entries the f32 prefilter keeps (0 = k + max(6, k/2))
   int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
   int64_t knn_general = 0;      // kNN: unfused general path
+  int64_t tune0 = 0, tune1 = 0, tune2 = 0, tune3 = 0;  // experiment hooks (0 = the built-in choice)
   int64_t debug_host = 0;       // stderr: host-side phase times of a build
   int64_t debug_stamps = 0;     // device time stamps of the wave kernel
 };

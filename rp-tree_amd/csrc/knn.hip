@@ -516,13 +516,15 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
 constexpr int kFC = 2048;     // candidates per batch
 constexpr int kFR = 512;      // leaf ranges per query in LDS
 constexpr int kFK = 64;       // largest k served by the arg-min selection
+constexpr int kVoteCap = 16384;  // candidates of one query the voting mode can count (64 KB of LDS)
 
 template <class TD, class TK, bool PRE32>
 __global__ __launch_bounds__(256) void knn_fused_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
     const double* __restrict__ thr, const double* __restrict__ mglo,
     const double* __restrict__ mghi, int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T,
-    int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
+    int L, int min_leaf, int64_t N, int k, int dedup_vote /* duplicate rule | vote threshold << 8 */,
+    int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
     unsigned int* ovf_count, unsigned long long* cand_total,
     const float* __restrict__ Xf /* PRE32: f32 shadow of X */, double xmax /* max row norm */,
@@ -541,11 +543,18 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   int* bpos = bid + kFK;                                           // [kFK]
   TA* qs = reinterpret_cast<TA*>(bpos + kFK);                      // [d]
   float* qs32 = reinterpret_cast<float*>(qs + d);                  // [d] (PRE32)
+  // voting mode (dedup_vote >> 8 = v > 0, RPTree.hs:464-478 counts / keepCounts): all candidate
+  // ids of the query, sorted, so that the ids found in at least v trees can be picked out
+  int* vid = reinterpret_cast<int*>(
+      (reinterpret_cast<uintptr_t>(qs32 + d) + 15) & ~(uintptr_t)15);  // [kVoteCap]
   __shared__ int s_nr, s_nc;
   __shared__ double s_qn;
   __shared__ double s_red_d[8];
   __shared__ int s_red_p[8], s_red_i[8];
   __shared__ unsigned long long s_red64[8];
+  __shared__ int s_wk[4];
+  const int vote = PRE32 ? 0 : (dedup_vote >> 8);
+  const int dedup = vote > 0 ? 0 : (dedup_vote & 3);  // kept ids are distinct
 
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -603,6 +612,42 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
                  });
   }
   __syncthreads();
+
+  // ---- voting mode: every candidate id into LDS, ascending (the order of M.foldrWithKey in
+  // keepCounts); an id found in c trees is a run of c equal entries ----
+  if (vote > 0) {
+    if (nc_tot > kVoteCap) {  // more candidates than the slab counts: reported, not answered
+      if (tid == 0) {
+        ovf_flags[q] = 3u;
+        atomicAdd(ovf_count, 1u);
+      }
+      return;
+    }
+    int pos = 0;
+    for (int r = 0; r < nr_tot; ++r) {  // every thread walks the same range list
+      const int n = rn[r];
+      for (int i = tid; i < n; i += 256) vid[pos + i] = perm[rpoff[r] + i];
+      pos += n;
+    }
+    int np = 1;
+    while (np < nc_tot) np <<= 1;
+    for (int i = nc_tot + tid; i < np; i += 256) vid[i] = 0x7fffffff;
+    __syncthreads();
+    for (int kk = 2; kk <= np; kk <<= 1)
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < (np >> 1); i += 256) {
+          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+          const bool up = (lo & kk) == 0;
+          const int a = vid[lo], b = vid[hi];
+          if (up ? b < a : a < b) {
+            vid[lo] = b;
+            vid[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+  }
+  int vsrc = 0;  // voting mode: next entry of vid to look at
 
   // ---- selection: ksel rounds of block-wide arg-min by (distance, position) over the batch
   // entries [0, fill); the winners go to bdist / bid / bpos.  A thread keeps its eight entries
@@ -723,7 +768,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   int r_next = 0;     // next range to consume
   int r_done = 0;     // candidates of range r_next already consumed
   int pos_base = 0;   // candidate position of the next unconsumed candidate
-  while (r_next < nr_tot || best == 0) {
+  while ((vote > 0 ? vsrc < nc_tot : r_next < nr_tot) || best == 0) {
     // ---- fill the batch: best list first (keeps its positions), then new candidates ----
     for (int i = tid; i < best; i += 256) {
       cdist[i] = bdist[i];
@@ -732,9 +777,33 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     }
     int fill = best;
     const int first_new = fill;
+    // voting mode: the heads of the runs of at least `vote` equal ids, 256 entries of vid per
+    // round, compacted into the batch with their index in vid as position (ascending id order)
+    while (vote > 0 && vsrc < nc_tot && fill + 256 <= kFC) {
+      const int i = vsrc + tid;
+      int keep = 0;
+      if (i < nc_tot && (i == 0 || vid[i] != vid[i - 1])) {
+        int c = 1;
+        while (c < vote && i + c < nc_tot && vid[i + c] == vid[i]) ++c;
+        keep = c >= vote;
+      }
+      const unsigned long long bal = __ballot(keep);
+      if (lane == 0) s_wk[wave] = __popcll(bal);
+      __syncthreads();
+      int base = fill;
+      for (int w = 0; w < wave; ++w) base += s_wk[w];
+      if (keep) {
+        const int slot = base + __popcll(bal & ((1ULL << lane) - 1ULL));
+        cid[slot] = vid[i];
+        cpos[slot] = i;
+      }
+      fill += s_wk[0] + s_wk[1] + s_wk[2] + s_wk[3];
+      vsrc += 256;
+      __syncthreads();  // s_wk is rewritten by the next round
+    }
     // every thread walks the same range list (uniform control flow)
     int rr = r_next, rd = r_done, pb = pos_base;
-    while (rr < nr_tot && fill < kFC) {
+    while (vote == 0 && rr < nr_tot && fill < kFC) {
       int take = rn[rr] - rd;
       if (take > kFC - fill) take = kFC - fill;
       for (int i = tid; i < take; i += 256) {
@@ -763,7 +832,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     __syncthreads();
     const int nb = PRE32 ? select_packed(fill, k1) : pack32 ? select_packed(fill, k) : select(fill, k, dedup);
     best = nb;
-    if (r_next >= nr_tot) break;
+    if (vote > 0 ? vsrc >= nc_tot : r_next >= nr_tot) break;
   }
   if constexpr (PRE32) {
     // ---- refine: exact distances of the entries the f32 pass kept; certify the cut ----
@@ -1471,9 +1540,11 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // small shards (few trees => a few hundred candidates per query): one wave per query
   const int64_t force = ctx->opt.knn_wave;  // -1 auto
   const size_t wbytes = fused_wave_bytes(data->d, sizeof(TA));
+  const int vote = dedup >> 8;  // voting mode: the workgroup kernel, all-exact distances
   bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 &&
               (int64_t)f->T * f->min_leaf <= kWaveCandidates;
   if (force >= 0) wave = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
+  if (vote > 0) wave = false;
   ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
   // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
@@ -1513,7 +1584,8 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
     return RPT_OK;
   }
   const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFK * 16 +
-                      (size_t)data->d * (sizeof(TA) + 4) + 64;
+                      (size_t)data->d * (sizeof(TA) + 4) + 64 +
+                      (vote > 0 ? (size_t)kVoteCap * 4 + 16 : 0);
   if constexpr (std::is_same<TD, double>::value) {
     if (pre32) {
       if (smem > 64 * 1024)
@@ -1590,11 +1662,14 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   RPT_ARG((size_t)data->d * 8 + (sizeof(Entry) + 4) * kBuf <= 150 * 1024, "d too large");
   RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
           "query dtype must have the forest's projection type (f64 vs f32/bf16)");
-  const bool fused = !data->csr && k <= kFK && f->T <= 1024 && !ctx->opt.knn_general &&
+  const int vote = (flags >> 8) & 0xffff;  // RPT_KNN_VOTE(v)
+  const bool fused = !data->csr && k <= kFK && f->T <= 1024 && (!ctx->opt.knn_general || vote > 0) &&
                      (size_t)data->d * 8 <= 32 * 1024;
+  if (vote > 0 && !fused)
+    return fail(RPT_E_UNSUPPORTED, "RPT_KNN_VOTE: dense data, k <= 64 and at most 1024 trees");
   if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
   const int64_t nq = q->n;
-  const int dedup = flags & 3;
+  const int dedup = (flags & 3) | (vote << 8);
   DevBuf<char> Pq;
   // one control block, one memset, one read-back: u64 candidates visited, u64 queries whose
   // prefilter cut was not certified, u32 queries that overflowed the range slab, pad, flags[nq]
@@ -1610,7 +1685,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
   if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !ctx->opt.knn_no_pre32 &&
-      !f->prefilter_off)
+      !f->prefilter_off)  // (dedup carries the vote threshold too: no prefilter when voting)
     RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
@@ -1631,6 +1706,9 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   std::memcpy(tot, hctl, 16);
   ctx->last_candidates = (int64_t)tot[0];
   ctx->last_uncertified = (int64_t)tot[1];
+  if (novf && vote > 0)
+    return fail(RPT_E_UNSUPPORTED,
+                "RPT_KNN_VOTE: a query reaches more than 16384 candidates or 512 leaves");
   if (novf)  // some query reached more leaf ranges than the LDS slab holds: general path
     return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
   if (tot[1] * 4 > (unsigned long long)nq) f->prefilter_off = true;  // not worth it on this forest

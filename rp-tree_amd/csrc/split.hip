@@ -1534,7 +1534,40 @@ struct SNode {  // per (tree, node) of the current streaming level
   int n, nh, pb, cL, cMid, lowb, highb, midoff;
   unsigned int midcur;
   unsigned long long maxL, minR;
+  unsigned long long cthr;  // code mode: the pivot and margin bins as code thresholds (code_thr)
 };
+
+// ---- CODE mode (codes.h): hist bins (TK)code with the ordinary geometry (stream_geom /
+// stream_bin); stream_assign gets the pivot and margin bins as CODE THRESHOLDS, found by
+// inverting the monotone bin function with a binary search over the 65536 codes — exactly
+// consistent with the histogram by construction.  Packed into 4 x 16 bits:
+//   [0] T_lo: codes below go left        [1] T_hi: codes above go right   (pivot bin = [T_lo, T_hi])
+//   [2] E_lo: codes in [E_lo, T_lo) lie in the nearest non-empty bin below the pivot bin (the
+//       bins in between are empty) — tracked for the low margin; 0xffff: not needed
+//   [3] E_hi: codes in (T_hi, E_hi] lie in the nearest non-empty bin above; 0: not needed
+template <class TK>
+__device__ inline int stream_bin(TK key, TK lo, TK scale, int B);
+template <class TK>
+__device__ inline unsigned long long code_thr(TK lo, TK scale, int B, int pb, int lowb /* < 0: none */,
+                                              int highb /* >= B: none */) {
+  auto first_ge = [&](int p) -> int {  // smallest code whose bin is >= p (65536: none)
+    if (p <= 0) return 0;
+    int a = 0, b = 65536;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (stream_bin((TK)m, lo, scale, B) >= p) b = m;
+      else a = m + 1;
+    }
+    return a;
+  };
+  const int f0 = first_ge(pb);
+  const unsigned long long tlo = (unsigned long long)(f0 > 65535 ? 65535 : f0);
+  const unsigned long long thi = pb >= B - 1 ? 65535ULL : (unsigned long long)(first_ge(pb + 1) - 1);
+  const unsigned long long elo = lowb < 0 ? 0xffffULL : (unsigned long long)first_ge(lowb);
+  const unsigned long long ehi =
+      highb >= B ? 0ULL : (highb >= B - 1 ? 65535ULL : (unsigned long long)(first_ge(highb + 1) - 1));
+  return tlo | (thi << 16) | ((elo > 65535 ? 65535ULL : elo) << 32) | (ehi << 48);
+}
 
 // value bins per node of a streaming level: the 32768 LDS counters are split over the M nodes.
 // Nodes of up to ~2M points keep at most 4096 bins (one stream_pick block scans them); larger
@@ -1654,23 +1687,24 @@ __global__ __launch_bounds__(kStreamThreads) void stream_hist(
   typedef TK key2_t __attribute__((ext_vector_type(2)));
   if (Cd) {  // code mode: 4 bytes per point; eight points per thread and step (16-byte loads)
     const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
+    auto onec = [&](unsigned int j, unsigned int code) { one((int)j, (TK)code); };
     if (((N | i0 | per) & 7) == 0) {
       const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)7);
       for (int64_t i = i0 + 8 * (int64_t)threadIdx.x; i < ie; i += 8 * kStreamThreads) {
         const uint4 jj = *reinterpret_cast<const uint4*>(no + i);
         const uint4 cc = *reinterpret_cast<const uint4*>(Cl + i);
-        one((int)(jj.x & 0xffffu), (TK)(cc.x & 0xffffu));
-        one((int)(jj.x >> 16), (TK)(cc.x >> 16));
-        one((int)(jj.y & 0xffffu), (TK)(cc.y & 0xffffu));
-        one((int)(jj.y >> 16), (TK)(cc.y >> 16));
-        one((int)(jj.z & 0xffffu), (TK)(cc.z & 0xffffu));
-        one((int)(jj.z >> 16), (TK)(cc.z >> 16));
-        one((int)(jj.w & 0xffffu), (TK)(cc.w & 0xffffu));
-        one((int)(jj.w >> 16), (TK)(cc.w >> 16));
+        onec(jj.x & 0xffffu, cc.x & 0xffffu);
+        onec(jj.x >> 16, cc.x >> 16);
+        onec(jj.y & 0xffffu, cc.y & 0xffffu);
+        onec(jj.y >> 16, cc.y >> 16);
+        onec(jj.z & 0xffffu, cc.z & 0xffffu);
+        onec(jj.z >> 16, cc.z >> 16);
+        onec(jj.w & 0xffffu, cc.w & 0xffffu);
+        onec(jj.w >> 16, cc.w >> 16);
       }
-      for (int64_t i = ie + threadIdx.x; i < i1; i += kStreamThreads) one(no[i], (TK)Cl[i]);
+      for (int64_t i = ie + threadIdx.x; i < i1; i += kStreamThreads) onec(no[i], Cl[i]);
     } else {
-      for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) one(no[i], (TK)Cl[i]);
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) onec(no[i], Cl[i]);
     }
   } else if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {  // 16-byte key loads, 4-byte node loads
     const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)1);
@@ -1733,7 +1767,8 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
                                                    unsigned int* __restrict__ poolcur,
                                                    unsigned long long* __restrict__ cmin_next,
                                                    unsigned long long* __restrict__ cmax_next,
-                                                   unsigned int* __restrict__ bigmid) {
+                                                   unsigned int* __restrict__ bigmid,
+                                                   int code_mode) {
   constexpr int NPB = 256 / G, B = G * BPT, W = G < 64 ? G : 64, WPG = G / W;  // waves per group
   __shared__ unsigned int wtot[4];
   __shared__ int s_pb[NPB], s_cL[NPB], s_cMid[NPB], s_low[NPB], s_high[NPB];
@@ -1820,6 +1855,8 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
     a.cMid = cMid;
     a.lowb = need_lo ? s_low[g] : -2;
     a.highb = need_hi ? s_high[g] : B + 1;
+    a.cthr = code_mode ? code_thr<TK>(a.lo, a.scale, B, pb, need_lo ? s_low[g] : -1, need_hi ? s_high[g] : B)
+                       : 0ULL;
     a.midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
     a.midcur = 0;
     a.maxL = 0ULL;
@@ -1862,7 +1899,8 @@ __global__ __launch_bounds__(256) void stream_pick_big(int64_t N, int level, int
                                                        unsigned int* __restrict__ poolcur,
                                                        unsigned long long* __restrict__ cmin_next,
                                                        unsigned long long* __restrict__ cmax_next,
-                                                       unsigned int* __restrict__ bigmid) {
+                                                       unsigned int* __restrict__ bigmid,
+                                                       int code_mode) {
   __shared__ unsigned int wtot[4];
   __shared__ int s_owner, s_pb, s_cL, s_cMid, s_low, s_high;
   const int j = blockIdx.x, t = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1945,6 +1983,8 @@ __global__ __launch_bounds__(256) void stream_pick_big(int64_t N, int level, int
     a.cMid = cMid;
     a.lowb = need_lo ? s_low : -2;
     a.highb = need_hi ? s_high : B + 1;
+    a.cthr = code_mode ? code_thr<TK>(a.lo, a.scale, B, pb, need_lo ? s_low : -1, need_hi ? s_high : B)
+                       : 0ULL;
     a.midoff = (int)atomicAdd(&poolcur[t], (unsigned int)cMid);
     a.midcur = 0;
     a.maxL = 0ULL;
@@ -1970,9 +2010,14 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   __shared__ unsigned long long smin[2 * kStreamMaxNodes], smax[2 * kStreamMaxNodes];
   const int t = blockIdx.y;
   SNode<TK>* ndt = nd + (int64_t)t * M;
+  unsigned long long* cth = reinterpret_cast<unsigned long long*>(ngeo);  // code mode: code_thr
   for (int j = threadIdx.x; j < M; j += kStreamThreads) {
-    ngeo[j] = AGeom<TK>{ndt[j].lo, ndt[j].scale};
-    nbin[j] = ABins{ndt[j].pb, ndt[j].lowb, ndt[j].highb, 0};
+    if (Cd) {
+      cth[j] = ndt[j].cthr;
+    } else {
+      ngeo[j] = AGeom<TK>{ndt[j].lo, ndt[j].scale};
+      nbin[j] = ABins{ndt[j].pb, ndt[j].lowb, ndt[j].highb, 0};
+    }
     nmidoff[j] = ndt[j].midoff;
   }
   for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
@@ -1990,7 +2035,9 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   // The children's min/max of the NEXT level's key only shape that level's bins (keys outside
   // the range are clamped into the edge bins), so a sample is enough: the first quarter of the
   // block's points — every point while nodes are small.
-  const int64_t isamp = (N >> level) < 1024 ? i1 : (i0 + ((i1 - i0 + 3) >> 2) + 7) & ~(int64_t)7;
+  // (measured: the sampling — LDS min/max atomics — is the expensive part of this kernel; an
+  // eighth of the points, and 32-bit atomics on the codes themselves in code mode)
+  const int64_t isamp = (N >> level) < 1024 ? i1 : (i0 + ((i1 - i0 + 7) >> 3) + 7) & ~(int64_t)7;
   // few nodes: a per-thread running min/max per child avoids hammering one LDS word
   const bool few = M <= 4;
   unsigned long long tmn[8], tmx[8];
@@ -2037,11 +2084,50 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   if (Cd) {  // code mode: eight points per thread and step, 16-byte code and node loads / stores
     const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
     const uint16_t* Cn = has_next ? Cl + N : Cl;
+    // one 8-byte LDS word per point (code_thr) and integer compares; the exact key is read only
+    // for the pivot bin and the two margin bins
+    auto classc = [&](int64_t i, unsigned int j, unsigned int code) -> int {
+      const unsigned long long th = cth[j];
+      const unsigned int tlo = (unsigned int)th & 0xffffu, thi = (unsigned int)(th >> 16) & 0xffffu;
+      if (code < tlo) {
+        if (code >= ((unsigned int)(th >> 32) & 0xffffu)) atomicMax(&ndt[j].maxL, ord_of(Pl[i]));
+        return (int)(2 * j);
+      }
+      if (code > thi) {
+        if (code <= (unsigned int)(th >> 48)) atomicMin(&ndt[j].minR, ord_of(Pl[i]));
+        return (int)(2 * j + 1);
+      }
+      const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
+      pl[nmidoff[j] + p] = (int32_t)i;
+      pk[nmidoff[j] + p] = Pl[i];
+      return -1;
+    };
+    unsigned int* smin32 = reinterpret_cast<unsigned int*>(smin);  // [2M], all ones / zero like
+    unsigned int* smax32 = reinterpret_cast<unsigned int*>(smax);  // the 64-bit cells they overlay
+    unsigned int cmn[8], cmx[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      cmn[c] = 0xffffffffu;
+      cmx[c] = 0u;
+    }
+    auto samplec = [&](int child, unsigned int code) {
+      if (few) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c == child) {
+            cmn[c] = code < cmn[c] ? code : cmn[c];
+            cmx[c] = code > cmx[c] ? code : cmx[c];
+          }
+      } else {
+        atomicMin(&smin32[child], code);
+        atomicMax(&smax32[child], code);
+      }
+    };
     auto one = [&](int64_t i) {
-      const int c = classify(i, no[i], (TK)Cl[i]);
+      const int c = classc(i, no[i], Cl[i]);
       if (c >= 0) {
         no[i] = (uint16_t)c;
-        if (has_next && i < isamp) sample(c, (TK)Cn[i]);
+        if (has_next && i < isamp) samplec(c, Cn[i]);
       }
     };
     if (((N | i0 | per) & 7) == 0) {
@@ -2054,12 +2140,12 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
         unsigned int ow[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          const int ja = (int)(jw[w] & 0xffffu), jb = (int)(jw[w] >> 16);
-          ch[2 * w] = classify(i + 2 * w, ja, (TK)(cw[w] & 0xffffu));
-          ch[2 * w + 1] = classify(i + 2 * w + 1, jb, (TK)(cw[w] >> 16));
+          const unsigned int ja = jw[w] & 0xffffu, jb = jw[w] >> 16;
+          ch[2 * w] = classc(i + 2 * w, ja, cw[w] & 0xffffu);
+          ch[2 * w + 1] = classc(i + 2 * w + 1, jb, cw[w] >> 16);
           // a pivot-bin point keeps its node until stream_mid has ordered the bin
-          ow[w] = (unsigned int)(ch[2 * w] >= 0 ? ch[2 * w] : ja) |
-                  ((unsigned int)(ch[2 * w + 1] >= 0 ? ch[2 * w + 1] : jb) << 16);
+          ow[w] = (ch[2 * w] >= 0 ? (unsigned int)ch[2 * w] : ja) |
+                  ((ch[2 * w + 1] >= 0 ? (unsigned int)ch[2 * w + 1] : jb) << 16);
         }
         *reinterpret_cast<uint4*>(no + i) = uint4{ow[0], ow[1], ow[2], ow[3]};
         if (has_next && i < isamp) {
@@ -2067,8 +2153,8 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
           const unsigned int nw[4] = {nn.x, nn.y, nn.z, nn.w};
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
-            if (ch[2 * w] >= 0) sample(ch[2 * w], (TK)(nw[w] & 0xffffu));
-            if (ch[2 * w + 1] >= 0) sample(ch[2 * w + 1], (TK)(nw[w] >> 16));
+            if (ch[2 * w] >= 0) samplec(ch[2 * w], nw[w] & 0xffffu);
+            if (ch[2 * w + 1] >= 0) samplec(ch[2 * w + 1], nw[w] >> 16);
           }
         }
       }
@@ -2076,6 +2162,31 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     } else {
       for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) one(i);
     }
+    // flush: children this block sampled -> the next level's code range (as keys: ord_of((TK)code))
+    if (has_next && few) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c >= 2 * M) break;
+        unsigned int mn = cmn[c], mx = cmx[c];
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned int a = __shfl_xor(mn, o), b2 = __shfl_xor(mx, o);
+          mn = a < mn ? a : mn;
+          mx = b2 > mx ? b2 : mx;
+        }
+        if ((threadIdx.x & 63) == 0 && mn != 0xffffffffu) {
+          atomicMin(&smin32[c], mn);
+          atomicMax(&smax32[c], mx);
+        }
+      }
+    }
+    __syncthreads();
+    if (has_next)
+      for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads)
+        if (smin32[c] != 0xffffffffu) {
+          atomicMin(&cmin_next[(int64_t)t * 2 * M + c], ord_of((TK)smin32[c]));
+          atomicMax(&cmax_next[(int64_t)t * 2 * M + c], ord_of((TK)smax32[c]));
+        }
+    return;
   } else if (((N | i0 | per) & 1) == 0 && sizeof(TK) == 8) {
     const int64_t ie = i0 + ((i1 - i0) & ~(int64_t)1);
     for (int64_t i = i0 + 2 * (int64_t)threadIdx.x; i < ie; i += 2 * kStreamThreads) {
@@ -3102,7 +3213,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     const int64_t per = (((N + nblk - 1) / nblk) + 7) & ~(int64_t)7;  // multiple of 8, <= 65534
     const dim3 sgrid((unsigned)nblk, (unsigned)T);
     // assign pass: no per-block table to flush, fill the chip
-    int64_t nblkA = (4 * (int64_t)ctx->n_cu + T - 1) / T;
+    const int64_t afac = ctx->opt.tune0 > 0 ? ctx->opt.tune0 : 2;
+    int64_t nblkA = (afac * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblkA > (N + 8191) / 8192) nblkA = (N + 8191) / 8192;
     if (nblkA < 1) nblkA = 1;
     const int64_t perA = (((N + nblkA - 1) / nblkA) + 7) & ~(int64_t)7;  // 16-byte key / code loads
@@ -3143,7 +3255,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   hipLaunchKernelGGL((stream_pick<TK, BPT, G>), dim3((unsigned)((M + 256 / G - 1) / (256 / G)), \
                                                       (unsigned)T),                            \
                      dim3(256), 0, st, N, level, M, (int)nblk, part.p, cmin, cmax, snodes.p, pc, \
-                     cminN, cmaxN, sflags.p)
+                     cminN, cmaxN, sflags.p, Cs ? 1 : 0)
         switch (B) {
           case 4096: RPT_PICK(16, 256); break;
           case 2048: RPT_PICK(8, 256); break;
@@ -3159,7 +3271,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
                                dim3(256), 0, st, M * B / 2, (int)nblk, part.p, totals.p);
             hipLaunchKernelGGL(stream_pick_big<TK>, dim3((unsigned)M, (unsigned)T), dim3(256), 0, st,
                                N, level, M, B, totals.p, cmin, cmax, snodes.p, pc, cminN, cmaxN,
-                               sflags.p);
+                               sflags.p, Cs ? 1 : 0);
           }
         }
 #undef RPT_PICK

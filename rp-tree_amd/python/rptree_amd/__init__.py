@@ -606,10 +606,12 @@ def candidatesBatch(forest, qs):
     return off, ids[:total.value]
 
 
-def knnBatch(k, forest, qs, dedup=False):
+def knnBatch(k, forest, qs, dedup=False, vote=0):
     """knn for a batch of queries -> (ids[nq][k], dist[nq][k], count[nq]).
     dedup: False = the reference's knn (duplicates kept), True = each id once,
-    RPT_KNN_DEDUP_DISTANCE = knnPQ's `nub` (one entry per distance)."""
+    RPT_KNN_DEDUP_DISTANCE = knnPQ's `nub` (one entry per distance).
+    vote = v > 0: only points found by at least v trees are ranked (RPT_KNN_VOTE; the
+    reference's commented-out counts / keepCounts, RPTree.hs:464-478), ties by ascending id."""
     ctx = forest.ctx
     qd, nq = _query_dataset(ctx, forest.data, qs)
     ids = np.empty((nq, k), dtype=np.int32)
@@ -617,6 +619,7 @@ def knnBatch(k, forest, qs, dedup=False):
     cnt = np.empty(nq, dtype=np.int32)
     flags = (RPT_KNN_DEDUP_DISTANCE if dedup == RPT_KNN_DEDUP_DISTANCE
              else RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES)
+    flags |= int(vote) << 8                       # RPT_KNN_VOTE(v)
     check(lib().rpt_knn_host(ctx._h, forest._h, forest.data._h, qd._h, int(k), flags, _vp(ids),
                              _vp(dist), _vp(cnt)))
     return ids, dist, cnt

@@ -231,6 +231,45 @@ def test_streaming_on_16bit_codes_is_exact(rp, ctx, oracle, kind, mode):
             assert np.array_equal(getattr(f, name), getattr(fo, name), equal_nan=True), name
 
 
+# --------------------------------------------------------------------------- voting (8f-4)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_knn_vote_matches_keep_counts(rp, ctx, oracle, dtype):
+    """RPT_KNN_VOTE(v): distances only for the points found by at least v trees (counts /
+    keepCounts, RPTree.hs:464-478, restated in the oracle), ascending id order, k best by
+    (distance, id).  v = 1 is 'each candidate once'; a threshold no point reaches gives nothing."""
+    n, d, T, ml, k = 40000, 20, 12, 60, 10
+    X = oracle.data_normal_dense2(11, n, d)
+    Q = X[:200] * 1.002 + 0.004
+    if dtype == "f32":
+        X, Q = X.astype(np.float32), Q.astype(np.float32)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(13, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    ff = oracle.Forest(n, d, R, L, ml, f.perm, f.thr, f.mglo, f.mghi)   # the device's own forest
+    kept_any = 0
+    for v in (1, 2, 3, 6, T, T + 1):
+        ids, dist, cnt = rp.knnBatch(k, f, Q, vote=v)
+        wi, wd, wc = oracle.knn_dense_batch(ff, X, Q.astype(np.float64), k, vote_thr=v, threads=4)
+        if dtype == "f64":
+            assert np.array_equal(cnt, wc) and np.array_equal(ids, wi), v
+            assert np.allclose(dist, wd, rtol=1e-12)
+        else:   # f32 distances: ids wherever the oracle's distances are separated
+            assert np.array_equal(cnt, wc), v
+            for i in range(len(Q)):
+                m = wc[i]
+                if m > 1 and (np.diff(wd[i, :m]) <= 1e-5 * wd[i, 1:m]).any():
+                    continue
+                assert np.array_equal(ids[i, :m], wi[i, :m]), (v, i)
+        kept_any += int(wc.sum() > 0)
+        if v == T + 1:
+            assert (cnt == 0).all() and (ids == -1).all()
+    assert kept_any >= 5
+    # every id is returned once; fewer trees agree on far points: counts shrink with v
+    c1 = rp.knnBatch(k, f, Q, vote=1)[2]
+    c6 = rp.knnBatch(k, f, Q, vote=6)[2]
+    assert (c6 <= c1).all()
+
+
 # --------------------------------------------------------------------------- import (8f-1)
 def test_import_of_an_oracle_built_forest(rp, ctx, case, oracle):
     """rpt_forest_import fed with arrays the DEVICE never produced (the oracle's = what a Haskell
