@@ -755,6 +755,9 @@ __global__ __launch_bounds__(kSubThreads) void subtree_kernel(
 // the host re-runs those nodes with subtree_kernel.
 // grid = ceil(S*T/4) blocks of 256 threads.
 // ---------------------------------------------------------------------------------------
+// (measured, round 2: feeding the wave kernel ONE gathered word per point — the 16-bit codes of
+// its three levels packed by a 0.1 ms pass — instead of a gathered key per point and level changes
+// nothing, 1.28 ms either way at C2: the kernel waits on its LDS phases, not on the gathers.)
 constexpr int kWCap = 1024;
 constexpr int kWE = kWCap / 64;   // points per lane
 constexpr int kWRmax = 5;         // levels per launch (<= 16 nodes at the deepest depth)
@@ -1524,6 +1527,8 @@ __global__ __launch_bounds__(256) void mid_kernel(int32_t* __restrict__ dst, int
 // streaming path at that level (the gather path has the general fallbacks).
 // ---------------------------------------------------------------------------------------
 constexpr int kStreamMaxNodes = 1024;
+// (measured, round 2: 65536 bins — 128 KB of LDS, one block per CU — halve the pivot bins, and what
+// stream_assign / stream_mid gain (-0.2 ms per C2 build) stream_hist / stream_pick lose)
 constexpr int kStreamBins = 32768;      // histogram entries per block: 16-bit counters packed
                                         // two per LDS word (64 KB); a block sees < 65536 points
 constexpr int kStreamThreads = 1024;
