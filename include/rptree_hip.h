@@ -126,6 +126,11 @@ int32_t rpt_dataset_dense_dev(rpt_ctx* ctx, const void* X_dev, int64_t n, int32_
 int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int32_t* col_host,
                              const void* val_host, int64_t n, int32_t d, int32_t dtype,
                              rpt_dataset** out);
+/* borrow CSR arrays that already live in HBM (they must outlive the handle; NOT validated:
+ * rowptr non-decreasing from 0 to nnz, every column index in [0, d), as the host variant checks) */
+int32_t rpt_dataset_csr_dev(rpt_ctx* ctx, const int64_t* rowptr_dev, const int32_t* col_dev,
+                            const void* val_dev, int64_t n, int32_t d, int32_t dtype, int64_t nnz,
+                            rpt_dataset** out);
 int32_t rpt_dataset_free(rpt_dataset* ds);
 int32_t rpt_dataset_info(const rpt_dataset* ds, int64_t* n, int32_t* d, int32_t* dtype,
                          int32_t* is_csr, int64_t* nnz);

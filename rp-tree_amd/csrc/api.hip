@@ -557,11 +557,43 @@ int32_t rpt_dataset_csr_host(rpt_ctx* ctx, const int64_t* rowptr_host, const int
   });
 }
 
+int32_t rpt_dataset_csr_dev(rpt_ctx* ctx, const int64_t* rowptr_dev, const int32_t* col_dev,
+                            const void* val_dev, int64_t n, int32_t d, int32_t dtype, int64_t nnz,
+                            rpt_dataset** out) {
+  return guarded([&]() -> int32_t {
+    if (ctx) dev_set_stream(ctx->stream);
+    RPT_ARG(ctx && out, "NULL argument");
+    *out = nullptr;
+    RPT_TRY(check_dtype(dtype));
+    RPT_ARG(dtype != RPT_BF16, "CSR datasets are f64 or f32");
+    RPT_ARG(n >= 0 && d >= 1 && nnz >= 0 && rowptr_dev, "bad CSR arguments");
+    RPT_ARG(n < (int64_t)0x7fffffff, "n must fit int32 point ids");
+    RPT_ARG(nnz == 0 || (col_dev && val_dev), "col/val NULL");
+    // borrowed device arrays are NOT validated (that would be a pass over them): rowptr must be
+    // non-decreasing from 0 to nnz and every column index in [0, d), as rpt_dataset_csr_host checks
+    rpt_dataset* ds = new (std::nothrow) rpt_dataset();
+    if (!ds) return fail(RPT_E_NOMEM, "out of host memory");
+    ds->ctx = ctx;
+    ds->n = n;
+    ds->d = d;
+    ds->dtype = dtype;
+    ds->csr = true;
+    ds->owns = false;
+    ds->nnz = nnz;
+    ds->rowptr = const_cast<int64_t*>(rowptr_dev);
+    ds->col = const_cast<int32_t*>(col_dev);
+    ds->val = const_cast<void*>(val_dev);
+    *out = ds;
+    return RPT_OK;
+  });
+}
+
 int32_t rpt_dataset_free(rpt_dataset* ds) {
   return guarded([&]() -> int32_t {
     if (ds) dev_set_stream(ds->ctx->stream);
     if (!ds) return RPT_OK;
     if (ds->shadow32) dev_free(ds->shadow32);
+    if (ds->csr_split) dev_free(ds->csr_split);
     if (ds->owns) {
       (void)hipSetDevice(ds->ctx->device);
       (void)stream_sync(ds->ctx->stream);

@@ -188,6 +188,10 @@ struct rpt_dataset {
   // candidates on it before it computes exact distances of the survivors) and the largest row norm
   mutable float* shadow32 = nullptr;
   mutable double max_norm = -1.0;
+  // lazily built by the first projection of a CSR dataset whose hyperplane tile does not fit LDS
+  // whole: index of every row's first nonzero with column >= csr_split_k (project.hip)
+  mutable int64_t* csr_split = nullptr;
+  mutable int csr_split_k = -1;
 };
 
 struct rpt_forest {

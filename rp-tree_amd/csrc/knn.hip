@@ -503,6 +503,67 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
   }
 }
 
+// CSR data for the fused kernel (SVector rows, Internal.hs:92-93): data rows and query rows
+struct CsrPtrs {
+  const int64_t* rowptr;
+  const int32_t* col;
+  const void* val;
+  const int64_t* qrowptr;
+  const int32_t* qcol;
+  const void* qval;
+};
+
+// distances of the CSR candidates [first, fill) of an LDS batch to the dense-ified query qs:
+// true Euclidean distance |q|^2 + sum over the row's nonzeros of ((x_j - q_j)^2 - q_j^2), the
+// arithmetic of topk_csr_kernel (sixteen lanes per row, lane-strided nonzeros, fixed butterfly),
+// but with SIXTEEN rows of a wave in flight (four row slots per lane group): the walk of a row
+// is a chain of dependent loads (id -> rowptr -> col / val -> qs[col]) and four rows per wave
+// left the kernel latency-bound.
+template <class TD>
+__device__ __forceinline__ void batch_distances_csr(const int64_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col,
+                                                    const TD* __restrict__ val, const int* cid,
+                                                    double* cdist, const double* qs, double qn2,
+                                                    int first, int fill, int wave, int lane) {
+  constexpr int U = 4;
+  const int grp = lane >> 4, l16 = lane & 15;
+  for (int i0 = first + wave * 4 * U; i0 < fill; i0 += 4 * 4 * U) {
+    int64_t j[U], rb[U];
+    double s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 4 + grp;
+      const bool ok = i < fill;
+      const int id = cid[ok ? i : first];
+      const int64_t ra = rowptr[id];
+      rb[u] = ok ? rowptr[id + 1] : ra;
+      j[u] = ra + l16;
+      s[u] = 0.0;
+    }
+    bool more = true;
+    while (more) {
+      more = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j[u] < rb[u]) {
+          const double qj = qs[col[j[u]]];
+          const double df = (double)val[j[u]] - qj;
+          s[u] += df * df - qj * qj;
+          j[u] += 16;
+          more = more || j[u] < rb[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double t = s[u];
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);  // fixed butterfly inside the group
+      t += qn2;
+      const int i = i0 + u * 4 + grp;
+      if (l16 == 0 && i < fill) cdist[i] = sqrt(t > 0 ? t : 0.0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // fused query kernel (dense data): one workgroup per query does everything after the query
 // projections — traversal of every tree (thread = tree, twice: count, then emit ranges in
@@ -518,7 +579,7 @@ constexpr int kFR = 512;      // leaf ranges per query in LDS
 constexpr int kFK = 64;       // largest k served by the arg-min selection
 constexpr int kVoteCap = 16384;  // candidates of one query the voting mode can count (64 KB of LDS)
 
-template <class TD, class TK, bool PRE32>
+template <class TD, class TK, bool PRE32, bool CSR = false>
 __global__ __launch_bounds__(256) void knn_fused_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
     const double* __restrict__ thr, const double* __restrict__ mglo,
@@ -528,7 +589,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
     unsigned int* ovf_count, unsigned long long* cand_total,
     const float* __restrict__ Xf /* PRE32: f32 shadow of X */, double xmax /* max row norm */,
-    int k1 /* PRE32: entries kept by the f32 pass, the last one = the first excluded */) {
+    int k1 /* PRE32: entries kept by the f32 pass, the last one = the first excluded */,
+    CsrPtrs csr /* CSR: X / Q are null, rows and queries are SVectors */) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* cdist = reinterpret_cast<double*>(smem);                 // [kFC]
@@ -562,10 +624,27 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   if (rerun && ovf_flags[q] != 2u) return;
   // f32 / bf16 data with duplicates kept: the distances are f32 values, so the squared distance is
   // ranked through the packed key as well and the root is taken once, on output (same bits)
-  const bool pack32 = !PRE32 && sizeof(TA) == 4 && dedup == 0;
-  for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
-  if (PRE32)
-    for (int j = tid; j < d; j += 256) qs32[j] = (float)ld<TD>(Q + q * d + j);
+  const bool pack32 = !PRE32 && !CSR && sizeof(TA) == 4 && dedup == 0;
+  double* qsd = reinterpret_cast<double*>(qs);  // CSR: the dense-ified query, d doubles (the
+                                                // slab holds d * (sizeof(TA) + 4) >= 8 d bytes)
+  if constexpr (CSR) {
+    for (int j = tid; j < d; j += 256) qsd[j] = 0.0;
+    __syncthreads();
+    const TD* qv = static_cast<const TD*>(csr.qval);
+    for (int64_t j = csr.qrowptr[q] + tid; j < csr.qrowptr[q + 1]; j += 256)
+      qsd[csr.qcol[j]] = (double)qv[j];
+    __syncthreads();
+    if (wave == 0) {
+      double sq = 0.0;
+      for (int j = lane; j < d; j += 64) sq += qsd[j] * qsd[j];
+      sq = wave_sum(sq);
+      if (lane == 0) s_qn = sq;  // |q|^2 (the dense variants keep |q| here, PRE32 only)
+    }
+  } else {
+    for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
+    if (PRE32)
+      for (int j = tid; j < d; j += 256) qs32[j] = (float)ld<TD>(Q + q * d + j);
+  }
 
   // ---- traversal 1: counts per tree ----
   for (int t = tid; t < T; t += 256) {
@@ -823,7 +902,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     pos_base = pb;
     __syncthreads();
     // ---- distances of the new candidates ----
-    if constexpr (PRE32)
+    if constexpr (CSR)
+      batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), cid, cdist, qsd,
+                              s_qn, first_new, fill, wave, lane);
+    else if constexpr (PRE32)
       batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
     else if (pack32)
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8), false>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
@@ -1544,7 +1626,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 &&
               (int64_t)f->T * f->min_leaf <= kWaveCandidates;
   if (force >= 0) wave = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
-  if (vote > 0) wave = false;
+  if (vote > 0 || data->csr) wave = false;
   ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
   // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
@@ -1553,7 +1635,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // per 10 000 queries at C2), too few and cuts fail their certificate (re-run per query): k + 6
   // certifies 10 000 of 10 000 C2 queries
   const int kp = kp_env > k && kp_env < kFK ? kp_env : prefilter_keep(k);
-  const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
+  const bool pre32 = std::is_same<TD, double>::value && !data->csr && dedup == 0 && kp + 1 <= kFK &&
                      !ctx->opt.knn_no_pre32 && data->shadow32 && !rerun && !f->prefilter_off;
   if (wave) {
     const size_t smem = 4 * wbytes;
@@ -1595,7 +1677,22 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                          ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                          f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                          f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                         (const float*)data->shadow32, data->max_norm, kp + 1);
+                         (const float*)data->shadow32, data->max_norm, kp + 1, CsrPtrs{});
+      RPT_HIP(hipGetLastError());
+      return RPT_OK;
+    }
+  }
+  if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
+    if (data->csr) {  // SVector rows: the same kernel, distances over CSR rows
+      const CsrPtrs cp{data->rowptr, data->col, data->val, q->rowptr, q->col, q->val};
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL((knn_fused_kernel<TD, TK, false, true>), dim3((unsigned)q->n), dim3(256),
+                         smem, ctx->stream, (const TD*)nullptr, data->d, (const TD*)nullptr,
+                         f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n,
+                         f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf,
+                         cand_total, (const float*)nullptr, 0.0, rerun ? -1 : 0, cp);
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -1607,7 +1704,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                      ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                      f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                      f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                     (const float*)nullptr, 0.0, rerun ? -1 : 0);
+                     (const float*)nullptr, 0.0, rerun ? -1 : 0, CsrPtrs{});
   RPT_HIP(hipGetLastError());
   return RPT_OK;
 }
@@ -1663,9 +1760,9 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
           "query dtype must have the forest's projection type (f64 vs f32/bf16)");
   const int vote = (flags >> 8) & 0xffff;  // RPT_KNN_VOTE(v)
-  const bool fused = !data->csr && k <= kFK && f->T <= 1024 && (!ctx->opt.knn_general || vote > 0) &&
+  const bool fused = k <= kFK && f->T <= 1024 && (!ctx->opt.knn_general || vote > 0) &&
                      (size_t)data->d * 8 <= 32 * 1024;
-  if (vote > 0 && !fused)
+  if (vote > 0 && (!fused || data->csr))
     return fail(RPT_E_UNSUPPORTED, "RPT_KNN_VOTE: dense data, k <= 64 and at most 1024 trees");
   if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
   const int64_t nq = q->n;
@@ -1684,7 +1781,8 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
-  if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !ctx->opt.knn_no_pre32 &&
+  if (f->pdtype == RPT_F64 && !data->csr && dedup == 0 && prefilter_keep(k) < kFK &&
+      !ctx->opt.knn_no_pre32 &&
       !f->prefilter_off)  // (dedup carries the vote threshold too: no prefilter when voting)
     RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
   auto launch = [&](bool rerun) -> int32_t {

@@ -1038,6 +1038,118 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// CSR, 32 hyperplanes per pass: the same scheme with EIGHT hyperplanes per lane (four lanes per
+// row), so the CSR arrays are read once per 32 hyperplanes instead of once per 16 — the CSR
+// bytes are what the 16-column kernel moves (C3: 1.79 GB per launch against 0.13 GB of output).
+// The tile Rt[k][32] of a column range [k_lo, k_hi) lives in LDS (row stride 34).  When all d
+// rows fit (f32 up to d ~ 1000, f64 up to d ~ 540) one launch does everything; otherwise the
+// columns are cut in two halves and a pass is TWO launches: the first walks every row's nonzeros
+// with column >= k_mid (CSR columns ascend, so that is the tail [split, end) of the row, found
+// once per dataset), from the last to the first, and leaves the partial sums in P; the second
+// starts from those sums and walks the head [begin, split).  Together they perform exactly the
+// reference's right-nested sum (Internal.hs:353-366), in the same order, so P is bit-identical;
+// each launch reads half of the CSR arrays.
+// ---------------------------------------------------------------------------------------
+constexpr int kCsrLd32 = 34;
+
+template <class T, int U, int E>
+__device__ inline void csr_term8(const int (&mycol)[4], const T (&myval)[4], const T* rl, int q,
+                                 int k_lo, T (&acc)[8]) {
+  const int cu = quad_bcast<U>(mycol[E]);
+  const T vu = quad_bcast<U>(myval[E]);
+  const T* r = rl + (cu - k_lo) * kCsrLd32 + 8 * q;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = add_rn(mul_rn(vu, r[k]), acc[k]);
+}
+template <class T, int I>
+__device__ inline void csr_batch8(const int (&mycol)[4], const T (&myval)[4], const T* rl, int q,
+                                  int k_lo, T (&acc)[8]) {
+  csr_term8<T, I / 4, I % 4>(mycol, myval, rl, q, k_lo, acc);
+  if constexpr (I > 0) csr_batch8<T, I - 1>(mycol, myval, rl, q, k_lo, acc);
+}
+
+// split[row] = index of the row's first nonzero with column >= k_mid (rowptr[row + 1] if none)
+__global__ void csr_split_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                 int64_t n, int k_mid, int64_t* __restrict__ split) {
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    int64_t a = rowptr[row], b = rowptr[row + 1];
+    while (a < b) {
+      const int64_t m = (a + b) >> 1;
+      if (col[m] >= k_mid) b = m;
+      else a = m + 1;
+    }
+    split[row] = a;
+  }
+}
+
+// part: 0 = the whole row, 1 = the tail [split, end) from zero, 2 = the head [begin, split)
+// continuing the sums the tail launch left in P
+template <class T>
+__global__ __launch_bounds__(1024) void proj_csr_lds32(const int64_t* __restrict__ rowptr,
+                                                       const int64_t* __restrict__ split,
+                                                       const int32_t* __restrict__ col,
+                                                       const T* __restrict__ val, int64_t n,
+                                                       int k_lo, int k_hi,
+                                                       const T* __restrict__ Rt /*[d][32]*/,
+                                                       T* __restrict__ P, int64_t ldp, int ncol,
+                                                       int part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* rl = reinterpret_cast<T*>(smem_raw);
+  for (int i = threadIdx.x; i < (k_hi - k_lo) * 32; i += blockDim.x)
+    rl[(i >> 5) * kCsrLd32 + (i & 31)] = Rt[(int64_t)k_lo * 32 + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int q = lane & 3;  // hyperplanes 8q .. 8q+7
+  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t ngroups = (n + 15) / 16;
+  for (int64_t g = wave_global; g < ngroups; g += wave_stride) {
+    const int64_t row = g * 16 + (lane >> 2);
+    const bool rv = row < n;
+    int64_t a = rv ? rowptr[row] : 0, b = rv ? rowptr[row + 1] : 0;
+    if (part == 1 && rv) a = split[row];
+    if (part == 2 && rv) b = split[row];
+    T acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      acc[k] = (part == 2 && rv && 8 * q + k < ncol) ? P[(int64_t)(8 * q + k) * ldp + row] : (T)0;
+    int64_t j0 = b;
+    while (__any(j0 > a)) {
+      int mycol[4];
+      T myval[4];
+      const int64_t i4 = j0 - 16 + 4 * q;
+      if (i4 >= a && j0 > a) {  // the lane's four nonzeros all exist: wide loads
+        struct __attribute__((packed, aligned(4))) C4 { int v[4]; };
+        struct __attribute__((packed, aligned(4))) V4 { T v[4]; };
+        const C4 c4 = *reinterpret_cast<const C4*>(col + i4);
+        const V4 v4 = *reinterpret_cast<const V4*>(val + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mycol[e] = c4.v[e];
+          myval[e] = v4.v[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t idx = i4 + e;
+          const bool ok = idx >= a && j0 > a;
+          mycol[e] = ok ? col[idx] : k_lo;  // padding: a column of the tile, value 0
+          myval[e] = ok ? val[idx] : (T)0;
+        }
+      }
+      csr_batch8<T, 15>(mycol, myval, rl, q, k_lo, acc);
+      j0 -= 16;
+    }
+    if (rv) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (8 * q + k < ncol) P[(int64_t)(8 * q + k) * ldp + row] = acc[k];
+    }
+  }
+}
+
 // one wide pass over a 128-element K chunk of X (columns [k0, k0 + D) of every row) for the
 // CBT*16 hyperplanes padded into fragment order at Ab
 template <class TIn, class TC, int D, int CBT, int KS>
@@ -1318,10 +1430,80 @@ int32_t launch_exact_dense(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_
   return RPT_OK;  // Rt returns to the stream-ordered allocator
 }
 
+// split point of every CSR row at column k_mid, computed once per dataset
+static int32_t ensure_csr_split(rpt_ctx* ctx, const rpt_dataset* ds, int k_mid) {
+  if (ds->csr_split && ds->csr_split_k == k_mid) return RPT_OK;
+  if (ds->csr_split) dev_free(ds->csr_split);
+  ds->csr_split = nullptr;
+  void* p = nullptr;
+  if (dev_alloc(&p, (size_t)(ds->n > 0 ? ds->n : 1) * 8) != hipSuccess)
+    return fail(RPT_E_NOMEM, "CSR split points");
+  int64_t blocks = (ds->n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(csr_split_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ds->rowptr,
+                     ds->col, ds->n, k_mid, (int64_t*)p);
+  if (hipGetLastError() != hipSuccess) {
+    dev_free(p);
+    return fail(RPT_E_HIP, "csr_split_kernel launch");
+  }
+  ds->csr_split = (int64_t*)p;
+  ds->csr_split_k = k_mid;
+  return RPT_OK;
+}
+
 template <class T>
 int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, T* P) {
   const int64_t n = ds->n;
   const int d = ds->d;
+  // ---- 32 hyperplanes per pass over the CSR arrays (whole rows, or two column halves) ----
+  const size_t tile32 = (size_t)d * kCsrLd32 * sizeof(T);
+  const int k_mid = (d + 1) / 2;
+  const size_t half32 = (size_t)k_mid * kCsrLd32 * sizeof(T);
+  const size_t kLdsMax = 144 * 1024;
+  if (C > 16 && half32 <= kLdsMax && !ctx->opt.proj_narrow) {
+    const bool whole = tile32 <= kLdsMax;
+    constexpr int CB = 32;
+    const int nblk = (C + CB - 1) / CB;
+    DevBuf<T> Rt;
+    RPT_TRY(Rt.alloc((size_t)nblk * d * CB));
+    hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
+    if (!whole) RPT_TRY(ensure_csr_split(ctx, ds, k_mid));
+    const size_t smem = whole ? tile32 : half32;
+    static bool attr_done = false;
+    if (!attr_done) {
+      RPT_HIP(hipFuncSetAttribute((const void*)proj_csr_lds32<T>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+      attr_done = true;
+    }
+    for (int b = 0; b < nblk; ++b) {
+      const int c0 = b * CB;
+      const int ncol = C - c0 < CB ? C - c0 : CB;
+      const T* rt = Rt.p + (size_t)b * d * CB;
+      T* pb = P + (int64_t)c0 * n;
+      if (whole) {
+        ProfScope ps(ctx, RPT_PROF_PROJECT);
+        hipLaunchKernelGGL(proj_csr_lds32<T>, dim3((unsigned)ctx->n_cu), dim3(1024), smem, ctx->stream,
+                           ds->rowptr, (const int64_t*)nullptr, ds->col, (const T*)ds->val, n, 0, d,
+                           rt, pb, n, ncol, 0);
+      } else {
+        {
+          ProfScope ps(ctx, RPT_PROF_PROJECT);
+          hipLaunchKernelGGL(proj_csr_lds32<T>, dim3((unsigned)ctx->n_cu), dim3(1024), smem,
+                             ctx->stream, ds->rowptr, (const int64_t*)ds->csr_split, ds->col,
+                             (const T*)ds->val, n, k_mid, d, rt, pb, n, ncol, 1);
+        }
+        {
+          ProfScope ps(ctx, RPT_PROF_PROJECT);
+          hipLaunchKernelGGL(proj_csr_lds32<T>, dim3((unsigned)ctx->n_cu), dim3(1024), smem,
+                             ctx->stream, ds->rowptr, (const int64_t*)ds->csr_split, ds->col,
+                             (const T*)ds->val, n, 0, k_mid, rt, pb, n, ncol, 2);
+        }
+      }
+    }
+    RPT_HIP(hipGetLastError());
+    return RPT_OK;  // Rt returns to the stream-ordered allocator
+  }
   constexpr int CB = 16;
   const int nblk = (C + CB - 1) / CB;
   DevBuf<T> Rt;

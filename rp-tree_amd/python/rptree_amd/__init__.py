@@ -254,6 +254,23 @@ class Dataset:
         return Dataset(ctx, h, len(rowptr) - 1, int(d), _DT[val.dtype], True)
 
     @staticmethod
+    def csr_from_torch(ctx, rowptr, col, val, d):
+        """Borrow CSR arrays held in torch tensors on ctx's device (int64 rowptr, int32 col,
+        float64 / float32 val).  Not validated (see rpt_dataset_csr_dev); torch's current stream
+        is synchronised first."""
+        import torch
+        dt = {torch.float64: RPT_F64, torch.float32: RPT_F32}[val.dtype]
+        if rowptr.dtype != torch.int64 or col.dtype != torch.int32:
+            raise ValueError("rowptr must be int64 and col int32")
+        torch.cuda.current_stream(val.device).synchronize()
+        n = rowptr.numel() - 1
+        h = C.c_void_p()
+        check(lib().rpt_dataset_csr_dev(ctx._h, C.c_void_p(rowptr.data_ptr()), C.c_void_p(col.data_ptr()),
+                                        C.c_void_p(val.data_ptr()), n, int(d), dt, val.numel(),
+                                        C.byref(h)))
+        return Dataset(ctx, h, n, int(d), dt, True, keep=(rowptr, col, val))
+
+    @staticmethod
     def of(ctx, data):
         """Pack `V.Vector (Embed v Double x)`-like input once at the boundary.  Accepts a
         Dataset, a 2-D array, (rowptr, col, val, d), a scipy CSR matrix, or a sequence of

@@ -38,6 +38,7 @@ SYMBOLS = {
     "rpt_dataset_dense_host": (i32, [vp, vp, i64, i32, i32, C.POINTER(vp)]),
     "rpt_dataset_dense_dev": (i32, [vp, vp, i64, i32, i32, C.POINTER(vp)]),
     "rpt_dataset_csr_host": (i32, [vp, vp, vp, vp, i64, i32, i32, C.POINTER(vp)]),
+    "rpt_dataset_csr_dev": (i32, [vp, vp, vp, vp, i64, i32, i32, i64, C.POINTER(vp)]),
     "rpt_dataset_free": (i32, [vp]),
     "rpt_dataset_info": (i32, [vp, p_i64, p_i32, p_i32, p_i32, p_i64]),
     "rpt_topology": (i32, [i64, i32, i32, vp, i64, p_i64]),

@@ -231,6 +231,95 @@ def test_streaming_on_16bit_codes_is_exact(rp, ctx, oracle, kind, mode):
             assert np.array_equal(getattr(f, name), getattr(fo, name), equal_nan=True), name
 
 
+@pytest.mark.parametrize("d,dtype", [(600, np.float64), (784, np.float64), (300, np.float64),
+                                     (784, np.float32), (1500, np.float32)])
+def test_csr_projection_32_per_pass_is_bit_identical(rp, ctx, oracle, d, dtype):
+    """CSR rows against 32 hyperplanes per pass: whole rows when the hyperplane tile fits LDS,
+    otherwise two column halves (tail launch, then head launch continuing its sums) — the same
+    right-nested sum as innerSS (Internal.hs:353-366) and as the 16-column kernel, bit for bit."""
+    n, C = 5000, 72                      # 32 + 32 + 8 columns
+    rng = np.random.default_rng(d)
+    dens = 0.19
+    m = rng.random((n, d)) < dens
+    m[7] = False                         # an empty row
+    m[8, :] = False
+    m[8, d - 1] = True                   # a row living in the upper half only
+    m[9, :] = False
+    m[9, 0] = True                       # ... in the lower half only
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(m.sum(axis=1))
+    col = np.nonzero(m)[1].astype(np.int32)
+    val = (1.0 - rng.random(len(col))).astype(dtype)
+    R = rng.standard_normal((C, d)) * (rng.random((C, d)) < 0.35)
+    ds = rp.Dataset.csr(ctx, rowptr, col, val, d)
+    P = rp.project(ds, R, ctx=ctx)
+    old = ctx.set_option("proj_narrow", 1)
+    try:
+        Pn = rp.project(ds, R, ctx=ctx)
+    finally:
+        ctx.set_option("proj_narrow", old)
+    assert np.array_equal(P, Pn)
+    if dtype == np.float64:
+        for c in (0, 31, 32, 71):
+            idx = np.nonzero(R[c])[0]
+            for i in (0, 7, 8, 9, 1234, n - 1):
+                a, b = rowptr[i], rowptr[i + 1]
+                assert P[c, i] == oracle.inner_ss(idx, R[c, idx], col[a:b], val[a:b])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csr_knn_fused_equals_general_path_and_oracle(rp, ctx, oracle, dtype):
+    """SVector data through the fused query kernel (traversal + CSR row distances + selection in
+    one workgroup per query): the same ids, distances and counts as the unfused general path, for
+    every duplicate rule; ids equal the oracle's (true L2) wherever its distances separate."""
+    n, d, T, ml, k = 20000, 200, 8, 40, 10
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.2)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(9, T, L, pnz, d)
+    f = rp.forestBatch(9, L, ml, T, pnz, d, (rowptr, col, val.astype(dtype), d), ctx=ctx, hyperplanes=R)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 64, d, 0.2)
+    qs = (qr, qc, qv.astype(dtype), d)
+    for dedup in (False, True, rp.RPT_KNN_DEDUP_DISTANCE):
+        a = rp.knnBatch(k, f, qs, dedup=dedup)
+        old = ctx.set_option("knn_general", 1)
+        try:
+            b = rp.knnBatch(k, f, qs, dedup=dedup)
+        finally:
+            ctx.set_option("knn_general", old)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), dedup
+    if dtype == np.float64:
+        fo = oracle.forest_build_csr(rowptr, col, val, d, R, ml)
+        assert np.array_equal(f.perm, fo.perm)
+        ids, dist, cnt = rp.knnBatch(k, f, qs)
+        for i in range(64):
+            a0, b0 = qr[i], qr[i + 1]
+            wi, wd = oracle.knn_csr(fo, rowptr, col, val, qc[a0:b0], qv[a0:b0], k, true_l2=True)
+            assert cnt[i] == len(wi)
+            assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-9, atol=1e-12)
+            if len(wd) > 1 and (np.diff(wd) > 1e-9 * wd[1:]).all():
+                assert np.array_equal(ids[i, :cnt[i]], wi)
+
+
+def test_csr_dataset_borrowed_from_hbm(rp, ctx, oracle):
+    """rpt_dataset_csr_dev: CSR arrays that already live in HBM give the forest of the host-copied
+    dataset (and of the oracle)."""
+    import torch
+    n, d = 4000, 30
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.3)
+    R, _ = oracle.forest_hyperplanes(9, 3, 6, 0.5, d)
+    tr, tc, tv = (torch.from_numpy(a).cuda() for a in (rowptr, col, val))
+    ds = rp.Dataset.csr_from_torch(ctx, tr, tc, tv, d)
+    f = rp._build(ctx, ds, R, 6, 25, rp.RPT_PROJ_AUTO)
+    fo = oracle.forest_build_csr(rowptr, col, val, d, R, 25)
+    assert np.array_equal(f.perm, fo.perm) and np.array_equal(f.thr, fo.thr, equal_nan=True)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 8, d, 0.3)
+    ids, dist, cnt = rp.knnBatch(5, f, (qr, qc, qv, d))
+    g = rp.forestBatch(9, 6, 25, 3, 0.5, d, (rowptr, col, val, d), ctx=ctx, hyperplanes=R)
+    ids2, dist2, cnt2 = rp.knnBatch(5, g, (qr, qc, qv, d))
+    assert np.array_equal(ids, ids2) and np.array_equal(dist, dist2) and np.array_equal(cnt, cnt2)
+
+
 # --------------------------------------------------------------------------- voting (8f-4)
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_knn_vote_matches_keep_counts(rp, ctx, oracle, dtype):
