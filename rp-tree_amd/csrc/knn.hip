@@ -508,56 +508,102 @@ struct CsrPtrs {
   const int64_t* rowptr;
   const int32_t* col;
   const void* val;
+  int64_t nnz;
   const int64_t* qrowptr;
   const int32_t* qcol;
   const void* qval;
 };
 
-// distances of the CSR candidates [first, fill) of an LDS batch to the dense-ified query qs:
-// true Euclidean distance |q|^2 + sum over the row's nonzeros of ((x_j - q_j)^2 - q_j^2), the
-// arithmetic of topk_csr_kernel (sixteen lanes per row, lane-strided nonzeros, fixed butterfly),
-// but with SIXTEEN rows of a wave in flight (four row slots per lane group): the walk of a row
-// is a chain of dependent loads (id -> rowptr -> col / val -> qs[col]) and four rows per wave
-// left the kernel latency-bound.
+// Squared-distance sums of U CSR rows per 16-lane group against the dense-ified query qs (LDS):
+// s[u] = sum over the row's nonzeros of ((x_j - q_j)^2 - q_j^2); the true Euclidean distance is
+// sqrt(|q|^2 + s).  Lane l of the group takes the nonzeros ra + 64 t + 4 l .. + 3 for t = 0, 1, ..
+// with one 16-byte column load and one 16/32-byte value load (4-byte aligned addresses), sums
+// them in index order and the group adds its sixteen partial sums by a fixed butterfly: a
+// row's value does not depend on the kernel or the slot it is computed in (the fused kernel and
+// the general path call this same function).  All loads of a step — U rows — are issued before
+// the first is used: the walk of a row is a chain of dependent loads (id -> rowptr -> col / val
+// -> qs[col]), and issuing them row by row left the kernels latency-bound (C3: 2.2 TB/s).
+template <class TD, int U>
+__device__ __forceinline__ void csr_rows_dist2(const int32_t* __restrict__ col,
+                                               const TD* __restrict__ val, int64_t nnz,
+                                               const int64_t (&ra)[U], const int64_t (&rb)[U],
+                                               const double* qs, int l16, double (&s)[U]) {
+  struct __attribute__((packed, aligned(4))) C4 { int v[4]; };
+  struct __attribute__((packed, aligned(4))) V4 { TD v[4]; };
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.0;
+  for (int64_t t = 4 * l16;; t += 64) {
+    C4 c[U];
+    V4 v[U];
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = ra[u] + t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c[u].v[e] = 0;
+        v[u].v[e] = (TD)0;
+      }
+      if (j < rb[u]) {
+        if (j + 4 <= nnz) {  // may run past the row's end (masked below), never past the arrays'
+          c[u] = *reinterpret_cast<const C4*>(col + j);
+          v[u] = *reinterpret_cast<const V4*>(val + j);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < rb[u]) {
+              c[u].v[e] = col[j + e];
+              v[u].v[e] = val[j + e];
+            }
+        }
+      }
+      more = more || j + 64 < rb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = ra[u] + t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = j + e < rb[u];
+        const double qj = qs[ok ? c[u].v[e] : 0];
+        const double df = (double)v[u].v[e] - qj;
+        const double term = df * df - qj * qj;
+        s[u] += ok ? term : 0.0;
+      }
+    }
+    if (!__any(more)) break;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    for (int o = 8; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);  // fixed butterfly inside the group
+}
+
+// distances of the CSR candidates [first, fill) of an LDS batch: sixteen rows of a wave in flight
+// (four row slots per 16-lane group)
 template <class TD>
 __device__ __forceinline__ void batch_distances_csr(const int64_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col,
-                                                    const TD* __restrict__ val, const int* cid,
-                                                    double* cdist, const double* qs, double qn2,
-                                                    int first, int fill, int wave, int lane) {
+                                                    const TD* __restrict__ val, int64_t nnz,
+                                                    const int* cid, double* cdist, const double* qs,
+                                                    double qn2, int first, int fill, int wave,
+                                                    int lane) {
   constexpr int U = 4;
   const int grp = lane >> 4, l16 = lane & 15;
   for (int i0 = first + wave * 4 * U; i0 < fill; i0 += 4 * 4 * U) {
-    int64_t j[U], rb[U];
+    int64_t ra[U], rb[U];
     double s[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * 4 + grp;
       const bool ok = i < fill;
       const int id = cid[ok ? i : first];
-      const int64_t ra = rowptr[id];
-      rb[u] = ok ? rowptr[id + 1] : ra;
-      j[u] = ra + l16;
-      s[u] = 0.0;
+      ra[u] = rowptr[id];
+      rb[u] = ok ? rowptr[id + 1] : ra[u];
     }
-    bool more = true;
-    while (more) {
-      more = false;
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (j[u] < rb[u]) {
-          const double qj = qs[col[j[u]]];
-          const double df = (double)val[j[u]] - qj;
-          s[u] += df * df - qj * qj;
-          j[u] += 16;
-          more = more || j[u] < rb[u];
-        }
-    }
+    csr_rows_dist2<TD, U>(col, val, nnz, ra, rb, qs, l16, s);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      double t = s[u];
-      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);  // fixed butterfly inside the group
-      t += qn2;
+      const double t = s[u] + qn2;
       const int i = i0 + u * 4 + grp;
       if (l16 == 0 && i < fill) cdist[i] = sqrt(t > 0 ? t : 0.0);
     }
@@ -903,8 +949,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     __syncthreads();
     // ---- distances of the new candidates ----
     if constexpr (CSR)
-      batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), cid, cdist, qsd,
-                              s_qn, first_new, fill, wave, lane);
+      batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), csr.nnz, cid,
+                              cdist, qsd, s_qn, first_new, fill, wave, lane);
     else if constexpr (PRE32)
       batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
     else if (pack32)
@@ -1253,7 +1299,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
 template <class TD>
 __global__ __launch_bounds__(256) void topk_csr_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const TD* __restrict__ val, int d, const int64_t* __restrict__ qrowptr,
+    const TD* __restrict__ val, int64_t nnz, int d, const int64_t* __restrict__ qrowptr,
     const int32_t* __restrict__ qcol, const TD* __restrict__ qval,
     const int32_t* __restrict__ perm, const Range* __restrict__ ranges,
     const int64_t* __restrict__ rng_off, int T, int k, int dedup, int32_t* __restrict__ out_ids,
@@ -1286,22 +1332,28 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
     while (done < rg.n) {
       int take = rg.n - done;
       if (take > cap - filled) take = cap - filled;
-      // sixteen lanes per candidate row, four rows per wave in flight (a sparse row has ~150
-      // nonzeros: one row per wave left the loads latency-bound)
-      for (int i = wave * 4 + (lane >> 4); i < take; i += 16) {
-        const int c = done + i;
-        const int id = perm[rg.poff + c];
-        double s = 0;
-        const int64_t ra = rowptr[id], rb = rowptr[id + 1];
-#pragma unroll 4
-        for (int64_t j = ra + (lane & 15); j < rb; j += 16) {
-          const double qj = qs[col[j]];
-          const double df = (double)val[j] - qj;
-          s += df * df - qj * qj;
+      // sixteen lanes per candidate row, sixteen rows per wave in flight (csr_rows_dist2)
+      for (int i0 = wave * 16; i0 < take; i0 += 64) {
+        constexpr int U = 4;
+        int64_t ra[U], rb[U];
+        int id[U];
+        double s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * 4 + (lane >> 4);
+          const bool ok = i < take;
+          id[u] = perm[rg.poff + done + (ok ? i : 0)];
+          ra[u] = rowptr[id[u]];
+          rb[u] = ok ? rowptr[id[u] + 1] : ra[u];
         }
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);  // fixed butterfly inside the group
-        s += qn2;
-        if ((lane & 15) == 0) buf[filled + i] = Entry{sqrt(s > 0 ? s : 0.0), rg.pos + c, id};
+        csr_rows_dist2<TD, U>(col, val, nnz, ra, rb, qs, lane & 15, s);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * 4 + (lane >> 4);
+          const double t = s[u] + qn2;
+          if ((lane & 15) == 0 && i < take)
+            buf[filled + i] = Entry{sqrt(t > 0 ? t : 0.0), rg.pos + done + i, id[u]};
+        }
       }
       filled += take;
       done += take;
@@ -1684,7 +1736,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   }
   if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
     if (data->csr) {  // SVector rows: the same kernel, distances over CSR rows
-      const CsrPtrs cp{data->rowptr, data->col, data->val, q->rowptr, q->col, q->val};
+      const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val};
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, false, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1725,7 +1777,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
         RPT_HIP(hipFuncSetAttribute((const void*)topk_csr_kernel<double>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(topk_csr_kernel<double>, dim3((unsigned)q->n), dim3(256), smem,
-                         ctx->stream, data->rowptr, data->col, (const double*)data->val, data->d,
+                         ctx->stream, data->rowptr, data->col, (const double*)data->val, data->nnz, data->d,
                          q->rowptr, q->col, (const double*)q->val, f->perm.p, pl.ranges.p,
                          pl.rng_off.p, f->T, k, dedup, ids_dev, dist_dev, count_dev);
     } else {
@@ -1733,7 +1785,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
         RPT_HIP(hipFuncSetAttribute((const void*)topk_csr_kernel<float>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(topk_csr_kernel<float>, dim3((unsigned)q->n), dim3(256), smem,
-                         ctx->stream, data->rowptr, data->col, (const float*)data->val, data->d,
+                         ctx->stream, data->rowptr, data->col, (const float*)data->val, data->nnz, data->d,
                          q->rowptr, q->col, (const float*)q->val, f->perm.p, pl.ranges.p,
                          pl.rng_off.p, f->T, k, dedup, ids_dev, dist_dev, count_dev);
     }

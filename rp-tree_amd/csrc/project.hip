@@ -65,6 +65,8 @@ __device__ inline double mul_rn(double a, double b) { return __dmul_rn(a, b); }
 __device__ inline double add_rn(double a, double b) { return __dadd_rn(a, b); }
 __device__ inline float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ inline float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ inline double fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // ---------------------------------------------------------------------------------------
 // exact-order dense kernel.  Block = 256 threads = 4 waves; a wave owns 64 consecutive
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(256) void proj_csr(const int64_t* __restrict__ rowp
 // ---------------------------------------------------------------------------------------
 template <int U>
 __device__ inline int quad_bcast(int x) {  // lane U of every quad to the whole quad
-  return __builtin_amdgcn_update_dpp(0, x, U | (U << 2) | (U << 4) | (U << 6), 0xf, 0xf, false);
+  return __builtin_amdgcn_mov_dpp(x, U | (U << 2) | (U << 4) | (U << 6), 0xf, 0xf, true);
 }
 template <int U>
 __device__ inline float quad_bcast(float x) {
@@ -1040,33 +1042,84 @@ __global__ __launch_bounds__(1024) void proj_csr_lds(const int64_t* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // CSR, 32 hyperplanes per pass: the same scheme with EIGHT hyperplanes per lane (four lanes per
-// row), so the CSR arrays are read once per 32 hyperplanes instead of once per 16 — the CSR
-// bytes are what the 16-column kernel moves (C3: 1.79 GB per launch against 0.13 GB of output).
-// The tile Rt[k][32] of a column range [k_lo, k_hi) lives in LDS (row stride 34).  When all d
-// rows fit (f32 up to d ~ 1000, f64 up to d ~ 540) one launch does everything; otherwise the
-// columns are cut in two halves and a pass is TWO launches: the first walks every row's nonzeros
-// with column >= k_mid (CSR columns ascend, so that is the tail [split, end) of the row, found
-// once per dataset), from the last to the first, and leaves the partial sums in P; the second
-// starts from those sums and walks the head [begin, split).  Together they perform exactly the
+// row), so the CSR arrays are read once per 32 hyperplanes instead of once per 16.
+//
+// The 16-column kernel is not bound by HBM but by the LDS: every (nonzero, hyperplane) pair
+// fetches its own hyperplane component (rows of a wave hit unrelated columns: no reuse), and
+// with padded tile rows the four rows of a ds_read_b128 lane group land on random 64-byte
+// quarters of the 256-byte bank row — two of four collide on average (~2.1 LDS cycles per
+// group instead of 1).  Here the tile row of a column is exactly one bank row (32 f64 = 256
+// bytes, no padding) cut in four 64-byte PIECES, a quad reads one piece per instruction (lane q
+// its 16 bytes), and the four quads of a lane group read four DIFFERENT pieces: quad r starts at
+// piece rho(r) and walks (rho + j) mod 4 over its four reads.  Whatever columns the rows hit,
+// the group covers each bank once: conflict-free by construction.  A lane's accumulators are
+// therefore rotated by its rho; they are rotated back once per row when P is written.
+// (f32: rows are 128 bytes = two pieces; two of a group's four quads share a piece and collide
+// when their columns have the same parity — 1.5 cycles per group on average.)
+//
+// The tile Rt[k][32] of a column range [k_lo, k_hi) lives in LDS.  When all d rows fit (f32 up
+// to d ~ 1100, f64 up to d ~ 570) one launch does everything; otherwise the columns are cut in
+// two halves and a pass is TWO launches: the first walks every row's nonzeros with column >=
+// k_mid (CSR columns ascend, so that is the tail [split, end) of the row, found once per
+// dataset), from the last to the first, and leaves the partial sums in P; the second starts
+// from those sums and walks the head [begin, split).  Together they perform exactly the
 // reference's right-nested sum (Internal.hs:353-366), in the same order, so P is bit-identical;
 // each launch reads half of the CSR arrays.
 // ---------------------------------------------------------------------------------------
-constexpr int kCsrLd32 = 34;
+template <class T>
+struct Csr32 {
+  static constexpr int kPer = 16 / (int)sizeof(T);      // hyperplanes per 16-byte read: 2 / 4
+  static constexpr int kReads = 8 / kPer;               // reads per lane and nonzero: 4 / 2
+  static constexpr int kRowBytes = 32 * (int)sizeof(T);  // one tile row: 256 / 128
+  struct __attribute__((aligned(16))) Vec {
+    T v[kPer];
+  };
+};
 
-template <class T, int U, int E>
-__device__ inline void csr_term8(const int (&mycol)[4], const T (&myval)[4], const T* rl, int q,
-                                 int k_lo, T (&acc)[8]) {
-  const int cu = quad_bcast<U>(mycol[E]);
-  const T vu = quad_bcast<U>(myval[E]);
-  const T* r = rl + (cu - k_lo) * kCsrLd32 + 8 * q;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = add_rn(mul_rn(vu, r[k]), acc[k]);
-}
-template <class T, int I>
-__device__ inline void csr_batch8(const int (&mycol)[4], const T (&myval)[4], const T* rl, int q,
-                                  int k_lo, T (&acc)[8]) {
-  csr_term8<T, I / 4, I % 4>(mycol, myval, rl, q, k_lo, acc);
-  if constexpr (I > 0) csr_batch8<T, I - 1>(mycol, myval, rl, q, k_lo, acc);
+// start piece of a quad: distinct over the four quads of every ds_read_b128 lane group
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same in the upper half: quads {0,3,5,6}
+// and {1,2,4,7})
+__device__ inline int csr_rho(int lane) { return ((lane >> 2) & 7) >> 1; }
+
+// the four nonzeros of quad lane U, from the last (element 3) to the first: the LDS reads of a
+// nonzero are issued two nonzeros ahead of its arithmetic, so a wave waits for the LDS once per
+// group, not once per read
+template <class T, int U, bool FUSED>
+__device__ inline void csr_group32(const int (&mycolb)[4], const T (&myval)[4],
+                                   const unsigned char* const (&rp)[Csr32<T>::kReads],
+                                   T (&acc)[Csr32<T>::kReads][Csr32<T>::kPer]) {
+  using G = Csr32<T>;
+  using Vec = typename G::Vec;
+  Vec ra[G::kReads], rb[G::kReads];
+#define RPT_CSR_ISSUE(E, buf)                                                    \
+  {                                                                              \
+    const int cb = quad_bcast<U>(mycolb[E]); /* (column - k_lo) * kRowBytes */   \
+    _Pragma("unroll") for (int j = 0; j < G::kReads; ++j)                        \
+        buf[j] = *reinterpret_cast<const Vec*>(rp[j] + cb);                      \
+  }
+#define RPT_CSR_MATH(E, buf)                                                     \
+  {                                                                              \
+    const T vu = quad_bcast<U>(myval[E]);                                        \
+    _Pragma("unroll") for (int j = 0; j < G::kReads; ++j)                        \
+        _Pragma("unroll") for (int e = 0; e < G::kPer; ++e)                      \
+            acc[j][e] = FUSED ? fma_rn(vu, buf[j].v[e], acc[j][e])               \
+                              : add_rn(mul_rn(vu, buf[j].v[e]), acc[j][e]);      \
+  }
+  RPT_CSR_ISSUE(3, ra)
+  RPT_CSR_ISSUE(2, rb)
+  __builtin_amdgcn_sched_barrier(0);
+  RPT_CSR_MATH(3, ra)
+  __builtin_amdgcn_sched_barrier(0);
+  RPT_CSR_ISSUE(1, ra)
+  __builtin_amdgcn_sched_barrier(0);
+  RPT_CSR_MATH(2, rb)
+  __builtin_amdgcn_sched_barrier(0);
+  RPT_CSR_ISSUE(0, rb)
+  __builtin_amdgcn_sched_barrier(0);
+  RPT_CSR_MATH(1, ra)
+  RPT_CSR_MATH(0, rb)
+#undef RPT_CSR_ISSUE
+#undef RPT_CSR_MATH
 }
 
 // split[row] = index of the row's first nonzero with column >= k_mid (rowptr[row + 1] if none)
@@ -1085,68 +1138,155 @@ __global__ void csr_split_kernel(const int64_t* __restrict__ rowptr, const int32
 }
 
 // part: 0 = the whole row, 1 = the tail [split, end) from zero, 2 = the head [begin, split)
-// continuing the sums the tail launch left in P
-template <class T>
-__global__ __launch_bounds__(1024) void proj_csr_lds32(const int64_t* __restrict__ rowptr,
-                                                       const int64_t* __restrict__ split,
-                                                       const int32_t* __restrict__ col,
-                                                       const T* __restrict__ val, int64_t n,
-                                                       int k_lo, int k_hi,
-                                                       const T* __restrict__ Rt /*[d][32]*/,
-                                                       T* __restrict__ P, int64_t ldp, int ncol,
-                                                       int part) {
+// continuing the sums the tail launch left in P.
+//
+// The wave's loop is software-pipelined over (row group, batch of 16 nonzeros): the column /
+// value loads of the NEXT batch — of the next row group when the current rows are finished, whose
+// row range was itself fetched a whole group earlier, and in part 2 that group's partial sums —
+// are issued before the arithmetic of the current batch.  Without this a wave paid a dependent
+// HBM latency for the row range, one per batch and (part 2) one for the sums: at C3 the kernel
+// ran at 2.8 TB/s with VALU and LDS half idle.
+constexpr int kCsr32Threads = 768;  // 3 waves per SIMD: 168 VGPRs for the two batches in flight
+
+template <class T, bool FUSED>
+__global__ __launch_bounds__(kCsr32Threads) void proj_csr_lds32(
+    const int64_t* __restrict__ rowptr, const int64_t* __restrict__ split,
+    const int32_t* __restrict__ col, const T* __restrict__ val, int64_t n, int k_lo, int k_hi,
+    const T* __restrict__ Rt /*[d][32]*/, T* __restrict__ P, int64_t ldp, int ncol, int part) {
+  using G = Csr32<T>;
+  constexpr int NR = G::kReads, NP = G::kPer;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* rl = reinterpret_cast<T*>(smem_raw);
-  for (int i = threadIdx.x; i < (k_hi - k_lo) * 32; i += blockDim.x)
-    rl[(i >> 5) * kCsrLd32 + (i & 31)] = Rt[(int64_t)k_lo * 32 + i];
-  __syncthreads();
+  {  // the tile is a straight copy of rows [k_lo, k_hi) of Rt
+    const typename G::Vec* src = reinterpret_cast<const typename G::Vec*>(Rt + (int64_t)k_lo * 32);
+    typename G::Vec* dst = reinterpret_cast<typename G::Vec*>(smem_raw);
+    const int nvec = (k_hi - k_lo) * 32 / NP;
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();  // the only barrier: waves leave independently below
   const int lane = threadIdx.x & 63;
-  const int q = lane & 3;  // hyperplanes 8q .. 8q+7
-  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int q = lane & 3;
+  const int rho = csr_rho(lane) & (NR - 1);
+  const unsigned char* rp[NR];  // read j inside tile row 0: piece (rho + j) mod NR, slot q
+#pragma unroll
+  for (int j = 0; j < NR; ++j) rp[j] = smem_raw + (((rho + j) & (NR - 1)) * 64 + 16 * q);
   const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t ngroups = (n + 15) / 16;
-  for (int64_t g = wave_global; g < ngroups; g += wave_stride) {
-    const int64_t row = g * 16 + (lane >> 2);
-    const bool rv = row < n;
-    int64_t a = rv ? rowptr[row] : 0, b = rv ? rowptr[row + 1] : 0;
-    if (part == 1 && rv) a = split[row];
-    if (part == 2 && rv) b = split[row];
-    T acc[8];
+  int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= ngroups) return;
+
+  struct __attribute__((packed, aligned(4))) C4 { int v[4]; };
+  struct __attribute__((packed, aligned(4))) V4 { T v[4]; };
+  // the lane's row range in group gg ([0, 0) past the end)
+  auto range = [&](int64_t gg, int64_t& ra, int64_t& rb) {
+    const int64_t r = gg * 16 + (lane >> 2);
+    ra = 0;
+    rb = 0;
+    if (gg < ngroups && r < n) {
+      ra = part == 1 ? split[r] : rowptr[r];
+      rb = part == 2 ? split[r] : rowptr[r + 1];
+    }
+  };
+  // the lane's four nonzeros [jj - 16 + 4q, +4) of the batch ending at jj, clipped to [ra, jj)
+  auto fetch = [&](int64_t ra, int64_t jj, C4& c, V4& v) {
+    const int64_t i4 = jj - 16 + 4 * q;
+    if (i4 >= ra && jj > ra) {  // all four exist: wide loads
+      c = *reinterpret_cast<const C4*>(col + i4);
+      v = *reinterpret_cast<const V4*>(val + i4);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      acc[k] = (part == 2 && rv && 8 * q + k < ncol) ? P[(int64_t)(8 * q + k) * ldp + row] : (T)0;
-    int64_t j0 = b;
-    while (__any(j0 > a)) {
-      int mycol[4];
-      T myval[4];
-      const int64_t i4 = j0 - 16 + 4 * q;
-      if (i4 >= a && j0 > a) {  // the lane's four nonzeros all exist: wide loads
-        struct __attribute__((packed, aligned(4))) C4 { int v[4]; };
-        struct __attribute__((packed, aligned(4))) V4 { T v[4]; };
-        const C4 c4 = *reinterpret_cast<const C4*>(col + i4);
-        const V4 v4 = *reinterpret_cast<const V4*>(val + i4);
+      for (int e = 0; e < 4; ++e) {
+        const int64_t idx = i4 + e;
+        const bool ok = idx >= ra && jj > ra;
+        c.v[e] = ok ? col[idx] : k_lo;  // padding: value 0 times tile row 0
+        v.v[e] = ok ? val[idx] : (T)0;
+      }
+    }
+  };
+  // hyperplane of accumulator (j, e) in this lane: piece (rho + j) mod NR, slot q
+  auto column = [&](int j, int e) { return 4 * NP * ((rho + j) & (NR - 1)) + NP * q + e; };
+  // partial sums of the lane's row in group gg (part 2), in accumulator order.  A lane touches 16
+  // bytes of a 128-byte line per access — the group's other quads fill the line within the same
+  // few instructions, L2 merges them.
+  auto sums = [&](int64_t gg, T (&dst)[NR][NP]) {
+    const int64_t r = gg * 16 + (lane >> 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          mycol[e] = c4.v[e];
-          myval[e] = v4.v[e];
-        }
-      } else {
+    for (int j = 0; j < NR; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int64_t idx = i4 + e;
-          const bool ok = idx >= a && j0 > a;
-          mycol[e] = ok ? col[idx] : k_lo;  // padding: a column of the tile, value 0
-          myval[e] = ok ? val[idx] : (T)0;
+      for (int e = 0; e < NP; ++e) {
+        const int c = column(j, e);
+        dst[j][e] = (gg < ngroups && r < n && c < ncol) ? P[(int64_t)c * ldp + r] : (T)0;
+      }
+  };
+
+  int64_t a, b, an, bn;
+  range(g, a, b);
+  int64_t j0 = b;
+  C4 cc;
+  V4 vc;
+  fetch(a, j0, cc, vc);
+  range(g + wave_stride, an, bn);
+  T acc[NR][NP], nat[NR][NP];
+#pragma unroll
+  for (int j = 0; j < NR; ++j)
+#pragma unroll
+    for (int e = 0; e < NP; ++e) acc[j][e] = nat[j][e] = (T)0;
+  if (part == 2) sums(g, acc);
+  for (;;) {
+    // ---- what comes after this batch (wave-uniform) ----
+    const bool more = __any(j0 - 16 > a);
+    const int64_t gn = g + wave_stride;
+    const bool last = !more && gn >= ngroups;
+    const int64_t na = more ? a : an, nj0 = more ? j0 - 16 : bn;
+    C4 cn;
+    V4 vn;
+    if (!last) fetch(na, nj0, cn, vn);
+    if (!more && !last && part == 2) sums(gn, nat);
+    // ---- this batch ----
+    int mycolb[4];
+    T myval[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mycolb[e] = (cc.v[e] - k_lo) * G::kRowBytes;
+      myval[e] = vc.v[e];
+    }
+    // quad lane U holds batch positions 4U .. 4U+3; a row with rem = j0 - a nonzeros left fills
+    // the positions from 16 - rem up, so group U is empty in every row of the wave unless some
+    // row has rem >= 13 - 4U (row lengths vary: the wave runs to its longest row)
+    const int64_t rem = j0 - a;
+    if (__any(rem >= 1)) {
+      csr_group32<T, 3, FUSED>(mycolb, myval, rp, acc);
+      if (__any(rem >= 5)) {
+        csr_group32<T, 2, FUSED>(mycolb, myval, rp, acc);
+        if (__any(rem >= 9)) {
+          csr_group32<T, 1, FUSED>(mycolb, myval, rp, acc);
+          if (__any(rem >= 13)) csr_group32<T, 0, FUSED>(mycolb, myval, rp, acc);
         }
       }
-      csr_batch8<T, 15>(mycol, myval, rl, q, k_lo, acc);
-      j0 -= 16;
     }
-    if (rv) {
+    if (!more) {  // the rows of this group are complete
+      const int64_t row = g * 16 + (lane >> 2);
+      if (row < n) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (8 * q + k < ncol) P[(int64_t)(8 * q + k) * ldp + row] = acc[k];
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int e = 0; e < NP; ++e) {
+            const int c = column(j, e);
+            if (c < ncol) P[(int64_t)c * ldp + row] = acc[j][e];
+          }
+      }
+      if (last) break;
+      g = gn;
+      a = an;
+      b = bn;
+      range(g + wave_stride, an, bn);  // used a whole group from now
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < NP; ++e) acc[j][e] = nat[j][e];  // zeros unless part 2
     }
+    j0 = nj0;
+    cc = cn;
+    vc = vn;
   }
 }
 
@@ -1453,13 +1593,14 @@ static int32_t ensure_csr_split(rpt_ctx* ctx, const rpt_dataset* ds, int k_mid) 
 }
 
 template <class T>
-int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, T* P) {
+int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, T* P,
+                   bool fused) {
   const int64_t n = ds->n;
   const int d = ds->d;
   // ---- 32 hyperplanes per pass over the CSR arrays (whole rows, or two column halves) ----
-  const size_t tile32 = (size_t)d * kCsrLd32 * sizeof(T);
+  const size_t tile32 = (size_t)d * Csr32<T>::kRowBytes;
   const int k_mid = (d + 1) / 2;
-  const size_t half32 = (size_t)k_mid * kCsrLd32 * sizeof(T);
+  const size_t half32 = (size_t)k_mid * Csr32<T>::kRowBytes;
   const size_t kLdsMax = 144 * 1024;
   if (C > 16 && half32 <= kLdsMax && !ctx->opt.proj_narrow) {
     const bool whole = tile32 <= kLdsMax;
@@ -1470,11 +1611,12 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
     hipLaunchKernelGGL(transpose_R<T>, dim3(256), dim3(256), 0, ctx->stream, R_dev, C, d, CB, Rt.p);
     if (!whole) RPT_TRY(ensure_csr_split(ctx, ds, k_mid));
     const size_t smem = whole ? tile32 : half32;
-    static bool attr_done = false;
-    if (!attr_done) {
-      RPT_HIP(hipFuncSetAttribute((const void*)proj_csr_lds32<T>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-      attr_done = true;
+    auto kern = fused ? proj_csr_lds32<T, true> : proj_csr_lds32<T, false>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[fused]) {
+      RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kLdsMax));
+      attr_done[fused] = true;
     }
     for (int b = 0; b < nblk; ++b) {
       const int c0 = b * CB;
@@ -1483,19 +1625,19 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
       T* pb = P + (int64_t)c0 * n;
       if (whole) {
         ProfScope ps(ctx, RPT_PROF_PROJECT);
-        hipLaunchKernelGGL(proj_csr_lds32<T>, dim3((unsigned)ctx->n_cu), dim3(1024), smem, ctx->stream,
+        hipLaunchKernelGGL(kern, dim3((unsigned)ctx->n_cu), dim3(kCsr32Threads), smem, ctx->stream,
                            ds->rowptr, (const int64_t*)nullptr, ds->col, (const T*)ds->val, n, 0, d,
                            rt, pb, n, ncol, 0);
       } else {
         {
           ProfScope ps(ctx, RPT_PROF_PROJECT);
-          hipLaunchKernelGGL(proj_csr_lds32<T>, dim3((unsigned)ctx->n_cu), dim3(1024), smem,
+          hipLaunchKernelGGL(kern, dim3((unsigned)ctx->n_cu), dim3(kCsr32Threads), smem,
                              ctx->stream, ds->rowptr, (const int64_t*)ds->csr_split, ds->col,
                              (const T*)ds->val, n, k_mid, d, rt, pb, n, ncol, 1);
         }
         {
           ProfScope ps(ctx, RPT_PROF_PROJECT);
-          hipLaunchKernelGGL(proj_csr_lds32<T>, dim3((unsigned)ctx->n_cu), dim3(1024), smem,
+          hipLaunchKernelGGL(kern, dim3((unsigned)ctx->n_cu), dim3(kCsr32Threads), smem,
                              ctx->stream, ds->rowptr, (const int64_t*)ds->csr_split, ds->col,
                              (const T*)ds->val, n, 0, k_mid, rt, pb, n, ncol, 2);
         }
@@ -1555,9 +1697,11 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
   if (ds->n == 0) return RPT_OK;
   if (mode == RPT_PROJ_AUTO) mode = ds->dtype == RPT_F64 ? RPT_PROJ_EXACT : RPT_PROJ_MFMA;
   if (ds->csr) {
-    // CSR x dense is not MFMA shaped; both modes use the segmented kernel
-    if (ds->dtype == RPT_F64) return launch_csr<double>(ctx, ds, R_dev, C, (double*)P_dev);
-    return launch_csr<float>(ctx, ds, R_dev, C, (float*)P_dev);
+    // CSR x dense is not MFMA shaped: both modes use the segmented kernel, RPT_PROJ_MFMA (the
+    // tolerance mode) with one fused multiply-add per term instead of the reference's two roundings
+    const bool fused = mode == RPT_PROJ_MFMA;
+    if (ds->dtype == RPT_F64) return launch_csr<double>(ctx, ds, R_dev, C, (double*)P_dev, fused);
+    return launch_csr<float>(ctx, ds, R_dev, C, (float*)P_dev, fused);
   }
   if (mode == RPT_PROJ_EXACT) {
     if (ds->dtype == RPT_F64)

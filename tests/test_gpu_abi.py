@@ -252,13 +252,21 @@ def test_csr_projection_32_per_pass_is_bit_identical(rp, ctx, oracle, d, dtype):
     val = (1.0 - rng.random(len(col))).astype(dtype)
     R = rng.standard_normal((C, d)) * (rng.random((C, d)) < 0.35)
     ds = rp.Dataset.csr(ctx, rowptr, col, val, d)
-    P = rp.project(ds, R, ctx=ctx)
+    P = rp.project(ds, R, mode=rp.RPT_PROJ_EXACT, ctx=ctx)
     old = ctx.set_option("proj_narrow", 1)
     try:
-        Pn = rp.project(ds, R, ctx=ctx)
+        Pn = rp.project(ds, R, mode=rp.RPT_PROJ_EXACT, ctx=ctx)
     finally:
         ctx.set_option("proj_narrow", old)
     assert np.array_equal(P, Pn)
+    # RPT_PROJ_MFMA on CSR rows = the same kernel with one fused multiply-add per term: the
+    # tolerance mode (1e-5 * |x| * |r|, include/rptree_hip.h), not bit-identical
+    Pf = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    xn = np.sqrt(np.add.reduceat(np.square(val.astype(np.float64)), np.minimum(rowptr[:-1], len(val) - 1))
+                 * (np.diff(rowptr) > 0))
+    rn = np.linalg.norm(R, axis=1)
+    assert np.all(np.abs(Pf.astype(np.float64) - P.astype(np.float64)) <= 1e-5 * rn[:, None] * xn[None, :] + 1e-300)
+    assert not np.array_equal(Pf, P)
     if dtype == np.float64:
         for c in (0, 31, 32, 71):
             idx = np.nonzero(R[c])[0]
