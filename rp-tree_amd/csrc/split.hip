@@ -3077,6 +3077,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     samp.d = ds->d;
     samp.dtype = ds->dtype;
     samp.X = Xs.p;
+    samp.sample = true;
     RPT_TRY(project_columns(ctx, &samp, f->R.p, Cs, RPT_PROJ_MFMA, Psamp.p));
     hipLaunchKernelGGL(code_minmax_kernel<TK>, dim3((unsigned)((Cs + 3) / 4)), dim3(256), 0, st,
                        Psamp.p, S, Cs, L, Lc, code_mm.p);

@@ -27,7 +27,7 @@ for k in sorted(acc):
     g = max(acc[k])
     d = acc[k][g]
     n = max(len(v) for v in d.values())
-    rows.append("%s,%d,%d," % (k, g, n) + ",".join(
+    rows.append('"%s",%d,%d,' % (k, g, n) + ",".join(
         "%.4g" % (sum(d[c]) / len(d[c])) if c in d else "" for c in counters))
 open(sys.argv[2], "w").write("\n".join(rows) + "\n")
 print("\n".join(rows))

@@ -10,7 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, rocprofv3 args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
-  rocprofv3 "$@" -d /tmp/rp_$name -o r -- "${CMD[@]}" > "$out/$name.log" 2>&1 || { echo "$name failed"; tail -5 "$out/$name.log"; return 1; }
+  echo "[prof] pass $name: $*"
+  timeout -k 10 ${PASS_TIMEOUT:-240} rocprofv3 "$@" -d /tmp/rp_$name -o r -- "${CMD[@]}" > "$out/$name.log" 2>&1 || { echo "$name failed"; tail -3 "$out/$name.log"; return 1; }
 }
 CMD=("$@")
 run trace --kernel-trace --stats || exit 1
