@@ -61,7 +61,9 @@ extern "C" {
 #define RPT_PROJ_EXACT 1    /* f64 VALU, the reference's summation order and no FMA
                                (Internal.hs:382): bit-identical to innerSD/innerSS */
 #define RPT_PROJ_MFMA 2     /* MFMA tiles (f64/f32/bf16 inputs), k-ordered fma chain:
-                               within 1e-5*|x||r| of the reference value */
+                               within 1e-5*|x||r| of the reference value.  CSR rows: the
+                               exact-order kernel with ONE fused multiply-add per term
+                               instead of the reference's two roundings (same tolerance) */
 
 /* knn flags */
 #define RPT_KNN_KEEP_DUPLICATES 0 /* the reference: RPTree.hs:174-176 never de-duplicates */
@@ -118,7 +120,13 @@ int32_t rpt_prof_get(rpt_ctx* ctx, int32_t which, double* total_ms, int64_t* lau
  * dense: row-major X[n][d] (`V.Vector (Embed DVector Double x)` packed once at the boundary).
  * csr:   SVector rows: rowptr[n+1] (int64), col[nnz] (int32, ascending per row, < d), val.
  * *_host variants copy to HBM; *_dev variants borrow device memory that must outlive the
- * handle.  Query batches use the same handle type. */
+ * handle.  Query batches use the same handle type.
+ * Stream order of borrowed memory: the ctx stream is a non-blocking stream of its own, nothing
+ * orders it against the stream that PRODUCED the borrowed arrays.  The producer must have
+ * finished (synchronise its stream, or make it wait on an event of it via rpt_ctx_stream) before
+ * the first rpt_* call that reads the memory; the same holds for output buffers of the *_dev
+ * query entry points that another stream initialises.  (rptree_amd.Dataset.from_torch and
+ * ShardedForest synchronise torch's current stream for exactly this reason.) */
 int32_t rpt_dataset_dense_host(rpt_ctx* ctx, const void* X_host, int64_t n, int32_t d,
                                int32_t dtype, rpt_dataset** out);
 int32_t rpt_dataset_dense_dev(rpt_ctx* ctx, const void* X_dev, int64_t n, int32_t d,
