@@ -343,12 +343,56 @@ __device__ __forceinline__ void tile_load(typename Mfma<TC>::acc_t (&acc)[CBT], 
   }
 }
 
+// value of lane l ^ 1 (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ double lane_swap1(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffLL), 0xb1, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0xb1, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_swap1(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xb1, 0xf, 0xf, true));
+}
+
 template <class TC, int CBT, bool CODES>
 __device__ __forceinline__ void tile_store(const typename Mfma<TC>::acc_t (&acc)[CBT], TC* __restrict__ P,
                                            int64_t ldp, int c0, int ncol, int64_t row0, int64_t n,
                                            int lane, const CodeCtl<TC>* ctl, unsigned int cmask) {
   const int64_t r4 = row0 + 4 * (lane >> 4);
+  if constexpr (sizeof(TC) == 8) {
+    // f64: a lane holds 32 bytes (four points) of one hyperplane row, the row's 128 bytes of
+    // this tile sit in four lanes 16 apart — stored as they are, every instruction writes half
+    // of each line (16 of every 32 bytes).  Lanes l and l ^ 1 (neighbouring hyperplanes) swap
+    // one 16-byte half instead, so that the first instruction writes the EVEN row of the pair
+    // completely (eight lanes x 16 contiguous bytes) and the second the odd row.
+    const bool whole = row0 + 15 < n && (ldp & 1) == 0 && ncol == CBT * 16;  // wave-uniform
+    if (whole) {
+      typedef double d2 __attribute__((ext_vector_type(2), aligned(16)));
+      const int odd = lane & 1;
+#pragma unroll
+      for (int h = 0; h < CBT; ++h) {
+        // even lane: keeps (a0, a1), gives (a2, a3); odd lane: keeps (b2, b3), gives (b0, b1)
+        const double g0 = odd ? acc[h][0] : acc[h][2], g1 = odd ? acc[h][1] : acc[h][3];
+        const double x0 = lane_swap1(g0), x1 = lane_swap1(g1);
+        const int col = h * 16 + (lane & 15);
+        TC* pe = P + (int64_t)(c0 + (col & ~1)) * ldp + r4 + 2 * odd;   // the pair's even row
+        TC* po = pe + ldp;                                               // ... and odd row
+        d2 ve, vo;
+        if (odd) {
+          ve = d2{x0, x1};                  // the even row's points 4q + 2, 4q + 3
+          vo = d2{acc[h][2], acc[h][3]};    // own points 4q + 2, 4q + 3
+        } else {
+          ve = d2{acc[h][0], acc[h][1]};    // own points 4q, 4q + 1
+          vo = d2{x0, x1};                  // the odd row's points 4q, 4q + 1
+        }
+        *reinterpret_cast<d2*>(pe) = ve;
+        *reinterpret_cast<d2*>(po) = vo;
+      }
+    }
+    if (whole) goto codes;
+  }
   if (r4 >= n) return;
+  {
   const bool vec = r4 + 3 < n && (ldp & 3) == 0;  // whole, 16-byte aligned runs
 #pragma unroll
   for (int h = 0; h < CBT; ++h) {
@@ -367,6 +411,8 @@ __device__ __forceinline__ void tile_store(const typename Mfma<TC>::acc_t (&acc)
       }
     }
   }
+  }
+codes:
   if constexpr (CODES) {
     if (cmask == 0) return;
     const CodeCtl<TC> cc = *ctl;
