@@ -100,7 +100,8 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  *   no_stream, stream_maxnodes, stream_minper, no_wmid, no_midselect, stream_big_node, no_wsub
  *       median split: which regime handles which level
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
- *   knn_wave (-1 auto, 0, 1), knn_kp, knn_no_pre32, knn_general     query kernels
+ *   knn_wave (-1 auto, 0, 1), knn_kp, knn_no_pre32, knn_csr_pre32, knn_general
+ *       query kernels
  *   debug_host, debug_stamps       stderr diagnostics
  * Unknown names: RPT_E_ARG. */
 int32_t rpt_ctx_set_option(rpt_ctx* ctx, const char* name, int64_t value);

@@ -212,6 +212,7 @@ const OptDesc kOptions[] = {
     {"knn_wave", &rpt_options::knn_wave},
     {"knn_kp", &rpt_options::knn_kp},
     {"knn_no_pre32", &rpt_options::knn_no_pre32},
+    {"knn_csr_pre32", &rpt_options::knn_csr_pre32},
     {"knn_general", &rpt_options::knn_general},
     {"tune0", &rpt_options::tune0},
     {"tune1", &rpt_options::tune1},
@@ -593,6 +594,7 @@ int32_t rpt_dataset_free(rpt_dataset* ds) {
     if (ds) dev_set_stream(ds->ctx->stream);
     if (!ds) return RPT_OK;
     if (ds->shadow32) dev_free(ds->shadow32);
+    if (ds->shadow_col16) dev_free(ds->shadow_col16);
     if (ds->csr_split) dev_free(ds->csr_split);
     if (ds->owns) {
       (void)hipSetDevice(ds->ctx->device);

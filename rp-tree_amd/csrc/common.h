@@ -126,6 +126,7 @@ struct rpt_options {
   int64_t knn_wave = -1;        // kNN: -1 auto, 0 workgroup-per-query, 1 wave-per-query kernel
   int64_t knn_kp = 0;           // kNN: entries the f32 prefilter keeps (0 = k + max(6, k/2))
   int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
+  int64_t knn_csr_pre32 = 0;    // kNN: rank CSR f64 rows on their (u16 column, f32 value) shadow
   int64_t knn_general = 0;      // kNN: unfused general path
   int64_t tune0 = 0, tune1 = 0, tune2 = 0, tune3 = 0;  // experiment hooks (0 = the built-in choice)
   int64_t debug_host = 0;       // stderr: host-side phase times of a build
@@ -186,7 +187,9 @@ struct rpt_dataset {
   int64_t nnz = 0;
   // lazily built by the first kNN call on dense f64 data: f32 copy of X (the fused kernel ranks
   // candidates on it before it computes exact distances of the survivors) and the largest row norm
-  mutable float* shadow32 = nullptr;
+  mutable float* shadow32 = nullptr;        // dense: X as f32; CSR: val as f32
+  mutable uint16_t* shadow_col16 = nullptr;  // CSR (d <= 65536): col as u16
+  mutable int64_t max_rowlen = 0;            // CSR: the longest row
   mutable double max_norm = -1.0;
   // lazily built by the first projection of a CSR dataset whose hyperplane tile does not fit LDS
   // whole: index of every row's first nonzero with column >= csr_split_k (project.hip)

@@ -512,6 +512,11 @@ struct CsrPtrs {
   const int64_t* qrowptr;
   const int32_t* qcol;
   const void* qval;
+  // f32 prefilter (f64 rows, d <= 65536): the rows again as (u16 column, f32 value), 6 instead of
+  // 12 bytes per nonzero; the longest row (bounds the f32 summation chains)
+  const uint16_t* col16;
+  const float* val32;
+  int64_t max_rowlen;
 };
 
 // Squared-distance sums of U CSR rows per 16-lane group against the dense-ified query qs (LDS):
@@ -610,6 +615,94 @@ __device__ __forceinline__ void batch_distances_csr(const int64_t* __restrict__ 
   }
 }
 
+// The same walk over the (u16 column, f32 value) shadow of the rows, in f32 arithmetic: the
+// RANKING pass of the CSR prefilter (knn_fused_kernel<.., PRE32, CSR>).  No FMA contraction in
+// this translation unit: the error bound of the refine step counts one rounding per operation.
+template <int U>
+__device__ __forceinline__ void csr_rows_dist2_f32(const uint16_t* __restrict__ col16,
+                                                   const float* __restrict__ val32, int64_t nnz,
+                                                   const int64_t (&ra)[U], const int64_t (&rb)[U],
+                                                   const float* qs32, int l16, float (&s)[U]) {
+  struct __attribute__((packed, aligned(2))) C4 { uint16_t v[4]; };
+  struct __attribute__((packed, aligned(4))) V4 { float v[4]; };
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.f;
+  for (int64_t t = 4 * l16;; t += 64) {
+    C4 c[U];
+    V4 v[U];
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = ra[u] + t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c[u].v[e] = 0;
+        v[u].v[e] = 0.f;
+      }
+      if (j < rb[u]) {
+        if (j + 4 <= nnz) {
+          c[u] = *reinterpret_cast<const C4*>(col16 + j);
+          v[u] = *reinterpret_cast<const V4*>(val32 + j);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < rb[u]) {
+              c[u].v[e] = col16[j + e];
+              v[u].v[e] = val32[j + e];
+            }
+        }
+      }
+      more = more || j + 64 < rb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = ra[u] + t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = j + e < rb[u];
+        const float qj = qs32[ok ? (int)c[u].v[e] : 0];
+        const float df = v[u].v[e] - qj;
+        const float term = df * df - qj * qj;
+        s[u] += ok ? term : 0.f;
+      }
+    }
+    if (!__any(more)) break;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    for (int o = 8; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
+}
+
+// f32 SQUARED distances (clamped at 0) of the CSR candidates [first, fill) from the shadow
+__device__ __forceinline__ void batch_distances_csr32(const int64_t* __restrict__ rowptr,
+                                                      const uint16_t* __restrict__ col16,
+                                                      const float* __restrict__ val32, int64_t nnz,
+                                                      const int* cid, double* cdist,
+                                                      const float* qs32, float qn2, int first,
+                                                      int fill, int wave, int lane) {
+  constexpr int U = 4;
+  const int grp = lane >> 4, l16 = lane & 15;
+  for (int i0 = first + wave * 4 * U; i0 < fill; i0 += 4 * 4 * U) {
+    int64_t ra[U], rb[U];
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 4 + grp;
+      const bool ok = i < fill;
+      const int id = cid[ok ? i : first];
+      ra[u] = rowptr[id];
+      rb[u] = ok ? rowptr[id + 1] : ra[u];
+    }
+    csr_rows_dist2_f32<U>(col16, val32, nnz, ra, rb, qs32, l16, s);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float t = qn2 + s[u];
+      const int i = i0 + u * 4 + grp;
+      if (l16 == 0 && i < fill) cdist[i] = (double)(t > 0.f ? t : 0.f);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // fused query kernel (dense data): one workgroup per query does everything after the query
 // projections — traversal of every tree (thread = tree, twice: count, then emit ranges in
@@ -680,6 +773,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     for (int64_t j = csr.qrowptr[q] + tid; j < csr.qrowptr[q + 1]; j += 256)
       qsd[csr.qcol[j]] = (double)qv[j];
     __syncthreads();
+    if (PRE32)  // the slab holds d * 12 bytes: d doubles, then d floats
+      for (int j = tid; j < d; j += 256) reinterpret_cast<float*>(qsd + d)[j] = (float)qsd[j];
     if (wave == 0) {
       double sq = 0.0;
       for (int j = lane; j < d; j += 64) sq += qsd[j] * qsd[j];
@@ -948,7 +1043,11 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     pos_base = pb;
     __syncthreads();
     // ---- distances of the new candidates ----
-    if constexpr (CSR)
+    if constexpr (CSR && PRE32)
+      batch_distances_csr32(csr.rowptr, csr.col16, csr.val32, csr.nnz, cid, cdist,
+                            reinterpret_cast<const float*>(qsd + d), (float)s_qn, first_new, fill,
+                            wave, lane);
+    else if constexpr (CSR)
       batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), csr.nnz, cid,
                               cdist, qsd, s_qn, first_new, fill, wave, lane);
     else if constexpr (PRE32)
@@ -962,7 +1061,41 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     best = nb;
     if (vote > 0 ? vsrc >= nc_tot : r_next >= nr_tot) break;
   }
-  if constexpr (PRE32) {
+  if constexpr (PRE32 && CSR) {
+    // ---- refine (CSR): exact distances of the kept entries; certify the cut on SQUARED distances.
+    // Error of the f32 squared distance of a row x (u = 2^-24, one rounding per operation, inputs
+    // rounded to f32): a term (x_j - q_j)^2 - q_j^2 is off by at most 6.2 u T_j, T_j = (|x_j| +
+    // |q_j|)^2 + q_j^2; the sum of n terms, the butterfly and the |q|^2 term pass through chains of
+    // at most m = 4 ceil(n / 64) + 5 additions: (m + 1) u (sum T_j + |q|^2); sum T_j <= 2 |x|^2 +
+    // 3 |q|^2.  Together E2 <= (m + 8) u (2 xmax^2 + 4 |q|^2) (clamping at 0 only moves the value
+    // towards the true one).  Every dropped candidate therefore has an exact squared distance
+    // >= F2 - E2, F2 = the smallest dropped f32 value.
+    const bool cut = best == k1;
+    const double F2 = cut ? bdist[k1 - 1] : 0.0;
+    const int m = cut ? k1 - 1 : best;
+    for (int i = tid; i < m; i += 256) {
+      cid[i] = bid[i];
+      cpos[i] = bpos[i];
+    }
+    __syncthreads();
+    batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), csr.nnz, cid,
+                            cdist, qsd, s_qn, 0, m, wave, lane);
+    __syncthreads();
+    best = select(m, k, 0);
+    if (cut && best > 0) {
+      const double u = 5.9604644775390625e-08;
+      const double chain = (double)(4 * ((csr.max_rowlen + 63) / 64) + 5);
+      const double E2 = (chain + 8.0) * u * (2.0 * xmax * xmax + 4.0 * s_qn) * 1.01 + 1e-37;
+      const double dk = bdist[best - 1];
+      if (!(s_qn < 1e36) || !(F2 < 1e37) || !(F2 - E2 > dk * dk * (1.0 + 1e-14))) {
+        if (tid == 0) {  // flag 2: the host re-runs this query with exact distances only
+          ovf_flags[q] = 2u;
+          atomicAdd(cand_total + 1, 1ULL);
+        }
+        return;
+      }
+    }
+  } else if constexpr (PRE32) {
     // ---- refine: exact distances of the entries the f32 pass kept; certify the cut ----
     // The f32 distance of a row differs from the exact one by at most
     //   err(x) = 2.1 u (|x| + |q|) + (d + 2) u dist32,  u = 2^-24
@@ -1665,6 +1798,75 @@ static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
   return RPT_OK;
 }
 
+// (u16 column, f32 value) shadow of a CSR f64 dataset, its largest squared row norm and longest row
+__global__ __launch_bounds__(256) void shadow_csr_kernel(const int64_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const double* __restrict__ val, int64_t n,
+                                                         int64_t nnz, uint16_t* __restrict__ col16,
+                                                         float* __restrict__ val32,
+                                                         unsigned long long* __restrict__ max_bits) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = gtid; j < nnz; j += gsz) {
+    col16[j] = (uint16_t)col[j];
+    val32[j] = (float)val[j];
+  }
+  double mx = 0.0;
+  long long ml = 0;
+  for (int64_t r = gtid; r < n; r += gsz) {  // rows are short (SVectors): one thread per row
+    const int64_t a = rowptr[r], b = rowptr[r + 1];
+    double s2 = 0.0;
+    for (int64_t j = a; j < b; ++j) s2 += val[j] * val[j];
+    if (!(s2 <= mx)) mx = s2 == s2 ? s2 : __longlong_as_double(0x7ff0000000000000LL);  // NaN -> +inf
+    if (b - a > ml) ml = b - a;
+  }
+  atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));  // mx >= 0
+  atomicMax(max_bits + 1, (unsigned long long)ml);
+}
+
+// Built once per dataset, like the dense shadow: an optimisation that is allowed to fail (no
+// memory, NaN rows, squares outside the f32 range): the dataset is then marked and the exact
+// kernel answers.
+static int32_t ensure_shadow_csr(rpt_ctx* ctx, const rpt_dataset* data) {
+  if (data->shadow_col16 || data->max_norm == -2.0) return RPT_OK;
+  void *pc = nullptr, *pv = nullptr;
+  DevBuf<unsigned long long> mb;
+  unsigned long long bits[2] = {0, 0};
+  auto give_up = [&]() {
+    if (pc) dev_free(pc);
+    if (pv) dev_free(pv);
+    (void)hipGetLastError();
+    data->max_norm = -2.0;
+    return RPT_OK;
+  };
+  const size_t nz = (size_t)(data->nnz > 0 ? data->nnz : 1);
+  if (dev_alloc(&pc, nz * 2 + 16) != hipSuccess) {
+    pc = nullptr;
+    return give_up();
+  }
+  if (dev_alloc(&pv, nz * 4 + 16) != hipSuccess) {
+    pv = nullptr;
+    return give_up();
+  }
+  if (mb.alloc(2) != RPT_OK) return give_up();
+  if (hipMemsetAsync(mb.p, 0, 16, ctx->stream) != hipSuccess) return give_up();
+  hipLaunchKernelGGL(shadow_csr_kernel, dim3((unsigned)ctx->n_cu * 8), dim3(256), 0, ctx->stream,
+                     data->rowptr, data->col, (const double*)data->val, data->n, data->nnz,
+                     (uint16_t*)pc, (float*)pv, mb.p);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (hipMemcpyAsync(bits, mb.p, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
+  double m2;
+  std::memcpy(&m2, &bits[0], 8);
+  data->max_norm = std::sqrt(m2) * (1.0 + 1e-12);
+  if (!(data->max_norm < 1e18)) return give_up();
+  data->max_rowlen = (int64_t)bits[1];
+  data->shadow32 = (float*)pv;
+  data->shadow_col16 = (uint16_t*)pc;
+  return RPT_OK;
+}
+
 template <class TD, class TK>
 static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                             const rpt_dataset* q, const void* Pq, int32_t k, int dedup,
@@ -1687,8 +1889,9 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // per 10 000 queries at C2), too few and cuts fail their certificate (re-run per query): k + 6
   // certifies 10 000 of 10 000 C2 queries
   const int kp = kp_env > k && kp_env < kFK ? kp_env : prefilter_keep(k);
-  const bool pre32 = std::is_same<TD, double>::value && !data->csr && dedup == 0 && kp + 1 <= kFK &&
-                     !ctx->opt.knn_no_pre32 && data->shadow32 && !rerun && !f->prefilter_off;
+  const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
+                     !ctx->opt.knn_no_pre32 && data->shadow32 && !rerun && !f->prefilter_off &&
+                     (!data->csr || data->shadow_col16);
   if (wave) {
     const size_t smem = 4 * wbytes;
     if constexpr (std::is_same<TD, double>::value) {
@@ -1721,6 +1924,20 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                       (size_t)data->d * (sizeof(TA) + 4) + 64 +
                       (vote > 0 ? (size_t)kVoteCap * 4 + 16 : 0);
   if constexpr (std::is_same<TD, double>::value) {
+    if (pre32 && data->csr) {  // SVector rows ranked on their (u16, f32) shadow
+      const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val,
+                       data->shadow_col16, data->shadow32, data->max_rowlen};
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL((knn_fused_kernel<TD, TK, true, true>), dim3((unsigned)q->n), dim3(256),
+                         smem, ctx->stream, (const TD*)nullptr, data->d, (const TD*)nullptr,
+                         f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n,
+                         f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf,
+                         cand_total, (const float*)nullptr, data->max_norm, kp + 1, cp);
+      RPT_HIP(hipGetLastError());
+      return RPT_OK;
+    }
     if (pre32) {
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true>,
@@ -1736,7 +1953,8 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   }
   if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
     if (data->csr) {  // SVector rows: the same kernel, distances over CSR rows
-      const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val};
+      const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val,
+                       nullptr, nullptr, 0};
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, false, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1833,10 +2051,16 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     ProfScope ps(ctx, RPT_PROF_KNN_PLAN);
     if (f->L > 0) RPT_TRY(project_columns(ctx, q, f->R.p, f->T * f->L, f->mode, Pq.p));
   }
-  if (f->pdtype == RPT_F64 && !data->csr && dedup == 0 && prefilter_keep(k) < kFK &&
-      !ctx->opt.knn_no_pre32 &&
-      !f->prefilter_off)  // (dedup carries the vote threshold too: no prefilter when voting)
-    RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
+  if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !ctx->opt.knn_no_pre32 &&
+      !f->prefilter_off) {  // (dedup carries the vote threshold too: no prefilter when voting)
+    if (!data->csr) RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
+    // CSR rows: the (u16, f32) shadow halves the bytes of the ranking pass but NOT its time — at C3
+    // the exact kernel already gathers rows at 6.4 TB/s and the f32 pass, with its 17 selection
+    // rounds per batch, is bound by its serial phases (14.3 ms against 13.8 ms per 10 000 queries):
+    // opt-in (knn_csr_pre32), kept for bandwidth-poorer configurations and pinned by a test
+    else if (ctx->opt.knn_csr_pre32 && data->dtype == RPT_F64 && data->d <= 65536)
+      RPT_TRY(ensure_shadow_csr(ctx, data));
+  }
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
       return launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,

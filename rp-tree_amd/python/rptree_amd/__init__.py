@@ -642,6 +642,14 @@ def knnBatch(k, forest, qs, dedup=False, vote=0):
     return ids, dist, cnt
 
 
+def knn_last_uncertified(ctx=None):
+    """queries of the last knn call whose f32 prefilter cut could not be certified (re-run exactly)"""
+    ctx = ctx or default_context()
+    v = C.c_int64()
+    check(lib().rpt_knn_last_uncertified(ctx._h, C.byref(v)))
+    return int(v.value)
+
+
 def knn(distf, k, tts, q, dedup=False):
     """RPTree.hs:168-176: `knn distf k forest q` -> [(distance, point id)] in increasing
     distance order, duplicates across trees kept (the reference never de-duplicates).

@@ -309,6 +309,51 @@ def test_csr_knn_fused_equals_general_path_and_oracle(rp, ctx, oracle, dtype):
                 assert np.array_equal(ids[i, :cnt[i]], wi)
 
 
+def test_csr_knn_f32_prefilter_is_exact(rp, ctx, oracle):
+    """f64 SVector rows, duplicates kept: candidates are ranked on the (u16 column, f32 value)
+    shadow of the rows, exact distances for the best k + 6, the cut certified per query on squared
+    distances (uncertifiable queries re-run exactly).  Bit-identical answers to the all-exact
+    kernel on continuous data, on values rounded to one decimal (equal distances everywhere) and
+    on a data set with every row twice (ties exactly at the cut: the re-run path)."""
+    n, d, T, ml, k = 30000, 300, 12, 40, 10
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.2)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(9, T, L, pnz, d)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 200, d, 0.2)
+    # (b): rounded values; (c): rows 0..n/2 repeated as rows n/2..n
+    half = n // 2
+    h_end = rowptr[half]
+    rp2 = np.concatenate([rowptr[:half + 1], rowptr[1:half + 1] + h_end])
+    col2, val2 = np.concatenate([col[:h_end]] * 2), np.concatenate([val[:h_end]] * 2)
+    # (d): forty copies of one row near the first query: equal distances across the cut
+    a0, b0 = qr[0], qr[1]
+    blk_c, blk_v = qc[a0:b0], qv[a0:b0] * 1.001
+    rp3 = np.concatenate([rowptr, rowptr[-1] + (b0 - a0) * np.arange(1, 41)])
+    col3, val3 = np.concatenate([col] + [blk_c] * 40), np.concatenate([val] + [blk_v] * 40)
+    cases = [("continuous", rowptr, col, val, qv), ("rounded", rowptr, col, np.round(val, 1) + 0.05, np.round(qv, 1) + 0.05),
+             ("every row twice", rp2, col2, val2, qv), ("forty copies", rp3, col3, val3, qv)]
+    for name, rptr, cc, vv, qvv in cases:
+        f = rp.forestBatch(9, L, ml, T, pnz, d, (rptr, cc, vv, d), ctx=ctx, hyperplanes=R)
+        on = ctx.set_option("knn_csr_pre32", 1)      # opt-in: no faster than the exact kernel at C3
+        try:
+            a = rp.knnBatch(k, f, (qr, qc, qvv, d))
+        finally:
+            ctx.set_option("knn_csr_pre32", on)
+        unc = rp.knn_last_uncertified(ctx)
+        old = ctx.set_option("knn_no_pre32", 1)
+        try:
+            b = rp.knnBatch(k, f, (qr, qc, qvv, d))
+        finally:
+            ctx.set_option("knn_no_pre32", old)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), name
+        if name == "continuous":
+            assert unc == 0
+        if name == "forty copies":
+            assert unc > 0          # the copies tie across the prefilter's cut: the re-run path
+        f.close()
+
+
 def test_csr_dataset_borrowed_from_hbm(rp, ctx, oracle):
     """rpt_dataset_csr_dev: CSR arrays that already live in HBM give the forest of the host-copied
     dataset (and of the oracle)."""

@@ -68,3 +68,35 @@ for name, which in (("query projections + traversal plan", 2), ("distance / top-
     ms, c = C.c_double(), C.c_int64()
     _lib.check(L_.rpt_prof_get(ctx._h, which, C.byref(ms), C.byref(c)))
     print("  %-36s %.2f ms in %d spans" % (name, ms.value, c.value))
+
+# 10 000 fresh queries of the data's distribution (Bernoulli(0.19) support, U(0,1] values): the
+# (u16 column, f32 value) prefilter applies.  (Queries that ARE data points, as above, tie with
+# their own copies in every tree across the prefilter's cut and are answered exactly; after a
+# batch with > 25 % such queries the forest stops trying.)
+nq2 = 10000
+rq = np.random.default_rng(3)
+mq = rq.random((nq2, d)) < dens
+qr2 = np.zeros(nq2 + 1, dtype=np.int64); qr2[1:] = np.cumsum(mq.sum(axis=1))
+qc2 = np.nonzero(mq)[1].astype(np.int32)
+qv2 = 1.0 - rq.random(qr2[-1])
+for label, opt in (("f32 prefilter", 0), ("all exact", 1)):
+    ctx.set_option("knn_no_pre32", opt)
+    ctx.set_option("knn_csr_pre32", 1 - opt)
+    g = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)   # a fresh forest: prefilter state
+    rp.knnBatch(10, g, (qr2, qc2, qv2, d))
+    _lib.check(L_.rpt_prof_reset(ctx._h)); _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+    t0 = time.perf_counter()
+    i2, d2, c2 = rp.knnBatch(10, g, (qr2, qc2, qv2, d))
+    dt = time.perf_counter() - t0
+    ms, c = C.c_double(), C.c_int64()
+    _lib.check(L_.rpt_prof_get(ctx._h, 3, C.byref(ms), C.byref(c)))
+    _lib.check(L_.rpt_prof_enable(ctx._h, 0))
+    print("knn %d queries, %s: %.2f ms = %.3f M queries/s (host call); distance / top-k kernel %.2f ms = %.3f M queries/s; uncertified %d"
+          % (nq2, label, dt * 1e3, nq2 / dt / 1e6, ms.value, nq2 / ms.value / 1e3, rp.knn_last_uncertified(ctx)))
+    if opt == 0:
+        keep = (i2.copy(), d2.copy(), c2.copy())
+    else:
+        assert np.array_equal(keep[0], i2) and np.array_equal(keep[1], d2) and np.array_equal(keep[2], c2)
+    g.close()
+ctx.set_option("knn_no_pre32", 0)
+print("prefiltered answers identical to the exact kernel's")
