@@ -8,7 +8,8 @@ import torch
 import rptree_amd as rp
 from rptree_amd import _lib
 
-n, d, T, min_leaf = 1_000_000, 128, 32, 128
+import os
+n, d, T, min_leaf = 1_000_000, 128, int(os.environ.get("TREES", "32")), 128
 opt = sys.argv[1] if len(sys.argv) > 1 else "tune2"
 vals = [int(v) for v in sys.argv[2:]] or [0]
 dev = torch.device("cuda:0")
@@ -29,7 +30,7 @@ for v in vals:
         rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_MFMA).close()
     ctx.sync()
     _lib.check(L_.rpt_prof_reset(ctx._h)); _lib.check(L_.rpt_prof_enable(ctx._h, 1))
-    K = 5
+    K = int(os.environ.get("BUILDS", "5"))
     t0 = time.perf_counter()
     for it in range(K):
         rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_MFMA).close()
