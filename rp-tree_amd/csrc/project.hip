@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void proj_exact(const T* __restrict__ X, int64
 // reference's innerSD order (Internal.hs:382), bit for bit.
 // ---------------------------------------------------------------------------------------
 template <class T, int D, int KC>
-__global__ __launch_bounds__(256, 1) void proj_exact_lds(const T* __restrict__ X, int64_t n,
+// (f64: 256 registers, two workgroups = two waves per SIMD, so one wave's chunk commits — which
+// wait for HBM — run under the other's arithmetic; the f32 instantiation needs more registers)
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 2 : 1) void proj_exact_lds(const T* __restrict__ X, int64_t n,
                                                          const T* __restrict__ Rt /*[D][32]*/,
                                                          T* __restrict__ P, int64_t ldp, int ncol,
                                                          int64_t ntiles,
@@ -207,20 +209,51 @@ __global__ __launch_bounds__(256, 1) void proj_exact_lds(const T* __restrict__ X
     }
     if (tn < ntiles) issue(tn, chn);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // One wave per SIMD: nothing hides a dependent instruction's latency.  Left to the compiler
+    // every v_mul was followed at once by the v_add that consumes it and every LDS read by its
+    // first use: the VALU sat idle half the time.  Here the chunk is one flat sequence of 16-byte
+    // hyperplane pieces (k descending, columns ascending); the pieces travel through a ring of
+    // eight registers, read kAhead pieces before their use, and the products of two pieces (four
+    // columns x two rows) are all issued before the first add.
+    constexpr int NV = CB / PIECE;           // pieces per hyperplane row (k)
+    constexpr int NPC = KC * NV;             // pieces per chunk
+    constexpr int kRing = 8, kAhead = 6;
+    static_assert(NPC % 2 == 0 && kAhead < kRing && kAhead % 2 == 0, "pieces are consumed in pairs");
+    Raw ring[kRing];
+    T xk[2][2];
+    auto piece_ptr = [&](int i) {  // same address in every lane (LDS broadcast)
+      return reinterpret_cast<const Raw*>(myr + (KC - 1 - i / NV) * CB) + (i % NV);
+    };
+    xk[(KC - 1) & 1][0] = myx[lane * LDW + KC - 1];
+    xk[(KC - 1) & 1][1] = myx[(lane + 64) * LDW + KC - 1];
 #pragma unroll
-    for (int k = KC - 1; k >= 0; --k) {
-      const T x0 = myx[lane * LDW + k];
-      const T x1 = myx[(lane + 64) * LDW + k];
-      const Raw* rk = reinterpret_cast<const Raw*>(myr + k * CB);  // same address in every lane
+    for (int i = 0; i < kAhead; ++i) ring[i % kRing] = *piece_ptr(i);
 #pragma unroll
-      for (int c2 = 0; c2 < CB / PIECE; ++c2) {
-        const Raw rv = rk[c2];
+    for (int i = 0; i < NPC; i += 2) {
+      const int k = KC - 1 - i / NV, kb = k & 1;
+      if (i % NV == 0 && k > 0) {  // the next row's two x values, a whole row ahead
+        xk[kb ^ 1][0] = myx[lane * LDW + k - 1];
+        xk[kb ^ 1][1] = myx[(lane + 64) * LDW + k - 1];
+      }
 #pragma unroll
-        for (int q = 0; q < PIECE; ++q) {
-          const int c = c2 * PIECE + q;
-          acc0[c] = add_rn(mul_rn(rv[q], x0), acc0[c]);
-          acc1[c] = add_rn(mul_rn(rv[q], x1), acc1[c]);
-        }
+      for (int u = 0; u < 2; ++u)
+        if (i + kAhead + u < NPC) ring[(i + kAhead + u) % kRing] = *piece_ptr(i + kAhead + u);
+      const T x0 = xk[kb][0], x1 = xk[kb][1];
+      constexpr int NPROD = 2 * PIECE;       // columns of the pair
+      T p0[NPROD], p1[NPROD];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NPROD; ++j) {
+        const T r = ring[(i + j / PIECE) % kRing][j % PIECE];
+        p0[j] = mul_rn(r, x0);
+        p1[j] = mul_rn(r, x1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int cbase = (i % NV) * PIECE;
+#pragma unroll
+      for (int j = 0; j < NPROD; ++j) {
+        acc0[cbase + j] = add_rn(p0[j], acc0[cbase + j]);
+        acc1[cbase + j] = add_rn(p1[j], acc1[cbase + j]);
       }
     }
     if (ch == 0) {
