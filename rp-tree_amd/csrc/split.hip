@@ -2089,6 +2089,18 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   if (Cd) {  // code mode: eight points per thread and step, 16-byte code and node loads / stores
     const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
     const uint16_t* Cn = has_next ? Cl + N : Cl;
+    // LDS that code mode leaves unused holds the pivot list: nbin (16 KB) and the upper halves of
+    // smin / smax (the sampling cells are 32-bit here)
+    constexpr int kAssignList = 2048;
+    static_assert(sizeof(nbin) >= (size_t)kAssignList * 8, "pivot list overlays nbin");
+    int32_t* lid = reinterpret_cast<int32_t*>(nbin);                   // [kAssignList]
+    unsigned int* lmeta = reinterpret_cast<unsigned int*>(nbin) + kAssignList;
+    unsigned int* lcnt = reinterpret_cast<unsigned int*>(smin + kStreamMaxNodes);   // [kStreamMaxNodes]
+    unsigned int* lbase = reinterpret_cast<unsigned int*>(smax + kStreamMaxNodes);  // [kStreamMaxNodes]
+    __shared__ unsigned int lfill[1];
+    for (int j = threadIdx.x; j < M; j += kStreamThreads) lcnt[j] = 0u;
+    if (threadIdx.x == 0) lfill[0] = 0u;
+    __syncthreads();
     // one 8-byte LDS word per point (code_thr) and integer compares; the exact key is read only
     // for the pivot bin and the two margin bins
     auto classc = [&](int64_t i, unsigned int j, unsigned int code) -> int {
@@ -2102,7 +2114,18 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
         if (code <= (unsigned int)(th >> 48)) atomicMin(&ndt[j].minR, ord_of(Pl[i]));
         return (int)(2 * j + 1);
       }
-      const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
+      // pivot-bin point: parked in an LDS list (slot inside the block's share of its node's list
+      // from an LDS counter); the block reserves its share with ONE global atomic per node after
+      // the pass and copies the list out then.  A returning global atomic per pivot point in the
+      // middle of the streaming pass cost a third of this kernel (ablation: 80 -> 54 us per level).
+      const unsigned int e = atomicAdd(&lfill[0], 1u);
+      if (e < (unsigned int)kAssignList) {
+        const unsigned int loc = atomicAdd(&lcnt[j], 1u);
+        lid[e] = (int32_t)i;
+        lmeta[e] = (loc << 16) | j;   // loc < kAssignList <= 65536, j < kStreamMaxNodes
+        return -1;
+      }
+      const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);  // list full: the direct way
       pl[nmidoff[j] + p] = (int32_t)i;
       pk[nmidoff[j] + p] = Pl[i];
       return -1;
@@ -2166,6 +2189,21 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
       for (int64_t i = ie + threadIdx.x; i < i1; i += kStreamThreads) one(i);
     } else {
       for (int64_t i = i0 + threadIdx.x; i < i1; i += kStreamThreads) one(i);
+    }
+    // the block's pivot-bin points -> the nodes' global lists
+    __syncthreads();
+    for (int j = threadIdx.x; j < M; j += kStreamThreads)
+      if (lcnt[j]) lbase[j] = atomicAdd(&ndt[j].midcur, lcnt[j]);
+    __syncthreads();
+    {
+      const unsigned int ne = lfill[0] < (unsigned int)kAssignList ? lfill[0] : (unsigned int)kAssignList;
+      for (unsigned int e = threadIdx.x; e < ne; e += kStreamThreads) {
+        const unsigned int j = lmeta[e] & 0xffffu, loc = lmeta[e] >> 16;
+        const int32_t i = lid[e];
+        const unsigned int p = lbase[j] + loc;
+        pl[nmidoff[j] + p] = i;
+        pk[nmidoff[j] + p] = Pl[i];
+      }
     }
     // flush: children this block sampled -> the next level's code range (as keys: ord_of((TK)code))
     if (has_next && few) {
