@@ -1557,6 +1557,22 @@ __device__ inline unsigned long long code_thr(TK lo, TK scale, int B, int pb, in
                                               int highb /* >= B: none */) {
   auto first_ge = [&](int p) -> int {  // smallest code whose bin is >= p (65536: none)
     if (p <= 0) return 0;
+    // the bin function is monotone: start from its algebraic inverse and step to the exact
+    // boundary (0-2 steps); the bisection below is the answer to any geometry that defeats that
+    {
+      const TK x = lo + (TK)p / scale;
+      int m = x >= (TK)65536 ? 65536 : (x > (TK)0 ? (int)x : 0);  // NaN -> 0
+      int steps = 0;
+      while (m > 0 && steps < 6 && stream_bin((TK)(m - 1), lo, scale, B) >= p) {
+        --m;
+        ++steps;
+      }
+      while (m < 65536 && steps < 6 && stream_bin((TK)m, lo, scale, B) < p) {
+        ++m;
+        ++steps;
+      }
+      if (steps < 6) return m;
+    }
     int a = 0, b = 65536;
     while (a < b) {
       const int m = (a + b) >> 1;
