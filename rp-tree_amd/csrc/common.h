@@ -195,9 +195,6 @@ struct rpt_dataset {
   // whole: index of every row's first nonzero with column >= csr_split_k (project.hip)
   mutable int64_t* csr_split = nullptr;
   mutable int csr_split_k = -1;
-  // an internal row sample (the code geometry pass of split.hip): its launches are not counted
-  // in the profile class that bench.py reads for the roofline (RPT_PROF_PROJECT_WIDE)
-  bool sample = false;
 };
 
 struct rpt_forest {

@@ -1481,7 +1481,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
         off += (size_t)(ps.tiles ? ps.tiles : 2) * frag;
         if (ps.tiles) {
           // resolved into class 0 as well
-          ProfScope pw(ctx, ds->sample ? RPT_PROF_PROJECT : RPT_PROF_PROJECT_WIDE);
+          ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
           switch (ps.tiles) {
             case 8:
               RPT_TRY((launch_wide<TIn, TC, D, 8, KS8>(ctx, ds, k0, kvalid, accumulate, ps.c0,
@@ -1592,7 +1592,7 @@ int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, 
   }
   off = 0;
   for (const Pass& ps : passes) {
-    ProfScope pw(ctx, ds->sample ? RPT_PROF_PROJECT : RPT_PROF_PROJECT_WIDE);
+    ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
     // (four 16-point tiles per wave would halve the LDS fragment traffic per MFMA, but with the
     // 4-deep B ring that is 256 VGPRs + 300 bytes of scratch: two tiles it is)
     // rows of up to 128 elements (A resident in LDS, no staging): four waves of 64 points each

@@ -2822,34 +2822,53 @@ __global__ __launch_bounds__(kStreamThreads) void stream_to_perm(
   }
 }
 
-// ---- code geometry (codes.h): a strided sample of the rows, projected like the data; the
-// minimum and maximum of every column that the streaming levels will histogram ----
-template <class TIn>
-__global__ void gather_rows_kernel(const TIn* __restrict__ X, int64_t n, int d, int64_t stride,
-                                   int S, TIn* __restrict__ Xs) {
-  const int64_t total = (int64_t)S * d;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / d;
-    int64_t row = r * stride;
-    row = row < n ? row : n - 1;
-    Xs[i] = X[row * d + (i - r * d)];
-  }
+// ---- code geometry (codes.h): mm[0..1] = (ord(min), ord(max)) of the projections of a strided
+// sample of the rows on the columns that the streaming levels will histogram (level c % L below
+// Lc) — ONE geometry for the whole build; mm starts as (~0, 0).  Straight from the data: S rows,
+// `stride` apart, against the C dense-ified hyperplanes R[C][d], sixteen columns and 256 sample
+// rows per block, plain FMA dot products — the range only shapes the code bins (values outside
+// it clamp into the edge codes), so it needs neither the build's projection kernel nor its
+// rounding.  (Round 2's first version gathered the rows, ran the MFMA kernels over them and
+// reduced the result: seven launches, 0.12 ms per build.)
+// grid = (ceil(C / 16), ceil(S / 256)), 256 threads.
+__device__ inline double sample_value(double v) { return v; }
+__device__ inline double sample_value(float v) { return (double)v; }
+__device__ inline double sample_value(uint16_t v) {  // bf16 bits
+  return (double)__uint_as_float((unsigned int)v << 16);
 }
-
-// mm[0..1] = (ord(min), ord(max)) over the sampled values Ps[c][0..S) of the columns whose level
-// (c % L) is below Lc: ONE code geometry for the whole batch (codes.h).  mm starts as (~0, 0).
-// One wave per column.  grid = ceil(C / 4), 256 threads
-template <class TK>
-__global__ __launch_bounds__(256) void code_minmax_kernel(const TK* __restrict__ Ps, int S, int C,
-                                                          int L, int Lc,
-                                                          unsigned long long* __restrict__ mm) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C || c % L >= Lc) return;
+template <class TIn, class TK>
+__global__ __launch_bounds__(256) void sample_range_kernel(const TIn* __restrict__ X, int64_t stride,
+                                                           int S, int d, const double* __restrict__ R,
+                                                           int C, int L, int Lc,
+                                                           unsigned long long* __restrict__ mm) {
+  constexpr int CG = 16, KCH = 128;
+  __shared__ __attribute__((aligned(16))) double rl[KCH * CG];
+  const int c0 = blockIdx.x * CG;
+  const int si = blockIdx.y * 256 + threadIdx.x;
+  const bool live = si < S;
+  const TIn* xr = X + (int64_t)(live ? si : 0) * stride * d;
+  double acc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) acc[c] = 0.0;
+  for (int k0 = 0; k0 < d; k0 += KCH) {
+    const int kn = d - k0 < KCH ? d - k0 : KCH;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kn * CG; i += 256) {
+      const int c = i / kn, k = i % kn;  // consecutive threads read consecutive k of one column
+      rl[k * CG + c] = c0 + c < C ? R[(int64_t)(c0 + c) * d + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < kn; ++k) {
+      const double x = sample_value(xr[k0 + k]);
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = __builtin_fma(x, rl[k * CG + c], acc[c]);
+    }
+  }
   unsigned long long mn = ~0ULL, mx = 0ULL;
-  for (int i = lane; i < S; i += 64) {
-    const TK v = Ps[(int64_t)c * S + i];
-    if (v == v) {  // NaN samples do not shape anything
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    const TK v = (TK)acc[c];
+    if (live && c0 + c < C && (c0 + c) % L < Lc && v == v) {  // NaN samples do not shape anything
       const unsigned long long o = ord_of(v);
       mn = o < mn ? o : mn;
       mx = o > mx ? o : mx;
@@ -2860,7 +2879,7 @@ __global__ __launch_bounds__(256) void code_minmax_kernel(const TK* __restrict__
     mn = a < mn ? a : mn;
     mx = b > mx ? b : mx;
   }
-  if (lane == 0 && mn <= mx) {
+  if ((threadIdx.x & 63) == 0 && mn <= mx) {
     atomicMin(&mm[0], mn);
     atomicMax(&mm[1], mx);
   }
@@ -3105,36 +3124,21 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     // the clusters, and a column that leaves the range clamps half its points into one code),
     // through the MFMA kernels whatever the build's mode (the range only shapes bins)
     constexpr int S = 4096;
-    DevBuf<char> Xs;
-    DevBuf<TK> Psamp;
     const int C = T * L;
-    const int Cs = C;
-    RPT_TRY(Xs.alloc((size_t)S * f->d * dtype_size(ds->dtype)));
-    RPT_TRY(Psamp.alloc((size_t)Cs * S));
     RPT_TRY(code_mm.alloc(2));
     hipLaunchKernelGGL(stream_init_kernel, dim3(1), dim3(64), 0, st, code_mm.p, code_mm.p + 1, 1,
                        (unsigned int*)nullptr, 0);  // (~0, 0)
     const int64_t stride = N / S;
-    const unsigned gb = (unsigned)(((int64_t)S * f->d + 255) / 256 < 2048 ? ((int64_t)S * f->d + 255) / 256 : 2048);
+    const dim3 sgrid((unsigned)((C + 15) / 16), (unsigned)((S + 255) / 256));
     if (ds->dtype == RPT_F64)
-      hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(gb), dim3(256), 0, st, (const double*)ds->X,
-                         N, f->d, stride, S, (double*)Xs.p);
+      hipLaunchKernelGGL((sample_range_kernel<double, TK>), sgrid, dim3(256), 0, st,
+                         (const double*)ds->X, stride, S, f->d, f->R.p, C, L, Lc, code_mm.p);
     else if (ds->dtype == RPT_F32)
-      hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(gb), dim3(256), 0, st, (const float*)ds->X, N,
-                         f->d, stride, S, (float*)Xs.p);
+      hipLaunchKernelGGL((sample_range_kernel<float, TK>), sgrid, dim3(256), 0, st,
+                         (const float*)ds->X, stride, S, f->d, f->R.p, C, L, Lc, code_mm.p);
     else
-      hipLaunchKernelGGL(gather_rows_kernel<uint16_t>, dim3(gb), dim3(256), 0, st,
-                         (const uint16_t*)ds->X, N, f->d, stride, S, (uint16_t*)Xs.p);
-    rpt_dataset samp;
-    samp.ctx = ctx;
-    samp.n = S;
-    samp.d = ds->d;
-    samp.dtype = ds->dtype;
-    samp.X = Xs.p;
-    samp.sample = true;
-    RPT_TRY(project_columns(ctx, &samp, f->R.p, Cs, RPT_PROJ_MFMA, Psamp.p));
-    hipLaunchKernelGGL(code_minmax_kernel<TK>, dim3((unsigned)((Cs + 3) / 4)), dim3(256), 0, st,
-                       Psamp.p, S, Cs, L, Lc, code_mm.p);
+      hipLaunchKernelGGL((sample_range_kernel<uint16_t, TK>), sgrid, dim3(256), 0, st,
+                         (const uint16_t*)ds->X, stride, S, f->d, f->R.p, C, L, Lc, code_mm.p);
     RPT_TRY(codes.alloc((size_t)T * L * N));
     CodeOut co;
     co.codes = codes.p;
