@@ -2067,6 +2067,20 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     tmn[c] = ~0ULL;
     tmx[c] = 0ULL;
   }
+  // 8-byte-key mode with at most 512 nodes: the upper halves of nbin / smin / smax are unused and
+  // hold the block's pivot-bin list (one global atomic per node and block instead of one per point)
+  constexpr int kKeyList = 2048;
+  const bool klist = !Cd && M <= kStreamMaxNodes / 2;
+  int32_t* kid = reinterpret_cast<int32_t*>(smin + kStreamMaxNodes);            // [kKeyList]
+  unsigned int* kmeta = reinterpret_cast<unsigned int*>(smax + kStreamMaxNodes);  // [kKeyList]
+  unsigned int* kcnt = reinterpret_cast<unsigned int*>(nbin + kStreamMaxNodes / 2);  // [512]
+  unsigned int* kbase = kcnt + kStreamMaxNodes / 2;                                  // [512]
+  __shared__ unsigned int kfill[1];
+  if (klist) {
+    for (int j = threadIdx.x; j < M; j += kStreamThreads) kcnt[j] = 0u;
+    if (threadIdx.x == 0) kfill[0] = 0u;
+    __syncthreads();
+  }
   // classify one point: child node index, or -1 when it went to the node's pivot-bin list.
   // kb = the value that is binned: the key itself, or (code mode) the key's 16-bit code; the
   // exact key is then read only where it decides something — pivot bin, margin bins.
@@ -2076,6 +2090,15 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     const int b = stream_bin(kb, g.lo, g.sc, B);
     const int pb = nb.pb;
     if (b == pb) {
+      if (klist) {  // parked in the LDS list, copied out after the pass (see the code-mode branch)
+        const unsigned int e = atomicAdd(&kfill[0], 1u);
+        if (e < (unsigned int)kKeyList) {
+          const unsigned int loc = atomicAdd(&kcnt[j], 1u);
+          kid[e] = (int32_t)i;
+          kmeta[e] = (loc << 16) | (unsigned int)j;
+          return -1;
+        }
+      }
       const unsigned int p = atomicAdd(&ndt[j].midcur, 1u);
       pl[nmidoff[j] + p] = (int32_t)i;
       pk[nmidoff[j] + p] = Cd ? Pl[i] : kb;
@@ -2279,6 +2302,20 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
         no[i] = (uint16_t)c;
         if (has_next && i < isamp) sample(c, Pn[i]);
       }
+    }
+  }
+  if (klist) {  // the block's pivot-bin points -> the nodes' global lists
+    __syncthreads();
+    for (int j = threadIdx.x; j < M; j += kStreamThreads)
+      if (kcnt[j]) kbase[j] = atomicAdd(&ndt[j].midcur, kcnt[j]);
+    __syncthreads();
+    const unsigned int ne = kfill[0] < (unsigned int)kKeyList ? kfill[0] : (unsigned int)kKeyList;
+    for (unsigned int e = threadIdx.x; e < ne; e += kStreamThreads) {
+      const unsigned int j = kmeta[e] & 0xffffu, loc = kmeta[e] >> 16;
+      const int32_t i = kid[e];
+      const unsigned int p = kbase[j] + loc;
+      pl[nmidoff[j] + p] = i;
+      pk[nmidoff[j] + p] = Pl[i];
     }
   }
   if (has_next && few) {
