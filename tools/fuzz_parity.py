@@ -8,8 +8,10 @@ kNN — more often."""
 import sys
 import time
 
-sys.path.insert(0, "rp-tree_amd/python")
-sys.path.insert(0, ".")
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path.insert(0, _os.path.join(_ROOT, "rp-tree_amd", "python"))
+sys.path.insert(0, _ROOT)
 import numpy as np
 
 import rptree_amd as rp

@@ -6,8 +6,10 @@ import os
 import sys
 import time
 
-sys.path.insert(0, "rp-tree_amd/python")
-sys.path.insert(0, ".")
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path.insert(0, _os.path.join(_ROOT, "rp-tree_amd", "python"))
+sys.path.insert(0, _ROOT)
 import numpy as np
 import torch
 
