@@ -94,6 +94,36 @@ def test_comm_init_rank_with_a_unique_id(rp, ctx, case):
     assert rp.project(X[:10], R[0, :1], ctx=ctx).shape == (1, 10)
 
 
+def test_comm_from_a_torch_process_group(rp, ctx, case):
+    """What bench.py does under torch.distributed.run: a gloo control plane, rank 0's RCCL id
+    broadcast through it, rpt_comm_init_rank on every rank (here a world of one process)."""
+    import os
+    import torch.distributed as dist
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = sharded.Comm.from_process_group(ctx)
+        assert (comm.nranks, comm.nlocal, comm.first_rank) == (1, 1, 0)
+        ds = rp.Dataset.dense(ctx, X)
+        qs = rp.Dataset.dense(ctx, Q[:20])
+        sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+        si, sd, sc = sf.knn([qs], 5)
+        plain, lo, nt = sf.local(0)
+        assert (lo, nt) == (0, R.shape[0])
+        pi, pd, pc = rp.knnBatch(5, plain, Q[:20])
+        assert np.array_equal(si, pi) and np.array_equal(sd, pd) and np.array_equal(sc, pc)
+        sf.close()
+        comm.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_comm_argument_errors(rp, ctx, case):
     from rptree_amd import _lib, sharded
     L_ = _lib.lib()
