@@ -214,6 +214,8 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                       const rpt_dataset* queries, int32_t k, int64_t* off_host, int32_t* ids_host,
                       double* dist_host, int64_t cap, int64_t* total);
 
+/* Dense f64 data: the distances returned are metricDDL2's own bits — the rows that reach a result
+ * are evaluated as the reference's left fold of (u - v)^2 — and the results are ordered by them. */
 /* knn (RPTree.hs:168-176) with distf = metricL2 (Internal.hs:318, metricDDL2 :403-406 /
  * true Euclidean distance for CSR data, evaluated as |q|^2 + sum over the row's nonzeros of
  * ((x_j - q_j)^2 - q_j^2): absolute error about 1e-8 |q|): per query the k best (distance, id), stable in

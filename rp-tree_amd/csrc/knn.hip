@@ -340,6 +340,20 @@ __device__ inline TA wave_sum(TA v) {
   return v;
 }
 
+// metricDDL2 exactly as the reference evaluates it (Internal.hs:403-406): a LEFT FOLD of
+// (u - v) ** 2 over the coordinates, then the root — one thread per row.  The batched distance
+// passes reduce a row by a lane butterfly (same value to ~1 ulp, different last bits); the few
+// rows that reach a result are evaluated again this way, so the distances that leave the
+// library carry the reference's bits and their order is the order of those values.
+__device__ inline double leftfold_distance(const double* __restrict__ x, const double* qs, int d) {
+  double acc = 0.0;
+  for (int j = 0; j < d; ++j) {
+    const double t = x[j] - qs[j];
+    acc = acc + t * t;
+  }
+  return sqrt(acc);
+}
+
 // dense data.  One block (256 threads) per query.  Candidate list given as ranges.
 // `identity`: the candidate list is the whole dataset in id order (brute force), perm unused.
 template <class TD>
@@ -414,6 +428,28 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
   if (filled > best || best == 0) {
     best = merge_best(buf, filled, k, dedup, scratch);
     __syncthreads();
+  }
+  if constexpr (std::is_same<TD, double>::value) {
+    // the results' distances again as the reference's left fold (leftfold_distance), the results
+    // in the order of those values (ties by candidate position)
+    double* lf = reinterpret_cast<double*>(scratch);  // [kBuf] ints = kBuf / 2 doubles >= k
+    for (int i = threadIdx.x; i < best; i += blockDim.x)
+      lf[i] = leftfold_distance(X + (int64_t)buf[i].id * d, qs, d);
+    __syncthreads();
+    for (int i = threadIdx.x; i < best; i += blockDim.x) {
+      const double di = lf[i];
+      const int pi = buf[i].pos;
+      int rank = 0;
+      for (int j = 0; j < best; ++j) rank += lf[j] < di || (lf[j] == di && buf[j].pos < pi);
+      out_ids[q * k + rank] = buf[i].id;
+      out_dist[q * k + rank] = di;
+    }
+    for (int i = best + threadIdx.x; i < k; i += blockDim.x) {
+      out_ids[q * k + i] = -1;
+      out_dist[q * k + i] = __longlong_as_double(0x7ff0000000000000LL);
+    }
+    if (threadIdx.x == 0) out_cnt[q] = best;
+    return;
   }
   for (int i = threadIdx.x; i < k; i += blockDim.x) {
     const bool ok = i < best;
@@ -1116,7 +1152,12 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       cpos[i] = bpos[i];
     }
     __syncthreads();
-    batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, wave, 4, lane);
+    if constexpr (std::is_same<TD, double>::value) {
+      for (int i = tid; i < m; i += 256)  // the reference's own arithmetic for the kept rows
+        cdist[i] = leftfold_distance(X + (int64_t)cid[i] * d, qs, d);
+    } else {
+      batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, wave, 4, lane);
+    }
     __syncthreads();
     best = select(m, k, 0);
     if (cut && best > 0) {
@@ -1135,6 +1176,27 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
         return;
       }
     }
+  }
+  if constexpr (!PRE32 && !CSR && std::is_same<TD, double>::value) {
+    // f64 rows ranked on butterfly sums: the results' distances again as the reference's left
+    // fold, and the results in the order of THOSE values (ties by candidate position)
+    __syncthreads();
+    for (int i = tid; i < best; i += 256) cdist[i] = leftfold_distance(X + (int64_t)bid[i] * d, qs, d);
+    __syncthreads();
+    for (int i = tid; i < best; i += 256) {
+      const double di = cdist[i];
+      const int pi = bpos[i];
+      int rank = 0;
+      for (int j = 0; j < best; ++j) rank += cdist[j] < di || (cdist[j] == di && bpos[j] < pi);
+      out_ids[q * k + rank] = bid[i];
+      out_dist[q * k + rank] = di;
+    }
+    for (int i = best + tid; i < k; i += 256) {
+      out_ids[q * k + i] = -1;
+      out_dist[q * k + i] = __longlong_as_double(0x7ff0000000000000LL);
+    }
+    if (tid == 0) out_cnt[q] = best;
+    return;
   }
   for (int i = tid; i < k; i += 256) {
     const bool ok = i < best;
@@ -1404,7 +1466,12 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
     for (int i = lane; i < m; i += 64) cid[i] = bid[i];
     wave_sync();
-    batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, 0, 1, lane);
+    if constexpr (std::is_same<TD, double>::value) {
+      for (int i = lane; i < m; i += 64)  // the reference's own arithmetic (leftfold_distance)
+        cdist[i] = leftfold_distance(X + (int64_t)cid[i] * d, qs, d);
+    } else {
+      batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, 0, 1, lane);
+    }
     wave_sync();
     best = wselect(m, m, 0, k, 0);
     if (cut && best > 0) {
@@ -1418,6 +1485,25 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
         return;
       }
     }
+  }
+  if constexpr (!PRE32 && std::is_same<TD, double>::value) {  // see knn_fused_kernel
+    wave_sync();
+    for (int i = lane; i < best; i += 64) cdist[i] = leftfold_distance(X + (int64_t)bid[i] * d, qs, d);
+    wave_sync();
+    for (int i = lane; i < best; i += 64) {
+      const double di = cdist[i];
+      const int pi = bpos[i];
+      int rank = 0;
+      for (int j = 0; j < best; ++j) rank += cdist[j] < di || (cdist[j] == di && bpos[j] < pi);
+      out_ids[q * k + rank] = bid[i];
+      out_dist[q * k + rank] = di;
+    }
+    for (int i = best + lane; i < k; i += 64) {
+      out_ids[q * k + i] = -1;
+      out_dist[q * k + i] = kInf;
+    }
+    if (lane == 0) out_cnt[q] = best;
+    return;
   }
   for (int i = lane; i < k; i += 64) {
     const bool ok = i < best;

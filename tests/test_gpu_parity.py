@@ -313,7 +313,7 @@ def test_knn_matches_oracle(rp, small_forest, oracle, k):
         wi, wd = oracle.knn_dense(fo, X, Q[i], k)
         assert cnt[i] == len(wi)
         assert np.array_equal(ids[i, :cnt[i]], wi), i       # duplicates kept, same order
-        assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=0)
+        assert np.array_equal(dist[i, :cnt[i]], wd)   # the reference's bits
     # single-query reference-shaped call
     hits = rp.knn(rp.metricL2, k, f, rp.fromListDv(Q[0]))
     assert [h[1] for h in hits] == oracle.knn_dense(fo, X, Q[0], k)[0].tolist()
@@ -360,7 +360,7 @@ def test_brute_knn(rp, small_forest, oracle):
     for i in range(8):
         wi, wd = oracle.brute_knn_dense(X, Q[i], 10)
         assert np.array_equal(ids[i], wi)
-        assert np.allclose(dist[i], wd, rtol=1e-12)
+        assert np.array_equal(dist[i], wd)
 
 
 def test_knn_csr(rp, ctx, oracle):
