@@ -1612,6 +1612,19 @@ __global__ __launch_bounds__(256) void dist_sel_dense_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int j = threadIdx.x; j < d; j += blockDim.x) qs[j] = ld<TD>(Q + q * d + j);
   __syncthreads();
+  if constexpr (std::is_same<TD, double>::value) {
+    // knnH returns whole buckets: every point's distance as metricDDL2's left fold (one thread per
+    // point; see leftfold_distance)
+    for (int64_t r = sel_off[q]; r < sel_off[q + 1]; ++r) {
+      const Range rg = sel[r];
+      for (int i = threadIdx.x; i < rg.n; i += blockDim.x) {
+        const int id = perm[rg.poff + i];
+        out_ids[out_off[q] + rg.pos + i] = id;
+        out_dist[out_off[q] + rg.pos + i] = leftfold_distance(X + (int64_t)id * d, qs, d);
+      }
+    }
+    return;
+  }
   for (int64_t r = sel_off[q]; r < sel_off[q + 1]; ++r) {
     const Range rg = sel[r];
     for (int i = wave; i < rg.n; i += 4) {

@@ -728,7 +728,7 @@ def test_knnh_matches_oracle(rp, ctx, small_forest, oracle):
             wi, wd = oracle.knn_h_dense(fo, X, Q[i], k)
             got = ids[off[i]:off[i + 1]]
             assert np.array_equal(got, wi), (k, i)
-            assert np.allclose(dist[off[i]:off[i + 1]], wd, rtol=1e-12)
+            assert np.array_equal(dist[off[i]:off[i + 1]], wd)   # the reference's bits
     hits = rp.knnH(rp.metricL2, 10, f, Q[0])
     wi, wd = oracle.knn_h_dense(fo, X, Q[0], 10)
     assert [i for _, i in hits] == wi.tolist()
