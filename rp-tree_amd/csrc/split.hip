@@ -2069,10 +2069,14 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   }
   // 8-byte-key mode with at most 512 nodes: the upper halves of nbin / smin / smax are unused and
   // hold the block's pivot-bin list (one global atomic per node and block instead of one per point)
-  constexpr int kKeyList = 2048;
+  // (the list itself: 4096 entries of its own — a block of the one-block-per-CU grid sees ~2000
+  // pivot-bin points per level at C2)
+  constexpr int kKeyList = 4096;
+  __shared__ int32_t list_id[kKeyList];
+  __shared__ unsigned int list_meta[kKeyList];
   const bool klist = !Cd && M <= kStreamMaxNodes / 2;
-  int32_t* kid = reinterpret_cast<int32_t*>(smin + kStreamMaxNodes);            // [kKeyList]
-  unsigned int* kmeta = reinterpret_cast<unsigned int*>(smax + kStreamMaxNodes);  // [kKeyList]
+  int32_t* kid = list_id;
+  unsigned int* kmeta = list_meta;
   unsigned int* kcnt = reinterpret_cast<unsigned int*>(nbin + kStreamMaxNodes / 2);  // [512]
   unsigned int* kbase = kcnt + kStreamMaxNodes / 2;                                  // [512]
   __shared__ unsigned int kfill[1];
@@ -2128,12 +2132,11 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   if (Cd) {  // code mode: eight points per thread and step, 16-byte code and node loads / stores
     const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
     const uint16_t* Cn = has_next ? Cl + N : Cl;
-    // LDS that code mode leaves unused holds the pivot list: nbin (16 KB) and the upper halves of
-    // smin / smax (the sampling cells are 32-bit here)
-    constexpr int kAssignList = 2048;
-    static_assert(sizeof(nbin) >= (size_t)kAssignList * 8, "pivot list overlays nbin");
-    int32_t* lid = reinterpret_cast<int32_t*>(nbin);                   // [kAssignList]
-    unsigned int* lmeta = reinterpret_cast<unsigned int*>(nbin) + kAssignList;
+    // the pivot list's per-node counters live in LDS that code mode leaves unused: the upper halves
+    // of smin / smax (the sampling cells are 32-bit here)
+    constexpr int kAssignList = kKeyList;
+    int32_t* lid = list_id;              // [kAssignList]
+    unsigned int* lmeta = list_meta;
     unsigned int* lcnt = reinterpret_cast<unsigned int*>(smin + kStreamMaxNodes);   // [kStreamMaxNodes]
     unsigned int* lbase = reinterpret_cast<unsigned int*>(smax + kStreamMaxNodes);  // [kStreamMaxNodes]
     __shared__ unsigned int lfill[1];
@@ -3314,7 +3317,11 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     const int64_t per = (((N + nblk - 1) / nblk) + 7) & ~(int64_t)7;  // multiple of 8, <= 65534
     const dim3 sgrid((unsigned)nblk, (unsigned)T);
     // assign pass: no per-block table to flush, fill the chip
-    const int64_t afac = ctx->opt.tune0 > 0 ? ctx->opt.tune0 : 2;
+    // blocks per CU of stream_assign: ONE since the pivot-bin points go through the LDS list (every
+    // block flushes 2 M range cells with global atomics and loads M node records: fewer blocks, less
+    // of both — 4-tree shard 1.28 -> 1.23 ms, 8 trees 1.79 -> 1.74, 32 trees unchanged; two were
+    // better while the pass waited on a returning atomic per pivot point)
+    const int64_t afac = ctx->opt.tune0 > 0 ? ctx->opt.tune0 : 1;
     int64_t nblkA = (afac * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblkA > (N + 8191) / 8192) nblkA = (N + 8191) / 8192;
     if (nblkA < 1) nblkA = 1;
