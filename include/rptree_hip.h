@@ -102,6 +102,10 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
  *   knn_wave (-1 auto, 0, 1), knn_kp, knn_no_pre32, knn_csr_pre32, knn_general
  *       query kernels
+ *   comm_force_exchange            sharded kNN on a ONE-rank communicator still runs record ->
+ *                                  ncclAllGather -> merge (set on the communicator's first ctx)
+ *   comm_inject_failure            test hook: the device's shard reports a failure (see "Failures"
+ *                                  under the multi-GPU entry points)
  *   debug_host, debug_stamps       stderr diagnostics
  * Unknown names: RPT_E_ARG. */
 int32_t rpt_ctx_set_option(rpt_ctx* ctx, const char* name, int64_t value);
@@ -250,7 +254,8 @@ int32_t rpt_knn_merge_dev(rpt_ctx* ctx, const int32_t* ids_dev, const double* di
                           int32_t* out_count_dev);
 /* the same merge over G packed exchange records (ONE all-gather instead of three): a shard
  * writes its rpt_knn_dev results into one record — distances at off_dist, ids at off_ids,
- * counts at off_count, `bytes` in all (rpt_knn_record_layout; a multiple of 16) — the records
+ * counts at off_count, then ONE int32 status word (0 = the shard answered; anything else = it
+ * failed and its lists are void), `bytes` in all (rpt_knn_record_layout; a multiple of 16) — the records
  * of all shards are gathered back to back (record_bytes apart, shard-major), and
  * rpt_knn_merge_records_dev merges them exactly like rpt_knn_merge_dev. */
 int32_t rpt_knn_record_layout(int64_t nq, int32_t k, int64_t* bytes, int64_t* off_dist,
@@ -276,7 +281,15 @@ int32_t rpt_knn_merge_records_dev(rpt_ctx* ctx, const void* records_dev, int64_t
  * with rpt_comm_unique_id and the host distributes its RPT_COMM_UID_BYTES bytes, e.g. through
  * the launcher's store).  Per-device arguments (ds, data, queries, outputs) are arrays of
  * `nlocal` entries, entry g living on the device of rpt_comm_ctx(comm, g): n entries after
- * rpt_comm_init(n), one after rpt_comm_init_rank. */
+ * rpt_comm_init(n), one after rpt_comm_init_rank.
+ *
+ * Failures.  With one process per device a rank's error code is invisible to its peers, so a rank
+ * whose query kernels fail still joins the all-gather — its record's status word set — and returns
+ * its own error; every rank scans the gathered status words after the merge: if one is set, all
+ * counts of the answer are -1 and the next rpt_comm_sync (rpt_knn_sharded calls it) returns
+ * RPT_E_INTERNAL naming the rank.  A rank that cannot join at all (no memory for its record, the
+ * collective cannot be enqueued) aborts its communicator (ncclCommAbort): peers see a failed
+ * collective instead of a hang, and every later call on the communicator returns RPT_E_INTERNAL. */
 #define RPT_COMM_UID_BYTES 128
 typedef struct rpt_comm rpt_comm;
 typedef struct rpt_sharded_forest rpt_sharded_forest;

@@ -129,10 +129,15 @@ struct FlatTree {
 
 // Internal.hs:258-297 `insert` on an empty Tip (= batch `create`, :223-225), recursion
 // restated over id lists.  `ids` holds the node's points in the node's current order.
+// `par` > 1 = host threads this node may use.  It changes nothing the reference computes: the
+// n inner products of :504 are independent of each other (they are split over the threads, each
+// one the scalar loop), and the two recursive calls of :296-297 write disjoint subtrees (the
+// left one goes to a second thread).  The sort stays the single-threaded stable sort.
 template <class Data>
 void build_node(const Data& D, const std::vector<SparseVec>& rvs /*L vectors of this tree*/,
                 int32_t L, int32_t minLeaf, int32_t level, int64_t heap, int64_t off,
-                std::vector<int32_t>& ids, FlatTree& ft, double* proj_tree /*[L][N] or null*/) {
+                std::vector<int32_t>& ids, FlatTree& ft, double* proj_tree /*[L][N] or null*/,
+                int32_t par = 1) {
   const int64_t n = (int64_t)ids.size();
   if (is_leaf(level, n, L, minLeaf)) {  // :289-290 Tip () xs'
     for (int64_t i = 0; i < n; ++i) ft.perm[off + i] = ids[i];
@@ -141,10 +146,20 @@ void build_node(const Data& D, const std::vector<SparseVec>& rvs /*L vectors of 
   // partitionAtMedian r xs, Internal.hs:491-505
   const SparseVec& r = rvs[level];  // :270 rvs ! ixLev
   std::vector<std::pair<double, int32_t>> projs((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {  // :504 map (\xe -> (xe, r `inner` eEmbed xe))
-    double p = D.inner(r, ids[i]);
-    projs[i] = {p, ids[i]};
-    if (proj_tree) proj_tree[(int64_t)level * D.N + ids[i]] = p;
+  auto project = [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; ++i) {  // :504 map (\xe -> (xe, r `inner` eEmbed xe))
+      double p = D.inner(r, ids[i]);
+      projs[i] = {p, ids[i]};
+      if (proj_tree) proj_tree[(int64_t)level * D.N + ids[i]] = p;
+    }
+  };
+  if (par > 1 && n >= 65536) {
+    std::vector<std::thread> pool;
+    for (int32_t w = 1; w < par; ++w) pool.emplace_back(project, n * w / par, n * (w + 1) / par);
+    project(0, n / par);
+    for (std::thread& th : pool) th.join();
+  } else {
+    project(0, n);
   }
   // :504,509-512 sortByVG snd = STABLE merge sort, `comparing` on Double (-0.0 == 0.0)
   std::stable_sort(projs.begin(), projs.end(),
@@ -170,6 +185,15 @@ void build_node(const Data& D, const std::vector<SparseVec>& rvs /*L vectors of 
   for (int64_t i = nh; i < n; ++i) rr[i - nh] = projs[i].second;
   std::vector<std::pair<double, int32_t>>().swap(projs);
   std::vector<int32_t>().swap(ids);
+  if (par > 1) {
+    const int32_t pl = par / 2, pr = par - pl;
+    std::thread left([&] {
+      build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 1, off, ll, ft, proj_tree, pl);  // :296
+    });
+    build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 2, off + nh, rr, ft, proj_tree, pr);  // :297
+    left.join();
+    return;
+  }
   build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 1, off, ll, ft, proj_tree);       // :296
   build_node(D, rvs, L, minLeaf, level + 1, 2 * heap + 2, off + nh, rr, ft, proj_tree);  // :297
 }
@@ -186,6 +210,8 @@ void forest_build(const Data& D, const double* R, int32_t T, int32_t L, int32_t 
   const int64_t nodes = ((int64_t)1 << L) - 1;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   std::vector<SparseVec> all = sparsify(R, T, L, D.d);
+  // more threads than trees: the surplus works INSIDE the trees (see build_node's `par`)
+  const int32_t par = threads > T ? threads / (T > 0 ? T : 1) : 1;
   auto one_tree = [&](int32_t t) {  // create, Internal.hs:217-225
     for (int64_t h = 0; h < nodes; ++h)
       thr[t * nodes + h] = mglo[t * nodes + h] = mghi[t * nodes + h] = nan;
@@ -194,7 +220,7 @@ void forest_build(const Data& D, const double* R, int32_t T, int32_t L, int32_t 
     for (int64_t i = 0; i < D.N; ++i) ids[i] = (int32_t)i;  // dataset in input order
     FlatTree ft{perm + (int64_t)t * D.N, thr + t * nodes, mglo + t * nodes, mghi + t * nodes};
     build_node(D, rvs, L, minLeaf, 0, 0, 0, ids, ft,
-               proj_out ? proj_out + (int64_t)t * L * D.N : nullptr);
+               proj_out ? proj_out + (int64_t)t * L * D.N : nullptr, par);
   };
   if (threads <= 1 || T <= 1) {
     for (int32_t t = 0; t < T; ++t) one_tree(t);  // createMulti, ascending key

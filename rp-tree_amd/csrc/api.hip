@@ -214,6 +214,8 @@ const OptDesc kOptions[] = {
     {"knn_no_pre32", &rpt_options::knn_no_pre32},
     {"knn_csr_pre32", &rpt_options::knn_csr_pre32},
     {"knn_general", &rpt_options::knn_general},
+    {"comm_force_exchange", &rpt_options::comm_force_exchange},
+    {"comm_inject_failure", &rpt_options::comm_inject_failure},
     {"tune0", &rpt_options::tune0},
     {"tune1", &rpt_options::tune1},
     {"tune2", &rpt_options::tune2},
@@ -988,7 +990,8 @@ int32_t rpt_knn_record_layout(int64_t nq, int32_t k, int64_t* bytes, int64_t* of
     *off_dist = 0;
     *off_ids = nq * k * 8;
     *off_count = nq * k * 12;
-    *bytes = (nq * k * 12 + nq * 4 + 15) & ~(int64_t)15;
+    // + the shard's status word (int32 behind the counts, 0 = ok), rounded to 16 bytes
+    *bytes = (nq * k * 12 + nq * 4 + 4 + 15) & ~(int64_t)15;
     return RPT_OK;
   });
 }

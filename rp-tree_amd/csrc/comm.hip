@@ -16,7 +16,18 @@
 //   rpt_comm_init_rank(ctx,..)  one process per device (launchers such as torch.distributed.run):
 //                               ncclCommInitRank with an id made by rpt_comm_unique_id on rank 0
 // The collective is enqueued on the ctx streams, behind the kernels that fill the exchange
-// records and ahead of the merge: no host synchronisation between the three.
+// records and ahead of the merge.  The shard's query kernels synchronise their stream once (they
+// read back the overflow / uncertified counters, knn.hip knn_dev); the collective, the merge and
+// the status check that follow are asynchronous: rpt_comm_sync is the second and last host wait.
+//
+// Failure protocol (one process per GPU: the peers have no way to see a local error code).  Every
+// record carries a status word behind its counts (rpt_knn_record_layout).  A rank whose query
+// kernels fail STILL enqueues the all-gather, with its status word poisoned, and returns its
+// error; after the merge every rank scans the gathered status words: if one is set, every count of
+// the answer becomes -1 and the next rpt_comm_sync (rpt_knn_sharded calls it) fails with
+// RPT_E_INTERNAL naming the rank.  A rank that cannot even hold its record (allocation failure)
+// or whose collective cannot be enqueued aborts its communicator (ncclCommAbort): the peers'
+// collective then fails instead of hanging, and the communicator is dead on every rank.
 #include <rccl/rccl.h>
 
 #include <condition_variable>
@@ -106,8 +117,13 @@ struct Exchange {
   int64_t nq = -1;
   int32_t k = -1;
   int64_t bytes = 0, off_dist = 0, off_ids = 0, off_count = 0;
+  int64_t off_status = 0;
   DevBuf<char> record;    // this shard's result (rpt_knn_record_layout)
   DevBuf<char> gathered;  // [nranks][bytes]
+  DevBuf<int32_t> failed; // device: 1 + the first rank whose status word is set, 0 = none
+  int32_t* failed_host = nullptr;  // pinned copy, valid after the stream is synchronised
+  bool poisoned = false;  // the record's status word is currently non-zero
+  bool check = false;     // an exchange ran since the last rpt_comm_sync
 };
 
 }  // namespace
@@ -115,6 +131,7 @@ struct Exchange {
 struct rpt_comm {
   int32_t nranks = 0, nlocal = 0, first_rank = 0;
   bool owns_ctx = false;
+  bool dead = false;  // aborted after an unrecoverable local failure (see the failure protocol)
   std::vector<rpt_ctx*> ctx;
   std::vector<ncclComm_t> comm;
   std::vector<Worker*> workers;  // nlocal > 1 only
@@ -177,14 +194,46 @@ void tree_block(int32_t T, int32_t G, int32_t r, int32_t* lo, int32_t* hi) {
 int32_t ensure_exchange(rpt_comm* c, int g, int64_t nq, int32_t k) {
   Exchange& e = *c->ex[(size_t)g];
   if (e.nq == nq && e.k == k) return RPT_OK;
+  e.nq = -1;
   RPT_TRY(rpt_knn_record_layout(nq, k, &e.bytes, &e.off_dist, &e.off_ids, &e.off_count));
+  e.off_status = e.off_count + nq * 4;  // the int32 behind the counts
   RPT_TRY(e.record.alloc((size_t)e.bytes));
   RPT_TRY(e.gathered.alloc((size_t)e.bytes * c->nranks));
-  // the tail padding of a record is gathered too: give it defined bytes once
+  if (!e.failed.p) RPT_TRY(e.failed.alloc(1));
+  if (!e.failed_host) {
+    RPT_HIP(hipHostMalloc((void**)&e.failed_host, 64, hipHostMallocDefault));
+    *e.failed_host = 0;
+  }
+  // the status word and the tail padding of a record are gathered too: defined bytes, once
   RPT_HIP(hipMemsetAsync(e.record.p, 0, (size_t)e.bytes, c->ctx[g]->stream));
+  e.poisoned = false;
   e.nq = nq;
   e.k = k;
   return RPT_OK;
+}
+
+// after the merge: any status word set among the G gathered records -> every count of the answer
+// becomes -1 and *failed = 1 + that rank
+__global__ void exchange_status_kernel(const char* __restrict__ gathered, int64_t record_bytes,
+                                       int64_t off_status, int G, int64_t nq,
+                                       int32_t* __restrict__ out_count,
+                                       int32_t* __restrict__ failed) {
+  int bad = 0;
+  for (int g = G - 1; g >= 0; --g)
+    if (*reinterpret_cast<const int32_t*>(gathered + g * record_bytes + off_status) != 0) bad = g + 1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *failed = bad;
+  if (bad && i < nq) out_count[i] = -1;
+}
+
+// unrecoverable local failure: the peers must not wait for a collective this rank will not join
+void abort_comm(rpt_comm* c) {
+  for (ncclComm_t& x : c->comm)
+    if (x) {
+      (void)ncclCommAbort(x);
+      x = nullptr;
+    }
+  c->dead = true;
 }
 
 void destroy_comm(rpt_comm* c) {
@@ -203,6 +252,9 @@ void destroy_comm(rpt_comm* c) {
     if (g < (int)c->ex.size() && c->ex[(size_t)g]) {
       c->ex[(size_t)g]->record.release();
       c->ex[(size_t)g]->gathered.release();
+      c->ex[(size_t)g]->failed.release();
+      if (c->ex[(size_t)g]->failed_host) (void)hipHostFree(c->ex[(size_t)g]->failed_host);
+      c->ex[(size_t)g]->failed_host = nullptr;
     }
     if (g < (int)c->comm.size() && c->comm[g]) (void)ncclCommDestroy(c->comm[g]);
   }
@@ -325,6 +377,17 @@ int32_t rpt_comm_sync(rpt_comm* comm) {
   return guarded([&]() -> int32_t {
     RPT_ARG(comm, "comm is NULL");
     for (rpt_ctx* x : comm->ctx) RPT_TRY(rpt_ctx_sync(x));
+    // the status words of the exchanges since the last sync (failure protocol, top of this file)
+    int32_t bad = 0;
+    for (auto& e : comm->ex)
+      if (e && e->check) {
+        e->check = false;
+        if (e->failed_host && *e->failed_host && !bad) bad = *e->failed_host;
+      }
+    if (bad)
+      return fail(RPT_E_INTERNAL, "sharded kNN: rank " + std::to_string(bad - 1) +
+                                      " failed to answer the batch (its own call returned the "
+                                      "error); the merged answer is invalid, every count is -1");
     return RPT_OK;
   });
 }
@@ -405,46 +468,102 @@ int32_t rpt_knn_sharded_dev(rpt_comm* comm, rpt_sharded_forest* sf,
               "NULL per-device argument");
       RPT_ARG(queries[g]->n == nq, "the replicas of the query batch differ in size");
     }
+    if (comm->dead)
+      return fail(RPT_E_INTERNAL, "the communicator was aborted after a local failure");
+    if (nq == 0) return RPT_OK;
+    // a one-rank communicator has nothing to exchange — unless comm_force_exchange asks for the
+    // full data path (record -> ncclAllGather -> merge), which is how the exchange is exercised
+    // on a one-GPU box
+    const bool exchange = comm->nranks > 1 || comm->ctx[0]->opt.comm_force_exchange != 0;
     // (1) every device answers the batch from its own trees into its exchange record
-    RPT_TRY(run_all(comm, [&](int g) -> int32_t {
-      rpt_ctx* ctx = comm->ctx[(size_t)g];
-      RPT_HIP(hipSetDevice(ctx->device));
-      dev_set_stream(ctx->stream);
-      RPT_TRY(ensure_exchange(comm, g, nq, k));
-      Exchange& e = *comm->ex[(size_t)g];
-      int32_t* rid = reinterpret_cast<int32_t*>(e.record.p + e.off_ids);
-      double* rdist = reinterpret_cast<double*>(e.record.p + e.off_dist);
-      int32_t* rcnt = reinterpret_cast<int32_t*>(e.record.p + e.off_count);
-      RPT_TRY(rpt_knn_dev(ctx, sf->local[(size_t)g], data[g], queries[g], k, flags, rid, rdist, rcnt));
-      if (comm->nranks == 1) {  // nothing to exchange: the record is the answer
-        if (nq) {
+    std::vector<int32_t> st((size_t)comm->nlocal, RPT_OK), have((size_t)comm->nlocal, 0);
+    std::vector<std::string> msg((size_t)comm->nlocal);
+    (void)run_all(comm, [&](int g) -> int32_t {
+      auto body = [&]() -> int32_t {
+        rpt_ctx* ctx = comm->ctx[(size_t)g];
+        RPT_HIP(hipSetDevice(ctx->device));
+        dev_set_stream(ctx->stream);
+        RPT_TRY(ensure_exchange(comm, g, nq, k));
+        have[(size_t)g] = 1;
+        Exchange& e = *comm->ex[(size_t)g];
+        if (e.poisoned) {
+          RPT_HIP(hipMemsetAsync(e.record.p + e.off_status, 0, 4, ctx->stream));
+          e.poisoned = false;
+        }
+        int32_t* rid = reinterpret_cast<int32_t*>(e.record.p + e.off_ids);
+        double* rdist = reinterpret_cast<double*>(e.record.p + e.off_dist);
+        int32_t* rcnt = reinterpret_cast<int32_t*>(e.record.p + e.off_count);
+        if (ctx->opt.comm_inject_failure)  // test hook of the failure protocol
+          return fail(RPT_E_INTERNAL, "comm_inject_failure: this rank pretends its query kernels failed");
+        RPT_TRY(rpt_knn_dev(ctx, sf->local[(size_t)g], data[g], queries[g], k, flags, rid, rdist, rcnt));
+        if (!exchange) {  // the record is the answer
           RPT_HIP(hipMemcpyAsync(ids_dev[g], rid, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, ctx->stream));
           RPT_HIP(hipMemcpyAsync(dist_dev[g], rdist, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, ctx->stream));
           RPT_HIP(hipMemcpyAsync(count_dev[g], rcnt, (size_t)nq * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
-      }
+        return RPT_OK;
+      };
+      st[(size_t)g] = body();
+      if (st[(size_t)g] != RPT_OK) msg[(size_t)g] = rpt_last_error();
       return RPT_OK;
-    }));
-    if (comm->nranks == 1 || nq == 0) return RPT_OK;
-    // (2) ONE all-gather of the records, enqueued behind the kernels on every ctx stream
-    if (comm->nlocal > 1) RPT_NCCL(ncclGroupStart());
+    });
+    int32_t first = RPT_OK;
+    std::string first_msg;
+    for (int g = 0; g < comm->nlocal; ++g)
+      if (st[(size_t)g] != RPT_OK && first == RPT_OK) {
+        first = st[(size_t)g];
+        first_msg = "device " + std::to_string(comm->ctx[(size_t)g]->device) + ": " + msg[(size_t)g];
+      }
+    if (!exchange) return first == RPT_OK ? RPT_OK : fail(first, first_msg);
+    // a failed device still joins the collective, with its record's status word poisoned; one
+    // that holds no record cannot: the communicator is aborted so that no peer waits for it
     for (int g = 0; g < comm->nlocal; ++g) {
-      Exchange& e = *comm->ex[(size_t)g];
-      const ncclResult_t r = ncclAllGather(e.record.p, e.gathered.p, (size_t)e.bytes, ncclUint8,
-                                           comm->comm[(size_t)g], comm->ctx[(size_t)g]->stream);
-      if (r != ncclSuccess) {
-        if (comm->nlocal > 1) (void)ncclGroupEnd();
-        return nccl_fail("ncclAllGather", r);
+      if (st[(size_t)g] == RPT_OK) continue;
+      bool ok = have[(size_t)g] != 0;
+      if (ok) {
+        Exchange& e = *comm->ex[(size_t)g];
+        (void)hipSetDevice(comm->ctx[(size_t)g]->device);
+        (void)hipGetLastError();
+        ok = hipMemsetAsync(e.record.p + e.off_status, 0xff, 4, comm->ctx[(size_t)g]->stream) == hipSuccess;
+        e.poisoned = true;
+      }
+      if (!ok) {
+        abort_comm(comm);
+        return fail(first, first_msg + " (no exchange record: communicator aborted)");
       }
     }
-    if (comm->nlocal > 1) RPT_NCCL(ncclGroupEnd());
-    // (3) k-way merge in (distance, shard, rank) order on every device, behind the collective
+    // (2) ONE all-gather of the records, enqueued behind the kernels on every ctx stream
+    ncclResult_t nr = ncclSuccess;
+    if (comm->nlocal > 1) nr = ncclGroupStart();
+    for (int g = 0; g < comm->nlocal && nr == ncclSuccess; ++g) {
+      Exchange& e = *comm->ex[(size_t)g];
+      nr = ncclAllGather(e.record.p, e.gathered.p, (size_t)e.bytes, ncclUint8,
+                         comm->comm[(size_t)g], comm->ctx[(size_t)g]->stream);
+    }
+    if (comm->nlocal > 1) {
+      const ncclResult_t ge = ncclGroupEnd();
+      if (nr == ncclSuccess) nr = ge;
+    }
+    if (nr != ncclSuccess) {  // some devices may have joined, others not: nothing to salvage
+      abort_comm(comm);
+      return nccl_fail("ncclAllGather (communicator aborted)", nr);
+    }
+    // (3) k-way merge in (distance, shard, rank) order on every device, behind the collective,
+    // then the scan of the gathered status words
     for (int g = 0; g < comm->nlocal; ++g) {
       Exchange& e = *comm->ex[(size_t)g];
-      RPT_TRY(rpt_knn_merge_records_dev(comm->ctx[(size_t)g], e.gathered.p, e.bytes, comm->nranks,
-                                        nq, k, flags, ids_dev[g], dist_dev[g], count_dev[g]));
+      rpt_ctx* ctx = comm->ctx[(size_t)g];
+      RPT_TRY(rpt_knn_merge_records_dev(ctx, e.gathered.p, e.bytes, comm->nranks, nq, k, flags,
+                                        ids_dev[g], dist_dev[g], count_dev[g]));
+      RPT_HIP(hipSetDevice(ctx->device));
+      hipLaunchKernelGGL(exchange_status_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0,
+                         ctx->stream, e.gathered.p, e.bytes, e.off_status, comm->nranks, nq,
+                         count_dev[g], e.failed.p);
+      RPT_HIP(hipGetLastError());
+      RPT_HIP(hipMemcpyAsync(e.failed_host, e.failed.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+      e.check = true;
     }
-    return RPT_OK;
+    return first == RPT_OK ? RPT_OK : fail(first, first_msg);
   });
 }
 
@@ -471,7 +590,13 @@ int32_t rpt_knn_sharded(rpt_comm* comm, rpt_sharded_forest* sf, const rpt_datase
       pc[(size_t)g] = cnt[(size_t)g].p;
     }
     int32_t s = rpt_knn_sharded_dev(comm, sf, data, queries, k, flags, pi.data(), pd.data(), pc.data());
-    if (s == RPT_OK) s = rpt_comm_sync(comm);
+    if (s == RPT_OK) {
+      s = rpt_comm_sync(comm);  // also reports a PEER's failure (status words of the records)
+    } else if (!comm->dead) {   // the collective this rank joined with a poisoned record drains
+      const std::string keep = rpt_last_error();
+      (void)rpt_comm_sync(comm);
+      set_error(keep);
+    }
     if (s == RPT_OK && nq) {  // every device holds the same merged answer: read device 0's
       RPT_HIP(hipSetDevice(comm->ctx[0]->device));
       RPT_HIP(hipMemcpy(ids_host, pi[0], (size_t)nq * k * 4, hipMemcpyDeviceToHost));

@@ -128,6 +128,8 @@ struct rpt_options {
   int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
   int64_t knn_csr_pre32 = 0;    // kNN: rank CSR f64 rows on their (u16 column, f32 value) shadow
   int64_t knn_general = 0;      // kNN: unfused general path
+  int64_t comm_force_exchange = 0;  // sharded kNN: a one-rank communicator runs record -> all-gather -> merge too
+  int64_t comm_inject_failure = 0;  // sharded kNN (test hook): this device's shard reports a failure
   int64_t tune0 = 0, tune1 = 0, tune2 = 0, tune3 = 0;  // experiment hooks (0 = the built-in choice)
   int64_t debug_host = 0;       // stderr: host-side phase times of a build
   int64_t debug_stamps = 0;     // device time stamps of the wave kernel

@@ -124,6 +124,95 @@ def test_comm_from_a_torch_process_group(rp, ctx, case):
             dist.destroy_process_group()
 
 
+def test_forced_exchange_runs_allgather_and_merge_on_one_rank(rp, ctx, case):
+    """comm_force_exchange: a ONE-rank communicator takes the whole multi-GPU data path — record ->
+    ncclAllGather on the ctx stream -> rpt_knn_merge_records_dev on the gathered buffer -> status
+    scan — instead of returning the record.  Result == rpt_knn_dev, bit for bit, for duplicates
+    kept / de-duplicated and nq in {0, 1, 10 000} (RPTree.hs:174-176)."""
+    import torch
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    k = 10
+    Qbig = np.concatenate([Q] * 34)[:10_000] * np.linspace(0.97, 1.03, 10_000)[:, None]
+    for style in ("init", "init_rank"):
+        if style == "init":
+            comm = sharded.Comm.local(1)
+            c0 = comm.contexts[0]
+        else:
+            comm = sharded.Comm.rank(ctx, 1, 0, sharded.Comm.unique_id())
+            c0 = ctx
+        old = c0.set_option("comm_force_exchange", 1)
+        try:
+            ds = rp.Dataset.dense(c0, X)
+            sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+            plain, _, _ = sf.local(0)
+            for nq in (0, 1, 10_000):
+                qs = rp.Dataset.dense(c0, Qbig[:nq].reshape(nq, X.shape[1]))
+                oi = torch.full((max(nq, 1), k), -7, dtype=torch.int32, device="cuda")
+                od = torch.zeros((max(nq, 1), k), dtype=torch.float64, device="cuda")
+                oc = torch.full((max(nq, 1),), -7, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                for flags in (rp.RPT_KNN_KEEP_DUPLICATES, rp.RPT_KNN_DEDUP):
+                    sf.knn_dev([qs], k, flags, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+                    comm.sync()
+                    if nq == 0:
+                        continue
+                    wi, wd, wc = rp.knnBatch(k, plain, qs, dedup=bool(flags))
+                    assert np.array_equal(oi.cpu().numpy(), wi), (style, nq, flags)
+                    assert np.array_equal(od.cpu().numpy(), wd)
+                    assert np.array_equal(oc.cpu().numpy(), wc)
+                si, sd, sc = sf.knn([qs], k)                       # host variant, same path
+                if nq:
+                    wi, wd, wc = rp.knnBatch(k, plain, qs)
+                    assert np.array_equal(si, wi) and np.array_equal(sd, wd) and np.array_equal(sc, wc)
+                qs.close()
+            sf.close()
+            ds.close()
+        finally:
+            c0.set_option("comm_force_exchange", old)
+            comm.close()
+
+
+def test_failed_rank_poisons_the_exchange_instead_of_hanging(rp, ctx, case):
+    """Failure protocol of comm.hip: a rank whose query kernels fail still joins the all-gather with
+    its record's status word set and returns its error; after the merge every count is -1 and
+    rpt_comm_sync names the rank.  The next batch (no failure) is answered normally."""
+    import torch
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    k, nq = 5, 64
+    comm = sharded.Comm.rank(ctx, 1, 0, sharded.Comm.unique_id())
+    old = ctx.set_option("comm_force_exchange", 1)
+    try:
+        ds = rp.Dataset.dense(ctx, X)
+        qs = rp.Dataset.dense(ctx, Q[:nq])
+        sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+        oi = torch.zeros((nq, k), dtype=torch.int32, device="cuda")
+        od = torch.zeros((nq, k), dtype=torch.float64, device="cuda")
+        oc = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.set_option("comm_inject_failure", 1)
+        with pytest.raises(rp.RPTError, match="comm_inject_failure"):
+            sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+        with pytest.raises(rp.RPTError, match="rank 0 failed"):
+            comm.sync()
+        assert (oc.cpu().numpy() == -1).all()
+        with pytest.raises(rp.RPTError, match="comm_inject_failure"):
+            sf.knn([qs], k)                                        # host variant: the rank's own error
+        ctx.set_option("comm_inject_failure", 0)
+        si, sd, sc = sf.knn([qs], k)
+        plain, _, _ = sf.local(0)
+        wi, wd, wc = rp.knnBatch(k, plain, Q[:nq])
+        assert np.array_equal(si, wi) and np.array_equal(sd, wd) and np.array_equal(sc, wc)
+        sf.close()
+        ds.close()
+        qs.close()
+    finally:
+        ctx.set_option("comm_inject_failure", 0)
+        ctx.set_option("comm_force_exchange", old)
+        comm.close()
+
+
 def test_comm_argument_errors(rp, ctx, case):
     from rptree_amd import _lib, sharded
     L_ = _lib.lib()

@@ -104,7 +104,8 @@ def test_record_layout():
     nq, k = 1000, 10
     b, od, oi, oc = sharded.record_layout(nq, k)
     assert (od, oi, oc) == (0, nq * k * 8, nq * k * 12)
-    assert b % 16 == 0 and nq * k * 12 + nq * 4 <= b < nq * k * 12 + nq * 4 + 16
+    # distances | ids | counts | one int32 status word, rounded up to 16 bytes
+    assert b % 16 == 0 and nq * k * 12 + nq * 4 + 4 <= b < nq * k * 12 + nq * 4 + 4 + 16
     rec = sharded.ExchangeRecord(7, 3, torch.device("cpu"))
     rec.dist.fill_(1.5)
     rec.ids.fill_(-2)
