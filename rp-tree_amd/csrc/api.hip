@@ -206,6 +206,8 @@ const OptDesc kOptions[] = {
     {"no_midselect", &rpt_options::no_midselect},
     {"stream_big_node", &rpt_options::stream_big_node},
     {"no_wsub", &rpt_options::no_wsub},
+    {"no_wsort", &rpt_options::no_wsort},
+    {"no_wpack", &rpt_options::no_wpack},
     {"no_codes", &rpt_options::no_codes},
     {"proj_narrow", &rpt_options::proj_narrow},
     {"proj_bf16_f32", &rpt_options::proj_bf16_f32},

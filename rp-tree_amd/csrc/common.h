@@ -120,6 +120,8 @@ struct rpt_options {
   int64_t no_midselect = 0;     // split: large pivot bins are sorted, not split by selection
   int64_t stream_big_node = (int64_t)1 << 21;  // split: nodes above this get > 4096 value bins
   int64_t no_wsub = 0;          // split: block-level subtree kernel instead of the wave kernel
+  int64_t no_wsort = 0;         // split: the wave kernel selects by histograms (round 2) instead of sorting
+  int64_t no_wpack = 0;         // split: the sorting wave kernel gathers a key per level, no packed images
   int64_t no_codes = 0;         // split: stream on the keys themselves, no 16-bit codes
   int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only
   int64_t proj_bf16_f32 = 0;    // projection: bf16 rows through the f32-MFMA kernels

@@ -1199,6 +1199,467 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
 #undef WSTAMP
 }
 
+// ---------------------------------------------------------------------------------------
+// wave-centric subtree kernel, SORT variant (round 3; replaces wsub_kernel's histogram select
+// on the default path, same interface, same results).  ONE WAVE per (tree, top node with
+// n <= kWCap), up to kWRmax levels.  The wave holds the node's <= 1024 points as 32-bit sort keys,
+// 16 CONSECUTIVE positions per lane (position = lane * 16 + r), and every level is ONE bitonic
+// sort of all of them:
+//     key = path of the point's node (left-aligned, depth + 1 bits) | monotone image of its
+//           projection on the level's hyperplane (21 - depth bits) | local index (10 bits)
+// so the nodes of the level stay where they are, each is sorted by projection, and the cut of
+// Internal.hs:495-505 is a matter of POSITION: left child = the first nh positions of the node,
+// thr / margins = the keys at positions nh, nh - 1, nh + 1, and the last level's sort leaves the
+// leaf buckets in the reference's order (children inherit the sorted order).  With consecutive
+// positions per lane the four closest exchange distances of the network are register-to-register
+// and only 21 of its 55 stages cross lanes (DPP quad permutes, ds_swizzle, v_permlane32_swap); a
+// lane whose block sorts descending keeps its keys complemented, so every exchange is a plain
+// min / max.  tools/micro/wsort_bench.hip: 0.105 ms per 32 768 sorts (C2's 32 x 1024 nodes).
+// The image is weakly monotone (subtract, multiply by a positive scale, truncate), so a smaller
+// image means a smaller projection; positions whose image equals a neighbour's — about one pair
+// every third (wave, level) on continuous data, every real tie — are ordered EXACTLY afterwards:
+// their true keys (fetched again by id) go to a small LDS pool, each member counts the run mates
+// that precede it by Keys::less (projection, then the earlier levels' projections, then the id)
+// and the run's keys are rewritten in that order.  More than kSPool such positions in one level
+// (heavy ties) flag the node for subtree_kernel, exactly like wsub_kernel's pool overflow.
+// Points are identified by a local index; the ids sit in LDS (4 KB per wave), nothing else moves.
+// PK variant (launches that cover <= 3 levels and most of the point set): the images come from
+// ONE packed word per point (wpack_kernel below), gathered once, instead of a key gather per level.
+// Measured at C2 (32 x 1024 nodes of 977 points, 3 levels; rocprofv3, profiles/r03_*): 0.83 ms +
+// 0.19 ms (wpack) + 0.02 (wgeo) against wsub_kernel's 1.29 ms; without the packed words 1.25 ms:
+// the three key gathers per point (8.6 GB of sector traffic) bound both.  The PK kernel is VALU
+// bound: 9.4 k VALU instructions per wave (SQ_INSTS_VALU), 60 % of all SIMD cycles, 5.4 k of them
+// the three sorts.
+// grid = ceil(S*T/4) blocks of 256 threads.
+// ---------------------------------------------------------------------------------------
+constexpr int kSPool = 128;  // positions per level a wave can order exactly
+constexpr int kWMaxNodes = 1 << (kWRmax - 1);
+constexpr int kPkBits = 21;  // image bits per level in a packed word (three levels per u64)
+constexpr int kPkLevels = 3;
+
+template <bool PK>
+struct WSortSlab {
+  // !PK: point id by local index (int[kWCap]); PK: the packed images by local index.  At the end
+  // both hold the id by position (bit 31 = node still active) for the coalesced stores.
+  unsigned long long store[PK ? kWCap : kWCap / 2];
+  double tk[kSPool];
+  unsigned int rkey[kSPool], rout[kSPool];
+  int rid[kSPool];
+  double vthr[kWMaxNodes], vlo[kWMaxNodes];
+  int tlab[kWMaxNodes * 3];
+};
+
+template <int D>
+__device__ __forceinline__ unsigned int ws_lane_xor(unsigned int v) {
+  if constexpr (D == 1) return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+  else if constexpr (D == 2) return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+  else if constexpr (D == 4) return (unsigned int)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
+  else if constexpr (D == 8) return (unsigned int)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);
+  else return (unsigned int)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+}
+
+// ascending compare-exchange with the lane D away; upper = this lane keeps the larger key
+template <int D>
+__device__ __forceinline__ void ws_cross(unsigned int (&k)[kWE], bool upper) {
+#pragma unroll
+  for (int r = 0; r < kWE; ++r) {
+    unsigned int a, b;
+    if constexpr (D == 32) {  // both halves of the wave see (low half's key, high half's key)
+      const auto sw = __builtin_amdgcn_permlane32_swap(k[r], k[r], false, false);
+      a = sw[0];
+      b = sw[1];
+    } else {
+      a = k[r];
+      b = ws_lane_xor<D>(k[r]);
+    }
+    const unsigned int mn = a < b ? a : b, mx = a < b ? b : a;
+    k[r] = upper ? mx : mn;
+  }
+}
+
+template <int J>
+__device__ __forceinline__ void ws_reg(unsigned int (&k)[kWE]) {
+#pragma unroll
+  for (int r = 0; r < kWE; ++r)
+    if ((r & J) == 0) {
+      const unsigned int a = k[r], b = k[r + J];
+      k[r] = a < b ? a : b;
+      k[r + J] = a < b ? b : a;
+    }
+}
+
+// phase KK of the bitonic network over index = lane * 16 + r: blocks of KK sorted, direction =
+// bit KK of the index (descending blocks are kept complemented)
+template <int KK>
+__device__ __forceinline__ void ws_phase(unsigned int (&k)[kWE], int lane, unsigned int& flip) {
+  if constexpr (KK < 16) {
+#pragma unroll
+    for (int r = 0; r < kWE; ++r)
+      if (r & KK) k[r] = ~k[r];
+    if constexpr (KK >= 8) ws_reg<4>(k);
+    if constexpr (KK >= 4) ws_reg<2>(k);
+    ws_reg<1>(k);
+#pragma unroll
+    for (int r = 0; r < kWE; ++r)
+      if (r & KK) k[r] = ~k[r];
+  } else {
+    const unsigned int want = (KK < 1024 && ((lane * 16) & KK)) ? ~0u : 0u;
+    const unsigned int x = want ^ flip;
+    flip = want;
+#pragma unroll
+    for (int r = 0; r < kWE; ++r) k[r] ^= x;
+    if constexpr (KK >= 1024) ws_cross<32>(k, (lane & 32) != 0);
+    if constexpr (KK >= 512) ws_cross<16>(k, (lane & 16) != 0);
+    if constexpr (KK >= 256) ws_cross<8>(k, (lane & 8) != 0);
+    if constexpr (KK >= 128) ws_cross<4>(k, (lane & 4) != 0);
+    if constexpr (KK >= 64) ws_cross<2>(k, (lane & 2) != 0);
+    if constexpr (KK >= 32) ws_cross<1>(k, (lane & 1) != 0);
+    ws_reg<8>(k);
+    ws_reg<4>(k);
+    ws_reg<2>(k);
+    ws_reg<1>(k);
+  }
+}
+
+__device__ __forceinline__ void ws_sort1024(unsigned int (&k)[kWE], int lane) {
+  unsigned int flip = 0;
+  ws_phase<2>(k, lane, flip);
+  ws_phase<4>(k, lane, flip);
+  ws_phase<8>(k, lane, flip);
+  ws_phase<16>(k, lane, flip);
+  ws_phase<32>(k, lane, flip);
+  ws_phase<64>(k, lane, flip);
+  ws_phase<128>(k, lane, flip);
+  ws_phase<256>(k, lane, flip);
+  ws_phase<512>(k, lane, flip);
+  ws_phase<1024>(k, lane, flip);  // ascending everywhere: the keys leave un-complemented
+}
+
+// Node of a position, packed: offset inside the top node (bits 0-10) | size (11-21) | path,
+// left-aligned to the current depth (22-26) | leaf (27).  ws_step takes it one level down
+// (Internal.hs:289 leaf test, :495,503 halves); branch-free, a leaf only shifts its path.
+constexpr unsigned int kWsLeaf = 1u << 27;
+__device__ __forceinline__ unsigned int ws_step(unsigned int info, int p, int next_level, int L,
+                                                int min_leaf) {
+  const int off = (int)(info & 2047u), n = (int)((info >> 11) & 2047u);
+  const unsigned int path = (info >> 22) & 31u;
+  const bool leaf = (info & kWsLeaf) != 0;
+  const int nh = n >> 1;
+  const bool right = !leaf && p - off >= nh;
+  const int off2 = off + (right ? nh : 0);
+  const int n2 = leaf ? n : (right ? n - nh : nh);
+  const bool leaf2 = leaf || is_leaf_dev(next_level, n2, L, min_leaf);
+  return (unsigned int)off2 | ((unsigned int)n2 << 11) | ((2u * path + (right ? 1u : 0u)) << 22) |
+         (leaf2 ? kWsLeaf : 0u);
+}
+
+// ---- packed images (PK): one u64 per point with the 21-bit images of the nl <= 3 levels a wave
+// launch covers, written in ID order by one coalesced pass over the projections (wpack_kernel) and
+// gathered ONCE per point by wsort_kernel — instead of one 8-byte key gather (a 64-byte sector
+// of HBM traffic each) per point and LEVEL.  One geometry per (tree, level) from a strided sample
+// of the column (wgeo_kernel); values outside the sampled range clamp into the edge images and
+// are ordered by the exact fix-up like any other equal images.
+template <class TK>
+__global__ __launch_bounds__(256) void wgeo_kernel(const TK* __restrict__ P, int64_t N, int L,
+                                                   int level0, int nl, double* __restrict__ geo) {
+  const int j = blockIdx.x, t = blockIdx.y;
+  const TK* col = P + ((int64_t)t * L + level0 + j) * N;
+  const int64_t m = N < 4096 ? N : 4096;
+  double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+  for (int64_t i = threadIdx.x; i < m; i += 256) {
+    const double v = (double)col[i * N / m];
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+  }
+  __shared__ double smn[256], smx[256];
+  smn[threadIdx.x] = mn;
+  smx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double a = smn[threadIdx.x + o], b = smx[threadIdx.x + o];
+      if (a < smn[threadIdx.x]) smn[threadIdx.x] = a;
+      if (b > smx[threadIdx.x]) smx[threadIdx.x] = b;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double lo = smn[0], hi = smx[0];
+    const double w = hi - lo;
+    const bool ok = lo < hi && w < 1e300;
+    geo[((int64_t)t * nl + j) * 2] = ok ? lo - 0.02 * w : 0.0;
+    geo[((int64_t)t * nl + j) * 2 + 1] = ok ? (double)(1u << kPkBits) / (1.04 * w) : 0.0;
+  }
+}
+
+template <class TK>
+__global__ __launch_bounds__(256) void wpack_kernel(const TK* __restrict__ P, int64_t N, int L,
+                                                    int level0, int nl, const double* __restrict__ geo,
+                                                    unsigned long long* __restrict__ packed) {
+  const int t = blockIdx.y;
+  double lo[kPkLevels], sc[kPkLevels];
+#pragma unroll
+  for (int j = 0; j < kPkLevels; ++j) {
+    lo[j] = j < nl ? geo[((int64_t)t * nl + j) * 2] : 0.0;
+    sc[j] = j < nl ? geo[((int64_t)t * nl + j) * 2 + 1] : 0.0;
+  }
+  const TK* base = P + ((int64_t)t * L + level0) * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    unsigned long long w = 0;
+#pragma unroll
+    for (int j = 0; j < kPkLevels; ++j)
+      if (j < nl) {
+        const double fq = ((double)base[(int64_t)j * N + i] - lo[j]) * sc[j];
+        unsigned int c;
+        asm("v_cvt_u32_f64 %0, %1" : "=v"(c) : "v"(fq));  // saturating; weakly monotone in the key
+        c = c < (1u << kPkBits) - 1u ? c : (1u << kPkBits) - 1u;
+        w |= (unsigned long long)c << (kPkBits * j);
+      }
+    packed[(int64_t)t * N + i] = w;
+  }
+}
+
+template <class TK, bool PK>
+__global__ __launch_bounds__(256, 3) void wsort_kernel(
+    const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int32_t* __restrict__ F,
+    int64_t N, const TK* __restrict__ P, int L, int T, int level0, int min_leaf,
+    const Seg* __restrict__ segs, int S, double* thr, double* mglo, double* mghi,
+    int64_t nodes, unsigned long long* tie_count, unsigned int* ovf_flags,
+    unsigned int* ovf_count, const unsigned int* __restrict__ abort,
+    const unsigned long long* __restrict__ packed) {
+  __shared__ WSortSlab<PK> slabs[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
+  if (wg >= (int64_t)S * T) return;
+  if (abort && *abort) return;  // the streaming levels above are being rebuilt by the host
+  const int si = (int)(wg % S), t = (int)(wg / S);
+  WSortSlab<PK>& W = slabs[wave];
+  int* wids = reinterpret_cast<int*>(W.store);
+  const Seg sg = segs[si];
+  const int n_top = sg.n;
+  if (n_top <= 0) return;
+  const TK* Pt = P + (int64_t)t * L * N;
+  const int32_t* s = src + (int64_t)t * N + sg.off;
+  auto id_of = [&](unsigned int label) -> int { return PK ? s[label] : wids[label]; };
+
+  // local index i = e * 64 + lane names point s[i] (coalesced); position p starts with index p
+#pragma unroll
+  for (int e = 0; e < kWE; ++e) {
+    const int i = e * 64 + lane;
+    const int id = i < n_top ? s[i] : 0;
+    if constexpr (PK) W.store[i] = i < n_top ? packed[(int64_t)t * N + id] : 0ULL;
+    else wids[i] = id;
+  }
+  unsigned int k[kWE], info[kWE];
+  {
+    const unsigned int top = ((unsigned int)n_top << 11) |
+                             (is_leaf_dev(level0, n_top, L, min_leaf) ? kWsLeaf : 0u);
+#pragma unroll
+    for (int r = 0; r < kWE; ++r) {
+      k[r] = (unsigned int)(lane * kWE + r);
+      info[r] = top;
+    }
+  }
+  wsync();
+
+  int depth = 0;
+  bool overflow = false;
+  for (; depth < kWRmax; ++depth) {
+    const int level = level0 + depth;
+    if (level >= L) break;
+    bool act = false;
+#pragma unroll
+    for (int r = 0; r < kWE; ++r) act = act || (lane * kWE + r < n_top && !(info[r] & kWsLeaf));
+    if (!__any(act)) break;
+
+    Keys<TK> K{Pt, N, level, nullptr};
+    const TK* Pl = Pt + (int64_t)level * N;
+    const int ib = 21 - depth;                  // image bits of this level's sort keys
+    const unsigned int imax = (1u << ib) - 1u;
+    unsigned int img[kWE];
+    if constexpr (PK) {
+      // ---- a. images from the packed words ----
+#pragma unroll
+      for (int r = 0; r < kWE; ++r) {
+        const unsigned long long w = W.store[k[r] & 1023u];
+        img[r] = ((unsigned int)(w >> (kPkBits * depth)) & ((1u << kPkBits) - 1u)) >> depth;
+      }
+    } else {
+      // ---- a. keys of this level, gathered by id; one value range for all nodes of the level ----
+      TK key[kWE];
+#pragma unroll
+      for (int r = 0; r < kWE; ++r) {
+        const bool a = lane * kWE + r < n_top && !(info[r] & kWsLeaf);
+        key[r] = a ? Pl[wids[k[r] & 1023u]] : (TK)0;
+      }
+      double kmn = __builtin_huge_val(), kmx = -__builtin_huge_val();
+#pragma unroll
+      for (int r = 0; r < kWE; ++r)
+        if (lane * kWE + r < n_top && !(info[r] & kWsLeaf)) {
+          const double v = (double)key[r];
+          kmn = v < kmn ? v : kmn;
+          kmx = v > kmx ? v : kmx;
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(kmn, o), b = __shfl_xor(kmx, o);
+        kmn = a < kmn ? a : kmn;
+        kmx = b > kmx ? b : kmx;
+      }
+      const double scale = kmn < kmx ? (double)(1u << ib) / (kmx - kmn) : 0.0;
+#pragma unroll
+      for (int r = 0; r < kWE; ++r) {
+        const double fq = ((double)key[r] - kmn) * scale;
+        unsigned int c;
+        asm("v_cvt_u32_f64 %0, %1" : "=v"(c) : "v"(fq));  // saturating
+        img[r] = c < imax ? c : imax;
+      }
+    }
+    // ---- b. sort keys: node path | image | local index; a leaf keeps its order ----
+#pragma unroll
+    for (int r = 0; r < kWE; ++r) {
+      const int p = lane * kWE + r;
+      const unsigned int path = (info[r] >> 22) & 31u;
+      const unsigned int im = (info[r] & kWsLeaf) ? (unsigned int)(p - (int)(info[r] & 2047u)) : img[r];
+      k[r] = p < n_top ? (path << (ib + 10)) | (im << 10) | (k[r] & 1023u)
+                       : ~0u;  // padding: behind every real key (their top bit is 0)
+    }
+    ws_sort1024(k, lane);
+    // ---- c. positions whose image equals a neighbour's: exact order inside those runs ----
+    {
+      unsigned int bits = 0;
+      const unsigned int up = (unsigned int)__shfl_up((int)k[kWE - 1], 1);
+      const unsigned int dn = (unsigned int)__shfl_down((int)k[0], 1);
+#pragma unroll
+      for (int r = 0; r < kWE; ++r) {
+        const unsigned int me = k[r] >> 10;
+        const bool eqp = r > 0 ? (k[r > 0 ? r - 1 : 0] >> 10) == me : (lane > 0 && (up >> 10) == me);
+        const bool eqn = r + 1 < kWE ? (k[r + 1 < kWE ? r + 1 : r] >> 10) == me
+                                     : (lane < 63 && (dn >> 10) == me);
+        if (k[r] != ~0u && (eqp || eqn)) bits |= 1u << r;
+      }
+      if (__any(bits != 0)) {
+        const int cnt = __popc(bits);
+        int inc = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(inc, o);
+          if (lane >= o) inc += v;
+        }
+        const int tot = __shfl(inc, 63);
+        if (tot > kSPool) {
+          overflow = true;
+          break;
+        }
+        const int base = inc - cnt;
+#pragma unroll
+        for (int r = 0; r < kWE; ++r)
+          if (bits & (1u << r)) W.rkey[base + __popc(bits & ((1u << r) - 1u))] = k[r];
+        wsync();
+        // by pool slot from here on: the true key of every member, fetched again by id
+        for (int sl = lane; sl < tot; sl += 64) {
+          const int id = id_of(W.rkey[sl] & 1023u);
+          W.rid[sl] = id;
+          W.tk[sl] = (double)Pl[id];
+        }
+        wsync();
+        for (int sl = lane; sl < tot; sl += 64) {
+          const unsigned int mk = W.rkey[sl];
+          const TK tkm = (TK)W.tk[sl];
+          const int idm = W.rid[sl];
+          int nleft = 0, less = 0;
+          for (int q = sl - 1; q >= 0 && (W.rkey[q] >> 10) == (mk >> 10); --q) {
+            ++nleft;
+            less += K.less((TK)W.tk[q], W.rid[q], tkm, idm) ? 1 : 0;
+          }
+          for (int q = sl + 1; q < tot && (W.rkey[q] >> 10) == (mk >> 10); ++q)
+            less += K.less((TK)W.tk[q], W.rid[q], tkm, idm) ? 1 : 0;
+          W.rout[sl - nleft + less] = mk;
+        }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < kWE; ++r)
+          if (bits & (1u << r)) k[r] = W.rout[base + __popc(bits & ((1u << r) - 1u))];
+        wsync();
+      }
+    }
+    // ---- d. thresholds and margins: the keys at positions nh, nh - 1, nh + 1 of every node
+    // (Internal.hs:496-501; n == 2 -> (p'[0], p'[1]); n == 1 -> p'[0] for all three).  The
+    // positions post their local index, one lane per (node, value) fetches and writes ----
+    if (lane < kWMaxNodes * 3) W.tlab[lane] = -1;
+    if (lane < kWMaxNodes) {
+      W.vthr[lane] = __builtin_huge_val();
+      W.vlo[lane] = -__builtin_huge_val();
+    }
+    wsync();
+#pragma unroll
+    for (int r = 0; r < kWE; ++r) {
+      const int p = lane * kWE + r;
+      const int off = (int)(info[r] & 2047u), n = (int)((info[r] >> 11) & 2047u);
+      const int rel = p - off, nh = n >> 1;
+      const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
+      const int j = (int)((info[r] >> 22) & 31u);
+      const bool a = p < n_top && !(info[r] & kWsLeaf);
+      const int lab = (int)(k[r] & 1023u) | (nh > 0 ? 1 << 16 : 0);
+      if (a && rel == nh) W.tlab[j * 3] = lab;
+      if (a && rel == il) W.tlab[j * 3 + 1] = lab;
+      if (a && rel == ih) W.tlab[j * 3 + 2] = lab;
+    }
+    wsync();
+    if (lane < 3 << depth) {
+      const int lab = W.tlab[lane];
+      if (lab >= 0) {
+        const int j = lane / 3, which = lane - 3 * j;
+        const double v = (double)Pl[id_of((unsigned int)lab & 1023u)];
+        const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
+        if (which == 0) {
+          thr[h] = v;
+          W.vthr[j] = v;
+        } else if (which == 1) {
+          mglo[h] = v;
+          if (lab >> 16) W.vlo[j] = v;
+        } else {
+          mghi[h] = v;
+        }
+      }
+    }
+    wsync();
+    if (lane < (1 << depth) && !(W.vlo[lane] < W.vthr[lane])) atomicAdd(tie_count, 1ULL);
+    // ---- e. every position one level down ----
+#pragma unroll
+    for (int r = 0; r < kWE; ++r) info[r] = ws_step(info[r], lane * kWE + r, level + 1, L, min_leaf);
+    wsync();
+  }
+  if (overflow) {
+    if (lane == 0) {
+      ovf_flags[si] = 1u;
+      atomicAdd(ovf_count, 1u);
+    }
+    return;
+  }
+  // ---- every point to its slot: position = slot.  Leaves go to the final perm (in their final
+  // order), nodes still active after kWRmax levels to nxt.  Through LDS, so that the stores are
+  // coalesced ----
+  int idr[kWE];
+#pragma unroll
+  for (int r = 0; r < kWE; ++r) {
+    const bool real = lane * kWE + r < n_top;
+    idr[r] = (real ? id_of(k[r] & 1023u) : 0) | ((info[r] & kWsLeaf) ? 0 : (int)0x80000000);
+  }
+  wsync();
+#pragma unroll
+  for (int r = 0; r < kWE; ++r) wids[lane * kWE + r] = idr[r];
+  wsync();
+  int32_t* of = F + (int64_t)t * N + sg.off;
+  int32_t* on = nxt + (int64_t)t * N + sg.off;
+#pragma unroll
+  for (int e = 0; e < kWE; ++e) {
+    const int p = e * 64 + lane;
+    if (p >= n_top) continue;
+    const int v = wids[p];
+    if (v < 0) on[p] = v & 0x7fffffff;
+    else of[p] = v;
+  }
+}
+
 // copy segments src -> dst unchanged (leaves that are already in final order). grid=(S,T)
 __global__ void copy_segs_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
                                  int64_t N, const Seg* __restrict__ segs) {
@@ -3493,6 +3954,8 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         descend(Seg{sgm.off + nh, sgm.n - nh, 2 * sgm.heap + 2}, level + 1, depth + 1, want, out);
       };
 
+  DevBuf<double> wgeo;                 // wsort_kernel's packed images: geometry and words
+  DevBuf<unsigned long long> wpacked;
   // wsub_kernel launches whose overflow flags have not been looked at yet
   struct Deferred {
     int level = 0, b = 0;
@@ -3526,10 +3989,39 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         df.b = b;
         RPT_TRY(df.flags.alloc((size_t)S + 1));
         RPT_HIP(hipMemsetAsync(df.flags.p, 0, ((size_t)S + 1) * 4, st));
-        hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
-                           st, cur, nxt, F, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
-                           f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, df.flags.p + 1,
-                           df.flags.p, (const unsigned int*)sflags.p, dbgbuf);
+        if (!ctx->opt.no_wsort) {  // one bitonic sort of the node's sort keys per level
+          // packed images (one gather per point instead of one per point and level) when the
+          // launch covers at most three levels and most of the point set
+          const int nl = std::min(L - level, kWRmax);
+          int64_t cover = 0;
+          for (const Seg& sgm : wsmall) cover += sgm.n;
+          const bool pk = !ctx->opt.no_wpack && nl <= kPkLevels && cover * 2 >= N && N * T >= (1 << 16);
+          if (pk) {
+            RPT_TRY(wgeo.ensure((size_t)T * kPkLevels * 2));
+            RPT_TRY(wpacked.ensure((size_t)T * N));
+            hipLaunchKernelGGL(wgeo_kernel<TK>, dim3((unsigned)nl, T), dim3(256), 0, st, P, N, L, level,
+                               nl, wgeo.p);
+            const unsigned pb = (unsigned)std::min<int64_t>((N + 1023) / 1024, (int64_t)ctx->n_cu * 8);
+            hipLaunchKernelGGL(wpack_kernel<TK>, dim3(pb, T), dim3(256), 0, st, P, N, L, level, nl,
+                               wgeo.p, wpacked.p);
+            hipLaunchKernelGGL((wsort_kernel<TK, true>), dim3((unsigned)(((int64_t)S * T + 3) / 4)),
+                               dim3(256), 0, st, cur, nxt, F, N, P, L, T, level, f->min_leaf, dsegs.p,
+                               (int)S, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count,
+                               df.flags.p + 1, df.flags.p, (const unsigned int*)sflags.p,
+                               (const unsigned long long*)wpacked.p);
+          } else {
+            hipLaunchKernelGGL((wsort_kernel<TK, false>), dim3((unsigned)(((int64_t)S * T + 3) / 4)),
+                               dim3(256), 0, st, cur, nxt, F, N, P, L, T, level, f->min_leaf, dsegs.p,
+                               (int)S, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count,
+                               df.flags.p + 1, df.flags.p, (const unsigned int*)sflags.p,
+                               (const unsigned long long*)nullptr);
+          }
+        }
+        else                     // round 1/2: histogram select in the wave's registers
+          hipLaunchKernelGGL(wsub_kernel<TK>, dim3((unsigned)(((int64_t)S * T + 3) / 4)), dim3(256), 0,
+                             st, cur, nxt, F, N, P, L, T, level, f->min_leaf, dsegs.p, (int)S,
+                             f->thr.p, f->mglo.p, f->mghi.p, f->nodes, tie_count, df.flags.p + 1,
+                             df.flags.p, (const unsigned int*)sflags.p, dbgbuf);
         // nodes the wave kernel left active (deeper than kWRmax levels) stay pending
         std::vector<Seg> rest;
         for (const Seg& sgm : wsmall) descend(sgm, level, 0, kWRmax, rest);

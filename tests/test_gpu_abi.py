@@ -305,7 +305,7 @@ def test_every_fallback_option_keeps_the_forest_identical(rp, ctx, oracle):
     L, _, pnz = oracle.tree_cfg(ml, n, d)
     R, _ = oracle.forest_hyperplanes(8, T, L, pnz, d)
     fo = oracle.forest_build_dense(X, R, ml)
-    for name in ("no_stream", "no_wsub", "no_wmid", "no_midselect", "proj_narrow"):
+    for name in ("no_stream", "no_wsub", "no_wsort", "no_wpack", "no_wmid", "no_midselect", "proj_narrow"):
         old = ctx.set_option(name, 1)
         try:
             f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R)

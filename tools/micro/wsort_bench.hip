@@ -35,8 +35,8 @@ __device__ __forceinline__ void cross_stage(unsigned int (&k)[E], bool upper) {
   if constexpr (D == 32) {  // v_permlane32_swap: both halves see (low half's key, high half's key)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-      unsigned int a = k[r], b = k[r];
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+      const auto sw = __builtin_amdgcn_permlane32_swap(k[r], k[r], false, false);
+      const unsigned int a = sw[0], b = sw[1];
       const unsigned int mn = a < b ? a : b, mx = a < b ? b : a;
       k[r] = upper ? mx : mn;
     }
