@@ -41,7 +41,329 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # v_mfma_f64_16x16x4_f64 = 2048 flop per 64 cycles per SIMD (32 flop/clk/SIMD, half the f32
 # 16x16x4 rate of the guide's table) x 1024 SIMDs x 2.4 GHz = 78.6e12.
 MFMA_F64_PEAK_TF = 78.6
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix = FP32 vector rate
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (no sparsity)
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+
+
+# ---------------------------------------------------------------------------------------------
+# other_configs: BASELINE configs[2..4] as ONE GPU sees them (C3 whole; the tree shard of one of
+# the 8 GPUs for C4 / C5, at the configuration's own point count, depth and k), N = 1 only.
+# Each leg is guarded: a failure is reported in its slot and cannot lose the C2 line.
+# ---------------------------------------------------------------------------------------------
+def _prof_read(L_, _lib, C, ctx):
+    out = {}
+    for name, which in (("project", 0), ("split", 1), ("knn_plan", 2), ("knn_topk", 3),
+                        ("project_wide", 4)):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(L_.rpt_prof_get(ctx._h, which, C.byref(ms), C.byref(cnt)))
+        out[name] = (ms.value, cnt.value)
+    return out
+
+
+def _timed_leg(rp, _lib, L_, C, torch, ctx, ds, qs, R, maxd, min_leaf, k, steps):
+    """steps timed builds + steps timed query batches of one configuration on one device ->
+    (forest, build ms, knn ms, kernel-class times of the builds, of the queries, candidates/query)"""
+    nq = qs.n
+    rp._build(ctx, ds, R, maxd, min_leaf, rp.RPT_PROJ_AUTO).close()          # warm
+    _lib.check(L_.rpt_prof_reset(ctx._h))
+    _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+    ctx.sync()
+    t0 = time.perf_counter()
+    f = None
+    for _ in range(steps):
+        if f is not None:
+            f.close()
+        f = rp._build(ctx, ds, R, maxd, min_leaf, rp.RPT_PROJ_AUTO)
+    ctx.sync()
+    t_build = (time.perf_counter() - t0) / steps
+    prof_b = _prof_read(L_, _lib, C, ctx)
+    _lib.check(L_.rpt_prof_reset(ctx._h))
+    dev = torch.device("cuda", ctx.device)
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float64, device=dev)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def knn():
+        _lib.check(L_.rpt_knn_dev(ctx._h, f._h, ds._h, qs._h, k, 0, C.c_void_p(ids.data_ptr()),
+                                  C.c_void_p(dist.data_ptr()), C.c_void_p(cnt.data_ptr())))
+        ctx.sync()
+
+    knn()                                                                    # warm (+ shadows)
+    _lib.check(L_.rpt_prof_reset(ctx._h))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        knn()
+    t_knn = (time.perf_counter() - t0) / steps
+    prof_q = _prof_read(L_, _lib, C, ctx)
+    _lib.check(L_.rpt_prof_enable(ctx._h, 0))
+    cand = C.c_int64()
+    _lib.check(L_.rpt_knn_last_candidates(ctx._h, C.byref(cand)))
+    return f, t_build * 1e3, t_knn * 1e3, prof_b, prof_q, cand.value / float(max(nq, 1)), (ids, dist, cnt)
+
+
+def _ncores(T):
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, n)
+
+
+def _roof(kernel, avg_ms, launches, nbytes, flops, flop_peak_tf, note):
+    hbm = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 and flops else 0.0
+    hf, mf = hbm / HBM_PEAK_GBS, (tf / flop_peak_tf if flop_peak_tf else 0.0)
+    r = ({"bound": "mfma", "achieved": tf, "peak": flop_peak_tf, "unit": "TFLOP/s", "frac": mf}
+         if mf > hf else
+         {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hf})
+    r.update({"kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches, "traffic": None,
+              "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+              "hbm_frac": hf, "mfma_frac": mf, "note": note})
+    return r
+
+
+def _sparse_uniform_device(torch, dev, n, d, density, seed):
+    """Bernoulli support + U(0,1] values, built on the device as CSR tensors"""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    cols, counts = [], []
+    for r0 in range(0, n, 100_000):
+        m = torch.rand((min(100_000, n - r0), d), device=dev, generator=g) < density
+        counts.append(m.sum(dim=1))
+        cols.append(m.nonzero()[:, 1].to(torch.int32))
+    col = torch.cat(cols)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.cat(counts), 0)
+    val = 1.0 - torch.rand(col.numel(), dtype=torch.float64, device=dev, generator=g)
+    return rowptr, col, val
+
+
+def other_configs(which, steps, with_cpu):
+    import ctypes as C
+    import torch
+    import rptree_amd as rp
+    from rptree_amd import _lib, gen
+    L_ = _lib.lib()
+    ctx = rp.default_context()
+    dev = torch.device("cuda", ctx.device)
+    ncores = _ncores(0)
+    out = {"note": "BASELINE configs[2..4] on ONE GPU: C3 whole, C4 / C5 as the tree shard of one of "
+                   "their 8 GPUs (all points, T/8 trees); build in the API-default projection mode of "
+                   "the element type; value = points / build time with the data resident in HBM",
+           "steps": steps}
+
+    def cpu_dense(orc, Xh, R, min_leaf, T, n_sample, fdev, Qh, k, L_full):
+        """oracle baselines of a dense shard: 1 thread on the first n_sample rows scaled by
+        point-levels, all cores INSIDE one full-size tree; knn over the device-built forest"""
+        n, d = Xh.shape
+        Ls = rp.rpTreeCfg(min_leaf, n_sample, d).fpMaxTreeDepth
+        Rs = np.ascontiguousarray(R[:1, :Ls])
+        t0 = time.perf_counter()
+        orc.forest_build_dense(Xh[:n_sample], Rs, min_leaf, threads=1)
+        t1 = time.perf_counter() - t0
+        per_pl = t1 / (n_sample * Ls)                      # seconds per point-level, one tree
+        v1 = n / (per_pl * n * L_full * T)
+        t0 = time.perf_counter()
+        fo = orc.forest_build_dense(Xh, R[:1], min_leaf, threads=ncores)
+        tall = time.perf_counter() - t0
+        ff = orc.Forest(n, d, R, L_full, min_leaf, fdev.perm, fdev.thr, fdev.mglo, fdev.mghi)
+        nqs = len(Qh)
+        t0 = time.perf_counter()
+        orc.knn_dense_batch(ff, Xh, Qh, k, threads=1)
+        tq = time.perf_counter() - t0
+        return {"value": v1, "unit": "vectors/s", "cores": 1, "kind": "port",
+                "sample": "oracle, 1 thread: ONE tree on the first %d rows (depth %d), %.1f s, "
+                          "scaled by point-levels to %d rows x depth %d x %d trees; knn: %d queries "
+                          "over the device-built forest" % (n_sample, Ls, t1, n, L_full, T, nqs),
+                "knn_queries_per_s": nqs / tq,
+                "cores_all": ncores, "value_all_cores": n / (tall * T),
+                "sample_all_cores": "ONE full-size tree built with all %d threads inside it "
+                                    "(%.1f s), scaled to %d trees" % (ncores, tall, T)}, fo
+
+    # ------------------------------------------------------------------ C3
+    if "c3" in which:
+        try:
+            n, d, T, min_leaf, k, nq = 1_000_000, 784, 32, 128, 10, 10_000
+            cfg = rp.rpTreeCfg(min_leaf, n, d)
+            maxd, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+            rowptr, col, val = _sparse_uniform_device(torch, dev, n, d, 0.19, 1234)
+            qr, qc, qv = _sparse_uniform_device(torch, dev, nq, d, 0.19, 4321)
+            ds = rp.Dataset.csr_from_torch(ctx, rowptr, col, val, d)
+            qs = rp.Dataset.csr_from_torch(ctx, qr, qc, qv, d)
+            _, R = gen.forest_hyperplanes(1235137, T, maxd, pnz, d)
+            f, b_ms, q_ms, pb, pq, cand, _ = _timed_leg(rp, _lib, L_, C, torch, ctx, ds, qs, R, maxd,
+                                                        min_leaf, k, steps)
+            nnz = int(val.numel())
+            p_ms, p_n = pb["project"]
+            per_build = p_n / steps
+            passes = T * maxd / 32.0
+            lpp = per_build / passes                     # launches per 32-hyperplane pass (2: halves)
+            pass_bytes = nnz * 12 + (n + 1) * 8 + n * 32 * 8          # SURVEY 8d, one level of 32 trees
+            res = {"workload": "C3: %d x %d CSR f64, density 0.19 (%d nonzeros), %d trees, minLeaf %d, "
+                               "maxDepth %d, pnz %.4f, k=%d, %d queries" % (n, d, nnz, T, min_leaf, maxd, pnz, k, nq),
+                   "dtype": "f64", "projection_mode": "exact (innerSS order, bit-identical)",
+                   "build_ms": b_ms, "value": n / (b_ms * 1e-3), "unit": "vectors/s",
+                   "knn_ms_per_batch": q_ms, "knn_queries_per_s": nq / (q_ms * 1e-3),
+                   "candidates_per_query": cand,
+                   "build_breakdown_ms": {"projection_total": p_ms / steps, "split_total": pb["split"][0] / steps},
+                   "roofline": _roof("proj_csr_lds32<double> (32 hyperplanes per pass over the CSR arrays, a pass = "
+                                     "%.0f launches over column halves)" % lpp,
+                                     p_ms / max(p_n, 1) * lpp, int(per_build / lpp), pass_bytes,
+                                     2.0 * nnz * 32, 0.0,
+                                     "per PASS (SURVEY 8d: nnz*12 + (N+1)*8 + N*32*8 bytes, 2*nnz*32 flops); the "
+                                     "kernel is instruction-issue bound, not HBM bound (DESIGN 4.1)"),
+                   "roofline_knn": _roof("knn_fused<CSR> (exact f64 distances over SVector rows)",
+                                         pq["knn_topk"][0] / max(pq["knn_topk"][1], 1), pq["knn_topk"][1],
+                                         nq * cand * (nnz / float(n)) * 12, 0.0, 0.0,
+                                         "nq x candidates x mean row nonzeros x 12 B")}
+            if with_cpu:
+                from oracle import oracle as orc
+                hr, hc, hv = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+                t0 = time.perf_counter()
+                fo1 = orc.forest_build_csr(hr, hc, hv, d, R[:1], min_leaf, threads=1)
+                t1 = time.perf_counter() - t0
+                nt_all = min(T, ncores)
+                t0 = time.perf_counter()
+                orc.forest_build_csr(hr, hc, hv, d, R[:nt_all], min_leaf, threads=ncores)
+                tall = time.perf_counter() - t0
+                same = bool(np.array_equal(fo1.perm[0], f.perm[0]) and
+                            np.array_equal(fo1.thr[0], f.thr[0], equal_nan=True))
+                ff = orc.Forest(n, d, R, maxd, min_leaf, f.perm, f.thr, f.mglo, f.mghi)
+                hqr, hqc, hqv = qr.cpu().numpy(), qc.cpu().numpy(), qv.cpu().numpy()
+                nqs = 20
+                t0 = time.perf_counter()
+                for i in range(nqs):
+                    orc.knn_csr(ff, hr, hc, hv, hqc[hqr[i]:hqr[i + 1]], hqv[hqr[i]:hqr[i + 1]], k, true_l2=True)
+                tq = time.perf_counter() - t0
+                res["cpu_baseline"] = {
+                    "value": n / (t1 * T), "unit": "vectors/s", "cores": 1, "kind": "port",
+                    "sample": "oracle, 1 thread: ONE full-size tree (%.1f s) scaled to %d trees; knn: %d "
+                              "queries over the device-built forest" % (t1, T, nqs),
+                    "knn_queries_per_s": nqs / tq, "cores_all": ncores,
+                    "value_all_cores": n / (tall / nt_all * T),
+                    "sample_all_cores": "%d trees on %d threads (%.1f s), scaled to %d" % (nt_all, ncores, tall, T),
+                    "tree0_identical_to_gpu": same}
+            out["c3"] = res
+            f.close()
+            ds.close()
+            qs.close()
+            del rowptr, col, val, qr, qc, qv
+        except Exception as e:          # noqa: BLE001 — a failed leg must not lose the C2 line
+            out["c3"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ C4 shard
+    if "c4" in which:
+        try:
+            n, d, Tall, G, min_leaf, k, nq = 10_000_000, 128, 64, 8, 128, 10, 100_000
+            T = Tall // G
+            cfg = rp.rpTreeCfg(min_leaf, n, d)
+            maxd, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+            g = torch.Generator(device=dev).manual_seed(1234)
+            coin = (torch.rand(n, 1, device=dev, generator=g) < 0.5).float() * 2.0
+            Xd = torch.randn(n, d, device=dev, dtype=torch.float32, generator=g) * 0.5 + coin
+            del coin
+            qi = torch.randint(0, n, (nq,), device=dev, generator=g)
+            Qd = (Xd[qi] * 1.001 + 0.003).contiguous()
+            torch.cuda.synchronize(dev)
+            ds = rp.Dataset.from_torch(ctx, Xd)
+            qs = rp.Dataset.from_torch(ctx, Qd)
+            _, R = gen.forest_hyperplanes(1235137, T, maxd, pnz, d)
+            f, b_ms, q_ms, pb, pq, cand, _ = _timed_leg(rp, _lib, L_, C, torch, ctx, ds, qs, R, maxd,
+                                                        min_leaf, k, steps)
+            w_ms, w_n = pb["project_wide"]
+            cols = T * maxd / max(w_n / steps, 1)
+            res = {"workload": "C4 shard: %d x %d f32 two-Gaussian mixture, %d of %d trees (one of %d GPUs), "
+                               "minLeaf %d, maxDepth %d, pnz %.4f, k=%d, %d queries" %
+                               (n, d, T, Tall, G, min_leaf, maxd, pnz, k, nq),
+                   "dtype": "f32", "projection_mode": "mfma (f32 MFMA 16x16x4, 1e-5 |x||r|)",
+                   "build_ms": b_ms, "value": n / (b_ms * 1e-3), "unit": "vectors/s",
+                   "knn_ms_per_batch": q_ms, "knn_queries_per_s": nq / (q_ms * 1e-3),
+                   "candidates_per_query": cand,
+                   "build_breakdown_ms": {"projection_total": pb["project"][0] / steps,
+                                          "split_total": pb["split"][0] / steps},
+                   "roofline": _roof("proj_mfma_wide<float> (%.0f hyperplanes per launch on average)" % cols,
+                                     w_ms / max(w_n, 1), int(w_n / steps),
+                                     n * d * 4 + d * cols * 8 + n * cols * 4, 2.0 * n * d * cols,
+                                     MFMA_F32_PEAK_TF, "SURVEY 8d formula at the hyperplanes one launch covers"),
+                   "roofline_knn": _roof("knn_fused_wave<float> (one wave per query)",
+                                         pq["knn_topk"][0] / max(pq["knn_topk"][1], 1), pq["knn_topk"][1],
+                                         nq * cand * d * 4, 0.0, 0.0, "nq x candidates x d x 4 B")}
+            if with_cpu:
+                from oracle import oracle as orc
+                Xh = Xd.cpu().numpy()
+                Qh = Qd[:50].cpu().numpy().astype(np.float64)
+                res["cpu_baseline"], _ = cpu_dense(orc, Xh, R, min_leaf, T, 1_000_000, f, Qh, k, maxd)
+                del Xh
+            out["c4_shard"] = res
+            f.close()
+            ds.close()
+            qs.close()
+            del Xd, Qd
+        except Exception as e:          # noqa: BLE001
+            out["c4_shard"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ C5 shard
+    if "c5" in which:
+        try:
+            n, d, Tall, G, min_leaf, k, nq = 10_000_000, 768, 128, 8, 256, 50, 100_000
+            T = Tall // G
+            cfg = rp.rpTreeCfg(min_leaf, n, d)
+            maxd, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+            g = torch.Generator(device=dev).manual_seed(99)
+            Xd = torch.empty(n, d, device=dev, dtype=torch.bfloat16)
+            for r0 in range(0, n, 1_000_000):
+                x = torch.randn(1_000_000, d, device=dev, dtype=torch.float32, generator=g)
+                Xd[r0:r0 + 1_000_000] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+            del x
+            qi = torch.randint(0, n, (nq,), device=dev, generator=g)
+            Qd = (Xd[qi].float() * 1.001 + 0.003).to(torch.bfloat16).contiguous()
+            torch.cuda.synchronize(dev)
+            ds = rp.Dataset.from_torch(ctx, Xd)
+            qs = rp.Dataset.from_torch(ctx, Qd)
+            _, R = gen.forest_hyperplanes(1235137, T, maxd, pnz, d)
+            f, b_ms, q_ms, pb, pq, cand, _ = _timed_leg(rp, _lib, L_, C, torch, ctx, ds, qs, R, maxd,
+                                                        min_leaf, k, steps)
+            w_ms, w_n = pb["project_wide"]
+            cols = T * maxd / max(w_n / steps, 1)
+            roof = _roof("proj_bf16x3 (bf16 rows x hyperplanes split into three bf16 terms, %.0f hyperplanes "
+                         "per launch)" % cols, w_ms / max(w_n, 1), int(w_n / steps),
+                         n * d * 2 + d * cols * 8 + n * cols * 4, 2.0 * n * d * cols, MFMA_BF16_PEAK_TF,
+                         "algorithmic flops 2*N*d*C against the dense bf16 MFMA peak; the kernel ISSUES three "
+                         "times that (r = r_hi + r_mid + r_lo keeps 24 bits: the 1e-5 tolerance)")
+            roof["mfma_issued_frac"] = 3.0 * roof["mfma_frac"]
+            res = {"workload": "C5 shard: %d x %d bf16 unit-norm rows, %d of %d trees (one of %d GPUs), minLeaf %d, "
+                               "maxDepth %d, pnz %.4f, k=%d, %d queries" %
+                               (n, d, T, Tall, G, min_leaf, maxd, pnz, k, nq),
+                   "dtype": "bf16", "projection_mode": "mfma (bf16 MFMA 16x16x32, f32 accumulation, 1e-5 |x||r|)",
+                   "build_ms": b_ms, "value": n / (b_ms * 1e-3), "unit": "vectors/s",
+                   "knn_ms_per_batch": q_ms, "knn_queries_per_s": nq / (q_ms * 1e-3),
+                   "candidates_per_query": cand,
+                   "build_breakdown_ms": {"projection_total": pb["project"][0] / steps,
+                                          "split_total": pb["split"][0] / steps},
+                   "roofline": roof,
+                   "roofline_knn": _roof("knn_fused<bf16>", pq["knn_topk"][0] / max(pq["knn_topk"][1], 1),
+                                         pq["knn_topk"][1], nq * cand * d * 2, 0.0, 0.0,
+                                         "nq x candidates x d x 2 B")}
+            if with_cpu:
+                from oracle import oracle as orc
+                Xh = np.empty((n, d), dtype=np.float32)
+                for r0 in range(0, n, 1_000_000):
+                    Xh[r0:r0 + 1_000_000] = Xd[r0:r0 + 1_000_000].float().cpu().numpy()
+                Qh = Qd[:20].float().cpu().numpy().astype(np.float64)
+                res["cpu_baseline"], _ = cpu_dense(orc, Xh, R, min_leaf, T, 300_000, f, Qh, k, maxd)
+                del Xh
+            out["c5_shard"] = res
+            f.close()
+            ds.close()
+            qs.close()
+            del Xd, Qd
+        except Exception as e:          # noqa: BLE001
+            out["c5_shard"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -60,7 +382,19 @@ def main():
                          "kernel (values within 1e-5*|x||r|), exact = reference summation order "
                          "(bit-identical leaf assignment); the other mode is timed as a side leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", default="c3,c4,c5",
+                    help="comma list of the other BASELINE configurations to time after C2 at N = 1 "
+                         "(c3, c4, c5; 'none' to skip): build / kNN / roofline / cpu_baseline each")
+    ap.add_argument("--_other-child", dest="other_child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.other_child:       # child process of the other_configs leg: ONE JSON line on stdout
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        res = other_configs([w for w in args.other_configs.split(",") if w], max(1, min(args.steps, 5)),
+                            not args.no_cpu_baseline)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -324,7 +658,7 @@ def main():
         t_cpu = time.perf_counter() - t0
         cpu_build = N / (t_cpu / nt * T)
         # (ii) courtesy upper baseline: trees in parallel over all host cores
-        nt_all = min(T, max(8, ncores))
+        nt_all = T                       # the whole forest on all cores
         t0 = time.perf_counter()
         f_all = orc.forest_build_dense(Xh, R[:nt_all], args.min_leaf, threads=ncores)
         t_all = time.perf_counter() - t0
@@ -361,15 +695,69 @@ def main():
                "cores_all": ncores,
                "value_all_cores": cpu_build_all,
                "knn_queries_per_s_all_cores": nq_all / t_cpuq_all,
-               "sample_all_cores": "courtesy upper baseline (SURVEY 8d-ii): %d trees built "
-                                   "concurrently on %d threads, scaled to %d trees; %d queries "
-                                   "answered concurrently" % (nt_all, ncores, T, nq_all),
+               "sample_all_cores": "courtesy upper baseline (SURVEY 8d-ii): all %d trees built "
+                                   "concurrently on %d threads (%.1f s, nothing scaled); %d queries "
+                                   "answered concurrently" % (nt_all, ncores, t_all, nq_all),
                "knn_ids_identical_to_gpu": "%d/%d" % (same, nqs),
                "trees_identical_to_gpu_exact_mode": "%d/%d" % (same_trees, ncmp),
                # recall@k of `knn` (duplicates kept) against brute force on the same queries:
                # the reference restatement vs the device
                "recall_at_k_reference_vs_gpu": [hit_ref / float(min(nqs, nq_eval) * k),
                                                 hit_gpu / float(min(nqs, nq_eval) * k)]}
+
+    # ---- the exchange on the hardware this run has: a 4-tree shard (what one of 8 GPUs holds at
+    # C2) answered through record -> ncclAllGather -> merge on the ONE-rank communicator
+    # (comm_force_exchange), against the same shard without the exchange ----
+    exch = None
+    if rank == 0 and world == 1 and T >= 8:
+        try:
+            Ts = T // 8
+            sf4 = sharded.ShardedForest(comm, dss, R[:Ts], maxd, args.min_leaf, mode)
+            tms = {}
+            for force in (0, 1):
+                ctx.set_option("comm_force_exchange", force)
+                for _ in range(3):
+                    knn(sf4, rp.RPT_KNN_KEEP_DUPLICATES)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(max(args.steps, 5)):
+                    knn(sf4, rp.RPT_KNN_KEEP_DUPLICATES)
+                barrier()
+                tms[force] = (time.perf_counter() - t0) / max(args.steps, 5) * 1e3
+            ctx.set_option("comm_force_exchange", 0)
+            t0 = time.perf_counter()
+            for _ in range(max(args.steps, 5)):
+                sharded.ShardedForest(comm, dss, R[:Ts], maxd, args.min_leaf, mode).close()
+            barrier()
+            b4 = (time.perf_counter() - t0) / max(args.steps, 5) * 1e3
+            exch = {"trees": Ts, "queries": nq, "k": k, "record_bytes": sharded.record_layout(nq, k)[0],
+                    "knn_ms_without_exchange": tms[0], "knn_ms_with_forced_exchange": tms[1],
+                    "exchange_one_rank_ms": tms[1] - tms[0], "build_ms": b4,
+                    "note": "one rank: the all-gather moves the record inside the device; what is "
+                            "measured is the enqueue + merge + status-scan cost of the path every rank "
+                            "of an N-GPU run takes, not xGMI transfer time"}
+            sf4.close()
+        except Exception as e:      # noqa: BLE001
+            exch = {"error": "%s: %s" % (type(e).__name__, e)}
+            ctx.set_option("comm_force_exchange", 0)
+
+    # ---- the other BASELINE configurations, in a child process (a crash or hang there cannot
+    # lose this line) ----
+    other = None
+    if rank == 0 and world == 1 and args.other_configs not in ("", "none"):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--_other-child", "--other-configs",
+               args.other_configs, "--steps", str(args.steps)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        try:
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=420)
+            line = pr.stdout.decode().strip().splitlines()[-1] if pr.stdout.strip() else ""
+            other = json.loads(line) if line else {"error": "child exited with %d, no output" % pr.returncode}
+        except subprocess.TimeoutExpired:
+            other = {"error": "other_configs child exceeded 420 s"}
+        except Exception as e:      # noqa: BLE001
+            other = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         p_ms, p_n = prof["project"]
@@ -516,7 +904,8 @@ def main():
                     "all-f64 kernel",
                     "exchange": None if world == 1 else
                     "one ncclAllGather of %d B records per rank on the ctx streams "
-                    "(rpt_knn_sharded_dev), merge on every device" % sharded.record_layout(nq, k)[0]},
+                    "(rpt_knn_sharded_dev), merge on every device" % sharded.record_layout(nq, k)[0],
+                    "exchange_one_rank": exch},
             "recall_at_10": {"forest_knn_dedup_vs_brute_force": recall_knn,
                              "reference_recallWith_mean_per_tree": recall_ref,
                              "queries": nq_eval,
@@ -534,6 +923,7 @@ def main():
                 "note": "exact = reference summation order, bit-identical to the oracle; "
                         "flips are points whose projection is within rounding of a median"},
             "forest_stats": f_loc.stats(),
+            "other_configs": other,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -157,14 +157,28 @@ hipError_t ctx_sync(rpt_ctx* ctx) {
   return e;
 }
 
+// Returns the cache of the CURRENT device to the driver: after hipDeviceSynchronize every stream
+// of that device has drained, so its cached blocks and its blocks waiting for a stream
+// synchronisation are all idle.  Other devices (other contexts, possibly driven by other host
+// threads: rpt_comm_init) are not touched — their streams were not synchronised here.
 void dev_trim() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  for (Pending& q : g_pool_pending) (void)hipFree(q.p);
-  g_pool_pending.clear();
-  for (auto& kv : g_pool_free) {
-    for (Block& b : kv.second) (void)hipFree(b.p);
-    kv.second.clear();
+  for (size_t i = 0; i < g_pool_pending.size();) {
+    if (g_pool_pending[i].dev == dev) {
+      (void)hipFree(g_pool_pending[i].p);
+      g_pool_pending[i] = g_pool_pending.back();
+      g_pool_pending.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  auto it = g_pool_free.find(dev);
+  if (it != g_pool_free.end()) {
+    for (Block& b : it->second) (void)hipFree(b.p);
+    it->second.clear();
   }
 }
 

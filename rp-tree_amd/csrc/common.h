@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,18 @@ void dev_free(void* p);
 void dev_trim();
 void dev_set_stream(hipStream_t s);          // stream of the calling thread's current entry point
 hipError_t stream_sync(hipStream_t s);       // hipStreamSynchronize + release blocks freed on s
+
+// "done once per DEVICE" flag for hipFuncSetAttribute calls: function attributes belong to the
+// device's copy of the code object, and one process may drive several devices from several host
+// threads (rpt_comm_init).  first(dev) is true exactly once per device (devices 0..63).
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool first(int dev) {
+    const unsigned long long bit = 1ULL << (dev & 63);
+    return (mask.fetch_or(bit) & bit) == 0;
+  }
+  void undo(int dev) { mask.fetch_and(~(1ULL << (dev & 63))); }
+};
 
 // simple owned device buffer
 template <class T>

@@ -1377,15 +1377,14 @@ int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int kvalid, int
                     const CodeOut* co /* null: no codes from this pass */) {
   constexpr int WPB = 8;
   constexpr size_t smem = wide_smem_bytes<TC, D, CBT, KS, WPB>();
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device: one process may drive several (rpt_comm_init)
+  if (attr_once.first(ctx->device)) {
     RPT_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     RPT_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
   }
   if (co)
     hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, true>), dim3((unsigned)blocks),
@@ -1548,13 +1547,12 @@ int32_t launch_bf16x3_pass(rpt_ctx* ctx, const rpt_dataset* ds, const uint4* Aim
   int64_t blocks = ntiles < ctx->n_cu ? ntiles : ctx->n_cu;
   if (blocks < 1) blocks = 1;
   constexpr size_t smem = (size_t)2 * kB3KC * 3 * CBT * 64 * 16;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;
+  if (attr_once.first(ctx->device)) {
     RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
   }
   if (nch == 2)
     hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), smem,
@@ -1692,12 +1690,10 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
     if (!whole) RPT_TRY(ensure_csr_split(ctx, ds, k_mid));
     const size_t smem = whole ? tile32 : half32;
     auto kern = fused ? proj_csr_lds32<T, true> : proj_csr_lds32<T, false>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[fused]) {
+    static DeviceOnce attr_once[2];
+    if (attr_once[fused].first(ctx->device))
       RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kLdsMax));
-      attr_done[fused] = true;
-    }
     for (int b = 0; b < nblk; ++b) {
       const int c0 = b * CB;
       const int ncol = C - c0 < CB ? C - c0 : CB;

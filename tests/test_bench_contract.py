@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-                          "--npoints", "200000", "--trees", "8", "--nq", "1000", "--no-cpu-baseline"],
+                          "--npoints", "200000", "--trees", "8", "--nq", "1000", "--no-cpu-baseline",
+                          "--other-configs", "none"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
@@ -34,6 +35,26 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert j["knn"]["value"] > 0 and j["knn"]["unit"] == "queries/s"
+    ex = j["knn"]["exchange_one_rank"]          # record -> ncclAllGather -> merge really ran
+    assert "error" not in ex and ex["trees"] == 1 and ex["knn_ms_with_forced_exchange"] > 0
+    assert j["other_configs"] is None
+
+
+@pytest.mark.gpu
+def test_other_configs_child_reports_c3_with_its_roofline():
+    """The other_configs leg (a child process of bench.py): BASELINE configs[2] (C3, 1 M x 784 CSR)
+    with build / kNN times and a roofline object for the CSR projection kernel."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--_other-child",
+                          "--other-configs", "c3", "--steps", "1", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])["c3"]
+    assert "error" not in j, j
+    assert j["build_ms"] > 0 and j["knn_queries_per_s"] > 0
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1.0 and "proj_csr" in r["kernel"]
 
 
 def test_bench_gpus_n_needs_no_launcher():
