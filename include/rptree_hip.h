@@ -179,6 +179,25 @@ int32_t rpt_forest_get_nodes(rpt_forest* f, double* thr_host, double* mglo_host,
                              double* mghi_host /* each [T][2^L-1] */);
 /* projections computed during the build, [T][L][N] in the compute type (parity tests) */
 int32_t rpt_forest_get_proj(rpt_forest* f, void* proj_host);
+/* ---- streaming build: `forest` / `tree` (Conduit.hs:58-121) = chunkedAccum (Conduit.hs:169-176)
+ * folding insertMulti / insert (Internal.hs:245-297) over chunks of `chunk` points (the last one may
+ * be shorter, C.chunksOf).  The reference's semantics, including its quirks: a chunk part that
+ * reaches a Bin is split at ITS OWN median and the thresholds are averaged ((thr0 + thr) / 2,
+ * Internal.hs:281), margins fold by (max, min) (:280, :86-87); an EMPTY part reaching a Bin replaces
+ * the subtree by an empty Tip (:277) — the points stored below it are lost (rpt_forest_get_topology
+ * reports how many).  With chunk >= n the result is the batch forest.  Dense rows only.
+ * The shape of a streamed tree depends on (n, chunk, minLeaf, maxDepth): such a forest carries an
+ * EXPLICIT topology — heap slots 0 .. 2^(maxDepth+1)-2, kind 0 absent / 1 Bin / 2 Tip, the points of
+ * Tip h = perm[t][leaf_off[h] .. leaf_off[h] + leaf_len[h]) — the same for every tree.
+ * rpt_forest_get_perm / _get_nodes return [T][n] ids (the first `held` of a row are valid) and
+ * [T][slots] node arrays; rpt_candidates / rpt_knn_* work on the handle (general query path). */
+int32_t rpt_forest_stream_build(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                                int32_t L, int32_t min_leaf, int64_t chunk, int32_t flags,
+                                rpt_forest** out);
+/* any output pointer may be NULL; kind / leaf_off / leaf_len hold *slots entries */
+int32_t rpt_forest_get_topology(rpt_forest* f, int64_t* slots, int8_t* kind_host,
+                                int64_t* leaf_off_host, int64_t* leaf_len_host, int64_t* held,
+                                int64_t* dropped);
 /* import a forest built elsewhere (e.g. deserialiseRPForest, Internal.hs:191-196) */
 int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
                           int32_t L, int32_t min_leaf, const int32_t* perm_host,

@@ -69,6 +69,8 @@ def lib():
         L.rpo_normal.restype = C.c_double
         L.rpo_keep_counts.restype = C.c_int64
         L.rpo_recall_with_dense_values.restype = C.c_double
+        L.rpo_stream_candidates_dense.restype = C.c_int64
+        L.rpo_stream_knn_dense.restype = C.c_int32
     return _lib
 
 
@@ -442,6 +444,38 @@ def stream_forest_dense(X, R, min_leaf, chunk):
                                   _p(leaf_off, _i64p), _p(leaf_len, _i64p), _p(leaf_ids, _i32p),
                                   _p(held, _i64p))
     return StreamForest(N, L, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids, held)
+
+
+def _sargs(sf):
+    i8p = C.POINTER(C.c_int8)
+    return (sf.kind.ctypes.data_as(i8p), _p(sf.thr, _f64p), _p(sf.mglo, _f64p), _p(sf.mghi, _f64p),
+            _p(sf.leaf_off, _i64p), _p(sf.leaf_len, _i64p), _p(sf.leaf_ids, _i32p))
+
+
+def stream_candidates_dense(sf, R, q, t):
+    """RPTree.hs:289-314 on tree t of a streamed forest (R = its hyperplane block [T][L][d])"""
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    T, L, d = R.shape
+    out = np.empty(max(sf.N, 1), dtype=np.int32)
+    m = lib().rpo_stream_candidates_dense(_p(q, _f64p), C.c_int32(d), _p(R, _f64p), C.c_int32(T),
+                                          C.c_int32(L), C.c_int64(sf.N), *_sargs(sf), C.c_int32(t),
+                                          _p(out, _i32p), C.c_int64(len(out)))
+    return out[:m].copy()
+
+
+def stream_knn_dense(sf, R, X, q, k, dedup=0):
+    """RPTree.hs:168-176 `knn metricL2` over a streamed forest -> (ids, dist)"""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    T, L, d = R.shape
+    ids = np.empty(k, dtype=np.int32)
+    dist = np.empty(k, dtype=np.float64)
+    m = lib().rpo_stream_knn_dense(_p(X, _f64p), C.c_int64(sf.N), C.c_int32(d), _p(q, _f64p),
+                                   _p(R, _f64p), C.c_int32(T), C.c_int32(L), *_sargs(sf),
+                                   C.c_int32(k), C.c_int32(int(dedup)), _p(ids, _i32p), _p(dist, _f64p))
+    return ids[:m], dist[:m]
 
 
 def brute_knn_dense(X, q, k):

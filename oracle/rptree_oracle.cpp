@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <functional>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -1189,6 +1190,67 @@ void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double
   DenseData D{X, N, d};
   stream_forest(D, R, T, L, minLeaf, chunk, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids,
                 held);
+}
+
+
+// ---- queries on a streamed tree: RPTree.hs:289-314 `candidates` / :168-176 `knn` walk the RPT
+// value whatever built it; on the heap arrays of rpo_stream_forest_dense a Tip is kind 2 with
+// its payload at leaf_off / leaf_len, a Bin kind 1; kind 0 never hangs below a Bin.
+int64_t rpo_stream_candidates_dense(const double* q, int32_t d, const double* R, int32_t T,
+                                    int32_t L, int64_t N, const int8_t* kind, const double* thr,
+                                    const double* mglo, const double* mghi, const int64_t* leaf_off,
+                                    const int64_t* leaf_len, const int32_t* leaf_ids, int32_t t,
+                                    int32_t* out, int64_t cap) {
+  const int64_t slots = ((int64_t)1 << (L + 1)) - 1;
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<double> projq((size_t)L);
+  for (int32_t l = 0; l < L; ++l) {
+    const SparseVec& r = all[(size_t)t * L + l];
+    projq[l] = rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+  }
+  const int8_t* kd = kind + t * slots;
+  const double *th = thr + t * slots, *lo = mglo + t * slots, *hi = mghi + t * slots;
+  const int64_t *lo_off = leaf_off + t * slots, *ln = leaf_len + t * slots;
+  std::vector<int32_t> res;
+  std::function<void(int32_t, int64_t)> go = [&](int32_t level, int64_t h) {
+    if (kd[h] != 1) {  // :299 Tip
+      if (kd[h] == 2)
+        for (int64_t i = 0; i < ln[h]; ++i) res.push_back(leaf_ids[(int64_t)t * N + lo_off[h] + i]);
+      return;
+    }
+    const double proj = projq[level];
+    const double dl = std::fabs(lo[h] - proj), dr = std::fabs(hi[h] - proj);
+    if (proj < th[h] && dl > dr) {  // :309-310
+      go(level + 1, 2 * h + 1);
+      go(level + 1, 2 * h + 2);
+    } else if (proj < th[h]) {  // :311
+      go(level + 1, 2 * h + 1);
+    } else if (proj > th[h] && dl < dr) {  // :312-313
+      go(level + 1, 2 * h + 1);
+      go(level + 1, 2 * h + 2);
+    } else {  // :314
+      go(level + 1, 2 * h + 2);
+    }
+  };
+  go(0, 0);
+  for (int64_t i = 0; i < (int64_t)res.size() && i < cap; ++i) out[i] = res[i];
+  return (int64_t)res.size();
+}
+
+int32_t rpo_stream_knn_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                             int32_t T, int32_t L, const int8_t* kind, const double* thr,
+                             const double* mglo, const double* mghi, const int64_t* leaf_off,
+                             const int64_t* leaf_len, const int32_t* leaf_ids, int32_t k,
+                             int32_t dedup, int32_t* out_ids, double* out_dist) {
+  DenseData D{X, N, d};
+  std::vector<DistId> cs;
+  std::vector<int32_t> buf((size_t)(N > 0 ? N : 1));
+  for (int32_t t = 0; t < T; ++t) {  // :176 fold over the IntMap, ascending key
+    const int64_t m = rpo_stream_candidates_dense(q, d, R, T, L, N, kind, thr, mglo, mghi, leaf_off,
+                                                  leaf_len, leaf_ids, t, buf.data(), N);
+    for (int64_t i = 0; i < m; ++i) cs.push_back(DistId{D.metric(buf[i], q), buf[i]});
+  }
+  return topk_from(cs, k, dedup, out_ids, out_dist);
 }
 
 }  // extern "C"

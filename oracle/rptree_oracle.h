@@ -228,6 +228,19 @@ void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double
                              double* mglo, double* mghi, int64_t* leaf_off, int64_t* leaf_len,
                              int32_t* leaf_ids, int64_t* held);
 
+/* candidates (RPTree.hs:289-314) / knn (:168-176, metricL2) over the heap arrays of a streamed
+ * forest: Tip = kind 2 (payload at leaf_off / leaf_len), Bin = kind 1 */
+int64_t rpo_stream_candidates_dense(const double* q, int32_t d, const double* R, int32_t T,
+                                    int32_t L, int64_t N, const int8_t* kind, const double* thr,
+                                    const double* mglo, const double* mghi, const int64_t* leaf_off,
+                                    const int64_t* leaf_len, const int32_t* leaf_ids, int32_t t,
+                                    int32_t* out, int64_t cap);
+int32_t rpo_stream_knn_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                             int32_t T, int32_t L, const int8_t* kind, const double* thr,
+                             const double* mglo, const double* mghi, const int64_t* leaf_off,
+                             const int64_t* leaf_len, const int32_t* leaf_ids, int32_t k,
+                             int32_t dedup, int32_t* out_ids, double* out_dist);
+
 #ifdef __cplusplus
 }
 #endif

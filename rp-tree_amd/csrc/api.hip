@@ -751,6 +751,62 @@ int32_t rpt_forest_build(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_ho
   });
 }
 
+int32_t rpt_forest_stream_build(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
+                                int32_t L, int32_t min_leaf, int64_t chunk, int32_t flags,
+                                rpt_forest** out) {
+  return guarded([&]() -> int32_t {
+    if (ctx) dev_set_stream(ctx->stream);
+    RPT_ARG(out, "out is NULL");
+    *out = nullptr;
+    RPT_ARG(ctx && ds && R_host, "NULL argument");
+    RPT_ARG(T >= 1, "T must be >= 1");
+    RPT_ARG(L >= 0 && L <= 24, "maxDepth of a streamed forest must be in [0,24]");
+    RPT_ARG(min_leaf >= 0, "minLeaf must be >= 0");
+    RPT_ARG(chunk >= 1, "chunk size must be >= 1");
+    RPT_ARG(ds->ctx == ctx, "dataset belongs to another context");
+    RPT_ARG(!ds->csr, "the streaming build takes dense rows");
+    RPT_HIP(hipSetDevice(ctx->device));
+    rpt_forest* f = new (std::nothrow) rpt_forest();
+    if (!f) return fail(RPT_E_NOMEM, "out of host memory");
+    f->ctx = ctx;
+    f->n = ds->n;
+    f->d = ds->d;
+    f->T = T;
+    f->L = L;
+    f->min_leaf = min_leaf;
+    f->pdtype = proj_dtype(ds->dtype);
+    f->nodes = ((int64_t)1 << (L + 1)) - 1;
+    int32_t s = f->perm.alloc((size_t)T * f->n);
+    if (s == RPT_OK) s = f->thr.alloc((size_t)T * f->nodes);
+    if (s == RPT_OK) s = f->mglo.alloc((size_t)T * f->nodes);
+    if (s == RPT_OK) s = f->mghi.alloc((size_t)T * f->nodes);
+    if (s == RPT_OK) s = upload_R(ctx, R_host, (size_t)T * L * f->d, f->R);
+    if (s == RPT_OK) s = stream_build_forest(ctx, ds, f, chunk, flags);
+    if (s != RPT_OK) {
+      delete f;
+      return s;
+    }
+    *out = f;
+    return RPT_OK;
+  });
+}
+
+int32_t rpt_forest_get_topology(rpt_forest* f, int64_t* slots, int8_t* kind_host,
+                                int64_t* leaf_off_host, int64_t* leaf_len_host, int64_t* held,
+                                int64_t* dropped) {
+  return guarded([&]() -> int32_t {
+    RPT_ARG(f, "forest is NULL");
+    RPT_ARG(f->xtopo, "this forest has the implicit batch topology (rpt_topology enumerates it)");
+    if (slots) *slots = f->nodes;
+    if (kind_host) std::memcpy(kind_host, f->xkind_h.data(), (size_t)f->nodes);
+    if (leaf_off_host) std::memcpy(leaf_off_host, f->xoff_h.data(), (size_t)f->nodes * 8);
+    if (leaf_len_host) std::memcpy(leaf_len_host, f->xlen_h.data(), (size_t)f->nodes * 8);
+    if (held) *held = f->held;
+    if (dropped) *dropped = f->dropped;
+    return RPT_OK;
+  });
+}
+
 int32_t rpt_forest_import(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_host, int32_t T,
                           int32_t L, int32_t min_leaf, const int32_t* perm_host,
                           const double* thr_host, const double* mglo_host,
@@ -919,6 +975,7 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
     RPT_ARG(data->csr == queries->csr, "data and queries must both be dense or both CSR");
     RPT_ARG(k >= 1, "k must be >= 1");
     RPT_ARG(total, "total is NULL");
+    if (f->xtopo) return fail(RPT_E_UNSUPPORTED, "knnH on a streamed forest is not implemented");
     return knn_h(ctx, f, data, queries, k, off_host, ids_host, dist_host, cap, total);
   });
 }

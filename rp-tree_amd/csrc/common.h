@@ -230,6 +230,17 @@ struct rpt_forest {
   rpt::DevBuf<char> proj;               // [T][L][N] in pdtype
   rpt::DevBuf<double> R;                // [T][L][d] hyperplanes (device copy)
   int64_t tie_nodes = 0, big_mid_nodes = 0;
+  // Explicit topology (forests built by the streaming insert, rpt_forest_stream_build): the shape
+  // of a streamed tree depends on the chunk sizes, so it is stored: heap slots 0 .. 2^(L+1)-2
+  // (`nodes` of them), kind 0 = absent, 1 = Bin, 2 = Tip; a Tip's points are
+  // perm[t][xoff[h] .. xoff[h] + xlen[h]).  The same for every tree (it is a function of
+  // (N, chunk, minLeaf, maxDepth) alone), which is why it is stored once.
+  bool xtopo = false;
+  std::vector<int8_t> xkind_h;
+  std::vector<int64_t> xoff_h, xlen_h;
+  rpt::DevBuf<int8_t> xkind;
+  rpt::DevBuf<int64_t> xoff, xlen;
+  int64_t held = 0, dropped = 0;  // points stored per tree / lost to Internal.hs:277
 };
 
 namespace rpt {
@@ -257,6 +268,10 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
 
 // ---- split / build (split.hip) ----------------------------------------------------------
 int32_t build_forest(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode);
+// streaming insert of the dataset in chunks of `chunk` points (Conduit.hs:147-176 over
+// Internal.hs:245-297); f->nodes = 2^(L+1)-1, node arrays and perm allocated by the caller
+int32_t stream_build_forest(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int64_t chunk,
+                            int32_t mode);
 int32_t split_segments(rpt_ctx* ctx, const double* key_host, int64_t n, int32_t* perm_io_host,
                        const int64_t* seg_off, const int64_t* seg_len, int32_t S,
                        double* thr_mg_host);

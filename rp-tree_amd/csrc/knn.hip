@@ -98,6 +98,83 @@ __device__ inline void traverse(const double* __restrict__ thr, const double* __
   }
 }
 
+// The same walk over an EXPLICIT topology (forests of the streaming build, common.h rpt_forest:
+// kind 0 absent / 1 Bin / 2 Tip per heap slot, a Tip's range = (xoff, xlen)); same stackless
+// scheme, nothing to replay on a pop.
+template <class TK, class Emit>
+__device__ inline void traverse_x(const double* __restrict__ thr, const double* __restrict__ mglo,
+                                  const double* __restrict__ mghi, const int8_t* __restrict__ kind,
+                                  const int64_t* __restrict__ xoff, const int64_t* __restrict__ xlen,
+                                  const TK* __restrict__ pq, int64_t pq_stride, Emit emit) {
+  unsigned int pending = 0, heap = 0;
+  int level = 0;
+  for (;;) {
+    for (;;) {
+      if (kind[heap] != 1) {  // Tip (RPTree.hs:299); an absent slot holds nothing
+        if (kind[heap] == 2) emit((int)xoff[heap], (int)xlen[heap]);
+        break;
+      }
+      const double proj = (double)pq[(int64_t)level * pq_stride];  // RPTree.hs:303-304
+      const double th = thr[heap];
+      const double dl = fabs(mglo[heap] - proj);
+      const double dr = fabs(mghi[heap] - proj);
+      const bool both = (proj < th && dl > dr) || (proj > th && dl < dr);
+      if (both) {
+        pending |= 1u << level;
+        heap = 2 * heap + 1;
+      } else if (proj < th) {
+        heap = 2 * heap + 1;
+      } else {
+        heap = 2 * heap + 2;
+      }
+      ++level;
+    }
+    if (!pending) break;
+    const int l = 31 - __clz((int)pending);
+    pending &= ~(1u << l);
+    heap = 2 * (((heap + 1) >> (level - l)) - 1) + 2;
+    level = l + 1;
+  }
+}
+
+template <class TK>
+__global__ void count_x_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
+                               const double* __restrict__ mghi, int64_t nodes,
+                               const int8_t* __restrict__ kind, const int64_t* __restrict__ xoff,
+                               const int64_t* __restrict__ xlen, const TK* Pq, int64_t nq, int T, int L,
+                               int* __restrict__ cnt_cand, int* __restrict__ cnt_rng) {
+  const int64_t q = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int nc = 0, nr = 0;
+    traverse_x<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, kind, xoff, xlen,
+                   Pq + (int64_t)t * L * nq + q, nq, [&](int, int n) {
+                     nc += n;
+                     ++nr;
+                   });
+    cnt_cand[q * T + t] = nc;
+    cnt_rng[q * T + t] = nr;
+  }
+}
+
+template <class TK>
+__global__ void ranges_x_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
+                                const double* __restrict__ mghi, int64_t nodes,
+                                const int8_t* __restrict__ kind, const int64_t* __restrict__ xoff,
+                                const int64_t* __restrict__ xlen, const TK* Pq, int64_t nq, int T, int L,
+                                int64_t N, const int64_t* __restrict__ cand_off,
+                                const int64_t* __restrict__ rng_off, Range* __restrict__ ranges) {
+  const int64_t q = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int64_t r = rng_off[q * T + t];
+    int64_t pos = cand_off[q * T + t] - cand_off[q * T];
+    traverse_x<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, kind, xoff, xlen,
+                   Pq + (int64_t)t * L * nq + q, nq, [&](int off, int n) {
+                     ranges[r++] = Range{(int64_t)t * N + off, n, (int)pos};
+                     pos += n;
+                   });
+  }
+}
+
 // per (query, tree) counts.  grid = nq blocks, blockDim >= T (multiple of 64).
 template <class TK>
 __global__ void count_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
@@ -1763,9 +1840,15 @@ int32_t make_plan_t(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, QueryPlan
   if (nq == 0) return RPT_OK;
   const int threads = T <= 64 ? 64 : (T <= 128 ? 128 : 256);
   const TK* Pq = reinterpret_cast<const TK*>(pl.Pq.p);
-  hipLaunchKernelGGL(count_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
-                     f->mglo.p, f->mghi.p, f->nodes, Pq, nq, T, L, f->min_leaf, f->n,
-                     pl.cnt_cand.p, pl.cnt_rng.p);
+  if (f->xtopo)
+    hipLaunchKernelGGL(count_x_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                       f->mglo.p, f->mghi.p, f->nodes, (const int8_t*)f->xkind.p,
+                       (const int64_t*)f->xoff.p, (const int64_t*)f->xlen.p, Pq, nq, T, L,
+                       pl.cnt_cand.p, pl.cnt_rng.p);
+  else
+    hipLaunchKernelGGL(count_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                       f->mglo.p, f->mghi.p, f->nodes, Pq, nq, T, L, f->min_leaf, f->n,
+                       pl.cnt_cand.p, pl.cnt_rng.p);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, pl.cnt_cand.p, m, pl.cand_off.p);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, pl.cnt_rng.p, m, pl.rng_off.p);
   RPT_HIP(hipGetLastError());
@@ -1776,9 +1859,15 @@ int32_t make_plan_t(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* q, QueryPlan
   pl.total_cand = tot[0];
   pl.total_rng = tot[1];
   RPT_TRY(pl.ranges.alloc((size_t)pl.total_rng));
-  hipLaunchKernelGGL(ranges_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
-                     f->mglo.p, f->mghi.p, f->nodes, Pq, nq, T, L, f->min_leaf, f->n,
-                     pl.cand_off.p, pl.rng_off.p, pl.ranges.p);
+  if (f->xtopo)
+    hipLaunchKernelGGL(ranges_x_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                       f->mglo.p, f->mghi.p, f->nodes, (const int8_t*)f->xkind.p,
+                       (const int64_t*)f->xoff.p, (const int64_t*)f->xlen.p, Pq, nq, T, L, f->n,
+                       pl.cand_off.p, pl.rng_off.p, pl.ranges.p);
+  else
+    hipLaunchKernelGGL(ranges_kernel<TK>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
+                       f->mglo.p, f->mghi.p, f->nodes, Pq, nq, T, L, f->min_leaf, f->n,
+                       pl.cand_off.p, pl.rng_off.p, pl.ranges.p);
   RPT_HIP(hipGetLastError());
   return RPT_OK;
 }
@@ -2129,8 +2218,9 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
           "query dtype must have the forest's projection type (f64 vs f32/bf16)");
   const int vote = (flags >> 8) & 0xffff;  // RPT_KNN_VOTE(v)
+  // (the fused kernels walk the implicit batch topology: streamed forests take the general path)
   const bool fused = k <= kFK && f->T <= 1024 && (!ctx->opt.knn_general || vote > 0) &&
-                     (size_t)data->d * 8 <= 32 * 1024;
+                     (size_t)data->d * 8 <= 32 * 1024 && !f->xtopo;
   if (vote > 0 && (!fused || data->csr))
     return fail(RPT_E_UNSUPPORTED, "RPT_KNN_VOTE: dense data, k <= 64 and at most 1024 trees");
   if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);

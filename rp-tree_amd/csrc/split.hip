@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void small_sort_kernel(
   const int np = next_pow2(n);
   TK* skey = reinterpret_cast<TK*>(smem);
   int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
-  Keys<TK> K{P + (int64_t)t * L * N, N, level, tb};
+  Keys<TK> K{P + (int64_t)t * L * N, N, level, tb ? tb + (int64_t)t * N : nullptr};  // tb: [T][N]
   const int32_t* s = src + (int64_t)t * N + sg.off;
   for (int i = threadIdx.x; i < np; i += blockDim.x) {
     if (i < n) {
@@ -3443,7 +3443,7 @@ __global__ __launch_bounds__(256) void gsort_chunk_kernel(int32_t* buf, int64_t 
   const int np = next_pow2(n);
   TK* skey = reinterpret_cast<TK*>(smem);
   int* sid = reinterpret_cast<int*>(smem + (size_t)np * sizeof(TK));
-  Keys<TK> K{P + (int64_t)g.t * L * N, N, level, tb};
+  Keys<TK> K{P + (int64_t)g.t * L * N, N, level, tb ? tb + (int64_t)g.t * N : nullptr};
   int32_t* s = buf + g.off + c0;
   for (int i = threadIdx.x; i < np; i += blockDim.x) {
     if (i < n) {
@@ -3470,7 +3470,7 @@ __global__ __launch_bounds__(256) void gsort_merge_kernel(const int32_t* __restr
   const GSeg g = gs[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= g.n) return;
-  Keys<TK> K{P + (int64_t)g.t * L * N, N, level, tb};
+  Keys<TK> K{P + (int64_t)g.t * L * N, N, level, tb ? tb + (int64_t)g.t * N : nullptr};
   const int32_t* s = in + g.off;
   const int id = s[i];
   const int64_t run = i / w, pair0 = (run & ~1LL) * w;
@@ -4246,7 +4246,380 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   return RPT_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming insert: `forest` / `tree` of Conduit.hs:58-121 = chunkedAccum
+// (Conduit.hs:169-176: C.chunksOf n, the last chunk may be shorter) folding `insert`
+// (Internal.hs:258-297) over the chunks, every tree with the same chunks (insertMulti :245-255).
+//   chunk part reaching a Bin (:272-283)  split at ITS OWN median (stable sort by the level's
+//       projection, cut at n div 2); thr' = (thr0 + thr) / 2, margin' = (max lows, min highs); an
+//       EMPTY part answers `Tip () mempty` (:277): the subtree built so far is dropped
+//   chunk part reaching a Tip (:285-297)  xs' = xs <> xs0 (the new points FIRST); stays a Tip at
+//       maxDepth or with <= minLeaf points, else it is split and both halves start from empty Tips
+// Every size in this recursion is n div 2 of a known size, so WHICH nodes are Bins / Tips, every
+// part's and every Tip's length — the whole evolution of the tree's shape — is a function of
+// (N, chunk, minLeaf, maxDepth) alone and identical for all trees: the host plans a chunk (which
+// segments are sorted at which level, what is copied where), the device does the data-dependent
+// part for all trees at once:
+//   per level of a chunk   gather the level's segments into a working row (chunk parts from the
+//                          previous level's sorted row, Tip contents from the Tip store), stable
+//                          segmented sort by P[t][level][id] with the POSITION in the segment as
+//                          tie-break (small_sort_kernel / gsort with tb = position), fold
+//                          thr / margins into the node arrays (set or average)
+//   per chunk              the Tip store is rewritten in heap order (untouched Tips copied, the
+//                          others = new part ++ old contents)
+// The fold over chunks is sequential by definition (chunk c's medians move the thresholds chunk
+// c + 1 is compared with... in fact only the node arrays and the Tip store carry over); the cost is
+// ~5 launches per (chunk, level).  Projections: all T x L columns for all points up front, the
+// batch kernels.
+// ---------------------------------------------------------------------------------------
+struct XCopy {
+  int32_t src;  // 0 = Tip store A, 1 = previous working row, 2 = iota (value soff + i)
+  int32_t dst;  // 0 = current working row, 1 = new Tip store B
+  int64_t soff, doff, len;
+};
+
+__global__ __launch_bounds__(256) void xs_copy_kernel(const XCopy* __restrict__ descs,
+                                                      const int32_t* __restrict__ A,
+                                                      const int32_t* __restrict__ Wp,
+                                                      int32_t* __restrict__ Wc, int32_t* __restrict__ B,
+                                                      int64_t N) {
+  const XCopy c = descs[blockIdx.x];
+  const int64_t row = (int64_t)blockIdx.y * N;
+  const int32_t* s = (c.src == 0 ? A : Wp) + row + c.soff;
+  int32_t* d = (c.dst == 0 ? Wc : B) + row + c.doff;
+  for (int64_t i = threadIdx.x; i < c.len; i += blockDim.x) d[i] = c.src == 2 ? (int32_t)(c.soff + i) : s[i];
+}
+
+// tb[t][id] = position of the point inside its segment (the stable sort's tie-break)
+__global__ __launch_bounds__(256) void xs_pos_kernel(const Seg* __restrict__ segs,
+                                                     const int32_t* __restrict__ W,
+                                                     int32_t* __restrict__ tb, int64_t N) {
+  const Seg sg = segs[blockIdx.x];
+  const int64_t row = (int64_t)blockIdx.y * N;
+  for (int i = threadIdx.x; i < sg.n; i += blockDim.x) tb[row + W[row + sg.off + i]] = i;
+}
+
+struct XNode {
+  int32_t heap;
+  int32_t avg;  // 0: a new Bin (Internal.hs:292), 1: fold into the Bin that is there (:280-283)
+};
+
+__global__ void xs_fold_kernel(const XNode* __restrict__ xn, int S, const double* __restrict__ tthr,
+                               const double* __restrict__ tlo, const double* __restrict__ thi,
+                               double* thr, double* mglo, double* mghi, int64_t slots) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int64_t t = blockIdx.y, h = t * slots + xn[s].heap;
+  const double a = tthr[t * S + s], lo = tlo[t * S + s], hi = thi[t * S + s];
+  if (!xn[s].avg) {
+    thr[h] = a;
+    mglo[h] = lo;
+    mghi[h] = hi;
+  } else {
+    thr[h] = (thr[h] + a) / 2;               // :281 thr' = (thr0 + thr) / 2
+    mglo[h] = mglo[h] >= lo ? mglo[h] : lo;  // :280 margin0 <> margin = (Max, Min), :86-87
+    mghi[h] = mghi[h] <= hi ? mghi[h] : hi;
+  }
+}
+
+// slots that are not Bins carry no numbers
+__global__ void xs_mask_kernel(const int8_t* __restrict__ kind, int64_t slots, int T, double* thr,
+                               double* mglo, double* mghi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slots * T) return;
+  if (kind[i % slots] != 1) {
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    thr[i] = mglo[i] = mghi[i] = nan;
+  }
+}
+
+template <class TK>
+int32_t stream_build_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int64_t chunk,
+                       int32_t mode) {
+  const int64_t N = f->n;
+  const int T = f->T, L = f->L, min_leaf = f->min_leaf;
+  const int64_t slots = f->nodes;  // 2^(L+1) - 1
+  hipStream_t st = ctx->stream;
+  f->mode = mode;
+  f->xtopo = true;
+  std::vector<int8_t>& kind = f->xkind_h;
+  kind.assign((size_t)slots, 0);
+  kind[0] = 2;  // `Tip () mempty` (Conduit.hs:160)
+  std::vector<int64_t> cnt((size_t)slots, 0), aoff((size_t)slots, 0);
+  f->dropped = 0;
+  {
+    const int64_t tot = (int64_t)T * slots;
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, f->thr.p, tot,
+                       std::numeric_limits<double>::quiet_NaN());
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, f->mglo.p, tot,
+                       std::numeric_limits<double>::quiet_NaN());
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, f->mghi.p, tot,
+                       std::numeric_limits<double>::quiet_NaN());
+  }
+  if (N > 0 && L > 0) {
+    RPT_TRY(f->proj.alloc((size_t)T * L * N * sizeof(TK)));
+    RPT_TRY(project_columns(ctx, ds, f->R.p, T * L, mode, f->proj.p));
+  }
+  const TK* P = reinterpret_cast<const TK*>(f->proj.p);
+  DevBuf<int32_t> bufA, bufB, W0, W1, tb, tmp;
+  const size_t rows = (size_t)T * (size_t)(N > 0 ? N : 1);
+  RPT_TRY(bufB.alloc(rows));
+  RPT_TRY(W0.alloc(rows));
+  RPT_TRY(W1.alloc(rows));
+  RPT_TRY(tb.alloc(rows));
+  RPT_TRY(tmp.alloc(rows));
+  int32_t* A = f->perm.p;  // Tip store, ping-pong with bufB; ends up in f->perm
+  int32_t* B = bufB.p;
+  DevBuf<XCopy> dcopy;
+  DevBuf<Seg> dsegs;
+  DevBuf<GSeg> dglist;
+  DevBuf<XNode> dxn;
+  DevBuf<double> tthr, tlo, thi;
+  DevBuf<unsigned long long> tie;
+  RPT_TRY(tie.alloc(1));
+  RPT_HIP(hipMemsetAsync(tie.p, 0, 8, st));
+
+  auto subtree_points = [&](int64_t h) {
+    int64_t tot = 0;
+    std::vector<int64_t> stk{h};
+    while (!stk.empty()) {
+      const int64_t x = stk.back();
+      stk.pop_back();
+      if (x >= slots) continue;
+      if (kind[(size_t)x] == 2) tot += cnt[(size_t)x];
+      else if (kind[(size_t)x] == 1) {
+        stk.push_back(2 * x + 1);
+        stk.push_back(2 * x + 2);
+      }
+    }
+    return tot;
+  };
+  auto clear_subtree = [&](int64_t h) {
+    std::vector<int64_t> stk{h};
+    while (!stk.empty()) {
+      const int64_t x = stk.back();
+      stk.pop_back();
+      if (x >= slots) continue;
+      if (kind[(size_t)x] == 1) {
+        stk.push_back(2 * x + 1);
+        stk.push_back(2 * x + 2);
+      }
+      kind[(size_t)x] = 0;
+      cnt[(size_t)x] = 0;
+    }
+  };
+
+  struct Item {
+    int64_t h, n, soff;
+    int src;  // where the part lies: 1 = the previous level's working row, 2 = iota
+  };
+  struct LevelPlan {
+    std::vector<XCopy> copies;
+    std::vector<Seg> segs;     // heap = index into xn
+    std::vector<XNode> xn;
+  };
+  struct Fin {  // a Tip that ends the chunk as `part ++ old contents`
+    int64_t h, part_n, old_off, old_n;
+    size_t level, copy_part, copy_old;  // indices of its two copies in plans[level].copies
+  };
+
+  for (int64_t c0 = 0; c0 < N; c0 += chunk) {  // C.chunksOf chunk .| C.foldl
+    const int64_t nc = std::min(chunk, N - c0);
+    // ---- plan the chunk (host; sizes only) ----
+    std::vector<LevelPlan> plans;
+    std::vector<Fin> fins;
+    std::vector<char> touched((size_t)slots, 0);
+    const std::vector<int64_t> aoff_old = aoff, cnt_old = cnt;
+    const std::vector<int8_t> kind_old = kind;
+    std::vector<Item> frontier{Item{0, nc, c0, 2}};
+    for (int level = 0; !frontier.empty(); ++level) {
+      plans.emplace_back();
+      LevelPlan& pl = plans.back();
+      std::vector<Item> next;
+      int64_t woff = 0;
+      for (const Item& it : frontier) {
+        const size_t h = (size_t)it.h;
+        if (kind[h] == 1) {  // Bin (:272)
+          if (level >= L) continue;  // :273-274
+          if (it.n < 1) {            // :277 Nothing -> Tip () mempty: the subtree is lost
+            f->dropped += subtree_points(it.h);
+            clear_subtree(it.h);
+            kind[h] = 2;
+            touched[h] = 1;
+            continue;
+          }
+          pl.copies.push_back(XCopy{it.src, 0, it.soff, woff, it.n});
+          pl.segs.push_back(Seg{woff, (int32_t)it.n, (int32_t)pl.xn.size()});
+          pl.xn.push_back(XNode{(int32_t)it.h, 1});
+          const int64_t nh = it.n / 2;
+          next.push_back(Item{2 * it.h + 1, nh, woff, 1});
+          next.push_back(Item{2 * it.h + 2, it.n - nh, woff + nh, 1});
+          woff += it.n;
+        } else {  // Tip, or never touched = the `z` of :268
+          kind[h] = 2;
+          const int64_t total = it.n + cnt[h];
+          if (level >= L || total <= (int64_t)min_leaf) {  // :287-288 Tip () xs'
+            Fin fn{it.h, it.n, 0, 0, (size_t)level, pl.copies.size(), pl.copies.size() + 1};
+            if (kind_old[h] == 2 && !touched[h]) {
+              fn.old_off = aoff_old[h];
+              fn.old_n = cnt_old[h];
+            }
+            pl.copies.push_back(XCopy{it.src, 1, it.soff, 0, it.n});       // doff: once B is laid out
+            pl.copies.push_back(XCopy{0, 1, fn.old_off, 0, fn.old_n});
+            fins.push_back(fn);
+            cnt[h] = total;
+            touched[h] = 1;
+          } else {  // :290-297 a new Bin over xs' = xs <> xs0, children from empty Tips
+            const int64_t old_n = (kind_old[h] == 2 && !touched[h]) ? cnt_old[h] : 0;
+            pl.copies.push_back(XCopy{it.src, 0, it.soff, woff, it.n});
+            if (old_n) pl.copies.push_back(XCopy{0, 0, aoff_old[h], woff + it.n, old_n});
+            pl.segs.push_back(Seg{woff, (int32_t)total, (int32_t)pl.xn.size()});
+            pl.xn.push_back(XNode{(int32_t)it.h, 0});
+            kind[h] = 1;
+            cnt[h] = 0;
+            touched[h] = 1;
+            const int64_t nh = total / 2;
+            for (int64_t ch = 2 * it.h + 1; ch <= 2 * it.h + 2; ++ch) {
+              kind[(size_t)ch] = 2;
+              cnt[(size_t)ch] = 0;
+              touched[(size_t)ch] = 1;
+            }
+            next.push_back(Item{2 * it.h + 1, nh, woff, 1});
+            next.push_back(Item{2 * it.h + 2, total - nh, woff + nh, 1});
+            woff += total;
+          }
+        }
+      }
+      frontier.swap(next);
+    }
+    // the new Tip store, heap order
+    {
+      int64_t w = 0;
+      for (int64_t h = 0; h < slots; ++h)
+        if (kind[(size_t)h] == 2) {
+          aoff[(size_t)h] = w;
+          w += cnt[(size_t)h];
+        } else {
+          aoff[(size_t)h] = w;
+        }
+    }
+    for (const Fin& fn : fins) {
+      if (kind[(size_t)fn.h] != 2) continue;  // (dropped again later in the same chunk: cannot happen)
+      LevelPlan& pl = plans[fn.level];
+      pl.copies[fn.copy_part].doff = aoff[(size_t)fn.h];
+      pl.copies[fn.copy_old].doff = aoff[(size_t)fn.h] + fn.part_n;
+    }
+    // Tips this chunk did not reach keep their contents
+    if (plans.empty()) plans.emplace_back();
+    for (int64_t h = 0; h < slots; ++h)
+      if (kind[(size_t)h] == 2 && !touched[(size_t)h] && cnt[(size_t)h] > 0)
+        plans[0].copies.push_back(XCopy{0, 1, aoff_old[(size_t)h], aoff[(size_t)h], cnt[(size_t)h]});
+
+    // ---- run it (all trees at once) ----
+    int32_t* Wp = W0.p;
+    int32_t* Wc = W1.p;
+    for (size_t level = 0; level < plans.size(); ++level) {
+      LevelPlan& pl = plans[level];
+      {
+        std::vector<XCopy> cp;
+        for (const XCopy& c : pl.copies)
+          if (c.len > 0) cp.push_back(c);
+        if (!cp.empty()) {
+          RPT_TRY(dcopy.ensure(cp.size()));
+          RPT_TRY(upload_async(ctx, dcopy.p, cp.data(), cp.size() * sizeof(XCopy)));
+          hipLaunchKernelGGL(xs_copy_kernel, dim3((unsigned)cp.size(), T), dim3(256), 0, st, dcopy.p,
+                             (const int32_t*)A, (const int32_t*)Wp, Wc, B, N);
+        }
+      }
+      const int S = (int)pl.segs.size();
+      if (S > 0) {
+        const TK* Pl = P + (int64_t)level * N;  // (t, level) is column t * L of this base
+        RPT_TRY(dsegs.ensure((size_t)S));
+        RPT_TRY(upload_async(ctx, dsegs.p, pl.segs.data(), (size_t)S * sizeof(Seg)));
+        RPT_TRY(dxn.ensure((size_t)S));
+        RPT_TRY(upload_async(ctx, dxn.p, pl.xn.data(), (size_t)S * sizeof(XNode)));
+        RPT_TRY(tthr.ensure((size_t)S * T));
+        RPT_TRY(tlo.ensure((size_t)S * T));
+        RPT_TRY(thi.ensure((size_t)S * T));
+        hipLaunchKernelGGL(xs_pos_kernel, dim3((unsigned)S, T), dim3(256), 0, st, dsegs.p,
+                           (const int32_t*)Wc, tb.p, N);
+        std::vector<Seg> small;
+        std::vector<GSeg> big;
+        for (const Seg& sg : pl.segs) {
+          if (sg.n <= kSmallCap) {
+            small.push_back(sg);
+          } else {
+            const int nn = sg.n, nh = nn / 2;
+            for (int t = 0; t < T; ++t)
+              big.push_back(GSeg{(int64_t)t * N + sg.off, nn, t, sg.heap, nh, nh > 0 ? nh - 1 : 0,
+                                 nh + 1 < nn ? nh + 1 : nn - 1});
+          }
+        }
+        if (!small.empty()) {
+          DevBuf<Seg>& ds2 = dsegs;  // the small ones, re-uploaded behind the position pass
+          int nmax = 0;
+          for (const Seg& sg : small) nmax = sg.n > nmax ? sg.n : nmax;
+          if (small.size() != pl.segs.size())
+            RPT_TRY(upload_async(ctx, ds2.p, small.data(), small.size() * sizeof(Seg)));
+          const size_t smem = (size_t)next_pow2(nmax) * (sizeof(TK) + 4);
+          if (smem > 64 * 1024)
+            RPT_HIP(hipFuncSetAttribute((const void*)small_sort_kernel<TK>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          hipLaunchKernelGGL(small_sort_kernel<TK>, dim3((unsigned)small.size(), T), dim3(256), smem, st,
+                             (const int32_t*)Wc, Wc, N, Pl, L, 0, ds2.p, (const int32_t*)tb.p, tthr.p,
+                             tlo.p, thi.p, (int64_t)S, tie.p);
+        }
+        if (!big.empty()) {
+          RPT_TRY(gsort<TK>(ctx, Wc, tmp.p, N, Pl, L, 0, big, dglist, tb.p));
+          hipLaunchKernelGGL(gsort_emit_kernel<TK>, dim3((unsigned)((big.size() + 63) / 64)), dim3(64),
+                             0, st, (const int32_t*)Wc, N, Pl, L, 0, dglist.p, (int)big.size(),
+                             (const NodeAux*)nullptr, (const int*)nullptr, tthr.p, tlo.p, thi.p,
+                             (int64_t)S, tie.p);
+        }
+        hipLaunchKernelGGL(xs_fold_kernel, dim3((unsigned)((S + 255) / 256), T), dim3(256), 0, st,
+                           dxn.p, S, tthr.p, tlo.p, thi.p, f->thr.p, f->mglo.p, f->mghi.p, slots);
+      }
+      RPT_HIP(hipGetLastError());
+      std::swap(Wp, Wc);
+    }
+    std::swap(A, B);
+  }
+  if (A != f->perm.p && N > 0)
+    RPT_HIP(hipMemcpyAsync(f->perm.p, A, (size_t)T * N * 4, hipMemcpyDeviceToDevice, st));
+  // the final shape, as rpo_stream_forest_dense lists it
+  f->xoff_h.assign((size_t)slots, 0);
+  f->xlen_h.assign((size_t)slots, 0);
+  {
+    int64_t w = 0;
+    for (int64_t h = 0; h < slots; ++h) {
+      f->xoff_h[(size_t)h] = w;
+      if (kind[(size_t)h] == 2) {
+        f->xlen_h[(size_t)h] = cnt[(size_t)h];
+        w += cnt[(size_t)h];
+      }
+    }
+    f->held = w;
+  }
+  RPT_TRY(f->xkind.alloc((size_t)slots));
+  RPT_TRY(f->xoff.alloc((size_t)slots));
+  RPT_TRY(f->xlen.alloc((size_t)slots));
+  RPT_HIP(hipMemcpyAsync(f->xkind.p, kind.data(), (size_t)slots, hipMemcpyHostToDevice, st));
+  RPT_HIP(hipMemcpyAsync(f->xoff.p, f->xoff_h.data(), (size_t)slots * 8, hipMemcpyHostToDevice, st));
+  RPT_HIP(hipMemcpyAsync(f->xlen.p, f->xlen_h.data(), (size_t)slots * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(xs_mask_kernel, dim3((unsigned)((slots * T + 255) / 256)), dim3(256), 0, st,
+                     (const int8_t*)f->xkind.p, slots, T, f->thr.p, f->mglo.p, f->mghi.p);
+  RPT_HIP(hipGetLastError());
+  RPT_HIP(ctx_sync(ctx));  // work buffers and the host vectors behind the copies are released
+  return RPT_OK;
+}
+
 }  // namespace
+
+int32_t stream_build_forest(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int64_t chunk,
+                            int32_t mode) {
+  if (f->pdtype == RPT_F64) return stream_build_t<double>(ctx, ds, f, chunk, mode);
+  return stream_build_t<float>(ctx, ds, f, chunk, mode);
+}
 
 int32_t build_forest(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32_t mode) {
   if (f->pdtype == RPT_F64) return build_forest_t<double>(ctx, ds, f, mode);

@@ -32,7 +32,7 @@ __all__ = [
     "candidates", "recallWith", "rpTreeCfg", "RPTreeConfig", "leaves", "levels", "points",
     "treeSize", "leafSizes", "metricL2", "inner", "project", "splitSegments", "topology",
     "bruteKnn", "RPTError", "forest", "tree", "saveForest", "loadForest", "importForest",
-    "knnH", "knnHBatch", "knnPQ", "candidatesBatch", "to_bf16", "from_bf16",
+    "knnH", "knnHBatch", "knnPQ", "candidatesBatch", "to_bf16", "from_bf16", "RPStreamForest",
 ]
 
 _DT = {np.dtype(np.float64): RPT_F64, np.dtype(np.float32): RPT_F32}
@@ -482,16 +482,75 @@ def treeBatch(seed, maxDepth, minLeaf, pnz, dim, src, **kw):
     return forestBatch(seed, maxDepth, minLeaf, 1, pnz, dim, src, **kw)
 
 
-def forest(seed, maxd, minl, ntrees, chunksize, pnz, dim, src, **kw):
-    """Conduit.hs:104-121 `forest` (streaming build), SURVEY §8(f)-2: the source is SUNK and
-    the forest is built in one batch.  This is NOT the reference's chunk-wise semantics (chunk-
-    local medians averaged into the thresholds, Internal.hs:274-285, which is inherently
-    sequential and drops data when a chunk half is empty): same signature, same
-    hyperplanes (same draw order, Conduit.hs:116-118), batch thresholds.  `chunksize` is
-    accepted for signature compatibility and ignored."""
-    del chunksize
-    xs = list(src) if not isinstance(src, (np.ndarray, Dataset, tuple)) else src
-    return forestBatch(seed, maxd, minl, ntrees, pnz, dim, xs, **kw)
+class RPStreamForest(RPForest):
+    """A forest built by the streaming insert (rpt_forest_stream_build): its trees have the
+    EXPLICIT topology the fold over chunks produced — `kind[h]` 0 absent / 1 Bin / 2 Tip per heap
+    slot (2^(L+1)-1 of them), a Tip's points = perm[t][leaf_off[h] : leaf_off[h] + leaf_len[h]] —
+    the same for every tree.  `held` = points stored per tree (< N after the reference's data-loss
+    branch, Internal.hs:277), `dropped` = how many that branch discarded (counted over the fold)."""
+
+    def __init__(self, ctx, handle, data, R, max_depth, min_leaf):
+        super().__init__(ctx, handle, data, R, max_depth, min_leaf)
+        n = C.c_int64()
+        check(lib().rpt_forest_get_topology(handle, C.byref(n), None, None, None, None, None))
+        self.slots = n.value
+        self.kind = np.empty(self.slots, dtype=np.int8)
+        self.leaf_off = np.empty(self.slots, dtype=np.int64)
+        self.leaf_len = np.empty(self.slots, dtype=np.int64)
+        held, dropped = C.c_int64(), C.c_int64()
+        check(lib().rpt_forest_get_topology(handle, C.byref(n), _vp(self.kind), _vp(self.leaf_off),
+                                            _vp(self.leaf_len), C.byref(held), C.byref(dropped)))
+        self.held, self.dropped = held.value, dropped.value
+
+    def _get_nodes(self):
+        if self._nodes is None:
+            a = [np.empty((self.T, self.slots), dtype=np.float64) for _ in range(3)]
+            check(lib().rpt_forest_get_nodes(self._h, _vp(a[0]), _vp(a[1]), _vp(a[2])))
+            self._nodes = a
+        return self._nodes
+
+    thr = property(lambda self: self._get_nodes()[0])
+    mglo = property(lambda self: self._get_nodes()[1])
+    mghi = property(lambda self: self._get_nodes()[2])
+
+    def topology(self):
+        raise TypeError("a streamed forest has an explicit topology: kind / leaf_off / leaf_len")
+
+    def tips(self, t):
+        """{heap: ids} of tree t's Tips, heap order"""
+        return {int(h): self.perm[t, self.leaf_off[h]:self.leaf_off[h] + self.leaf_len[h]]
+                for h in np.nonzero(self.kind == 2)[0]}
+
+
+def forest(seed, maxd, minl, ntrees, chunksize, pnz, dim, src, *, ctx=None, mode=RPT_PROJ_AUTO,
+           hyperplanes=None):
+    """Conduit.hs:104-121 `forest`: the streaming build with the reference's semantics — the source
+    is cut into chunks of `chunksize` points (C.chunksOf: the last may be shorter) and every chunk
+    is folded into every tree with `insert` (Internal.hs:245-297): a chunk part that meets a Bin is
+    split at its OWN median and averaged into the threshold, a part that meets a Tip is put in
+    front of its points, an empty part that meets a Bin drops the subtree (the reference's
+    data-loss quirk, kept; `dropped` counts it).  Hyperplanes are sampled exactly like
+    forestBatch's (same draw order, Conduit.hs:116-118).  Dense data.  With chunksize >= the
+    number of points the result is forestBatch's forest (as a streamed-forest handle)."""
+    ctx = ctx or default_context()
+    xs = src if isinstance(src, (np.ndarray, Dataset)) else list(src)
+    ds = Dataset.of(ctx, xs)
+    if ds.is_csr:
+        raise NotImplementedError("the streaming build takes dense rows")
+    if hyperplanes is None:
+        _, R = gen.forest_hyperplanes(seed, ntrees, maxd, pnz, dim)
+    else:
+        R = np.asarray(hyperplanes, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    if R.shape[2] != ds.d:
+        raise ValueError("projection vector dimension %d != data dimension %d" % (R.shape[2], ds.d))
+    T, L, _ = R.shape
+    if L != maxd:
+        raise ValueError("hyperplane block has %d levels, maxDepth is %d" % (L, maxd))
+    h = C.c_void_p()
+    check(lib().rpt_forest_stream_build(ctx._h, ds._h, _vp(R), T, L, int(minl), int(chunksize),
+                                        int(mode), C.byref(h)))
+    return RPStreamForest(ctx, h, ds, R, maxd, minl)
 
 
 def tree(seed, maxDepth, minLeaf, chunksize, pnz, dim, src, **kw):
@@ -540,6 +599,8 @@ def importForest(ctx, data, R, min_leaf, perm, thr, mglo, mghi, mode=RPT_PROJ_AU
 def leaves(tree):
     """All leaf buckets of a tree, left to right (ids)."""
     f, t = tree.forest, tree.t
+    if isinstance(f, RPStreamForest):
+        return _stream_leaves(f, t)
     topo = f.topology()
     return [f.perm[t, o:o + n] for (_, _, o, n, leaf) in topo if leaf]
 
@@ -549,10 +610,27 @@ def levels(tree):
 
 
 def points(tree):
+    if isinstance(tree.forest, RPStreamForest):
+        return tree.forest.perm[tree.t, :tree.forest.held]
     return tree.forest.perm[tree.t]
 
 
+def _stream_leaves(f, t):
+    """Tips of a streamed tree in left-to-right (DFS) order"""
+    out, stack = [], [0]
+    while stack:
+        h = stack.pop()
+        if f.kind[h] == 2:
+            out.append(f.perm[t, f.leaf_off[h]:f.leaf_off[h] + f.leaf_len[h]])
+        elif f.kind[h] == 1:
+            stack.append(2 * h + 2)
+            stack.append(2 * h + 1)
+    return out
+
+
 def leafSizes(tree):
+    if isinstance(tree.forest, RPStreamForest):
+        return [len(x) for x in _stream_leaves(tree.forest, tree.t)]
     return [int(n) for (_, _, _, n, leaf) in tree.forest.topology() if leaf]
 
 

@@ -50,6 +50,8 @@ SYMBOLS = {
     "rpt_forest_get_perm": (i32, [vp, vp]),
     "rpt_forest_get_nodes": (i32, [vp, vp, vp, vp]),
     "rpt_forest_get_proj": (i32, [vp, vp]),
+    "rpt_forest_stream_build": (i32, [vp, vp, vp, i32, i32, i32, i64, i32, C.POINTER(vp)]),
+    "rpt_forest_get_topology": (i32, [vp, p_i64, vp, vp, vp, p_i64, p_i64]),
     "rpt_forest_import": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]),
     "rpt_forest_get_mode": (i32, [vp, p_i32]),
     "rpt_forest_set_mode": (i32, [vp, i32]),

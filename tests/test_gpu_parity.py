@@ -656,15 +656,75 @@ def test_forest_save_load_roundtrip(rp, ctx, small_forest, tmp_path):
     assert np.array_equal(off_a, off_b) and np.array_equal(ids_a, ids_b)
 
 
-def test_streaming_forest_api_sinks_then_batches(rp, ctx, oracle):
-    # Conduit.hs:104-121 signature; batch semantics (documented difference)
-    X = oracle.data_circle2d2(3, 3000)
-    cfg = rp.rpTreeCfg(20, 3000, 2)
-    src = (rp.Embed(rp.fromListDv(x), ()) for x in X)          # a one-shot source
-    tts = rp.forest(3, cfg.fpMaxTreeDepth, 20, 4, cfg.fpDataChunkSize, 1.0, 2, src, ctx=ctx)
-    ref = rp.forestBatch(3, cfg.fpMaxTreeDepth, 20, 4, 1.0, 2, X, ctx=ctx)
-    assert np.array_equal(tts.perm, ref.perm)
-    assert all(rp.treeSize(t) == 3000 for t in tts)
+def assert_stream_equal(f, so, T):
+    """device streamed forest == rpo_stream_forest_dense's heap arrays, bit for bit"""
+    for t in range(T):
+        assert np.array_equal(f.kind, so.kind[t])
+        assert np.array_equal(f.leaf_off, so.leaf_off[t]) and np.array_equal(f.leaf_len, so.leaf_len[t])
+        assert f.held == so.held[t]
+        assert np.array_equal(f.perm[t, :f.held], so.leaf_ids[t, :f.held]), "tree %d" % t
+        for name in ("thr", "mglo", "mghi"):
+            assert np.array_equal(getattr(f, name)[t], getattr(so, name)[t], equal_nan=True), (name, t)
+
+
+@pytest.mark.parametrize("n,d,T,ml,chunk", [
+    (3000, 2, 4, 20, 30),        # the reference's own test shape: rpTreeCfg chunk = n / 100
+    (4000, 12, 3, 20, 100),      # chunk divides n: nothing lost
+    (4000, 12, 3, 20, 33),       # short last chunk: the data-loss branch (Internal.hs:277) fires
+    (4000, 12, 2, 20, 3999),     # a last chunk of ONE point drops about half of the tree
+    (5000, 8, 2, 0, 64),         # minLeaf 0: splits down to single points
+    (20000, 16, 3, 50, 7000),    # chunk parts above the LDS sort's 4096 points (HBM merge path)
+    (6000, 5, 2, 10, 6000),      # one chunk
+])
+def test_streaming_forest_is_the_reference_fold_over_chunks(rp, ctx, oracle, n, d, T, ml, chunk):
+    """Conduit.hs:104-121 `forest` = chunkedAccum folding `insert` (Internal.hs:245-297): chunk-own
+    medians averaged into the thresholds (:281), margins by (max, min) (:280), new points in front
+    of a Tip's (:286), an empty chunk half dropping the subtree (:277) — device == oracle."""
+    X = oracle.data_circle2d2(3, n) if d == 2 else oracle.data_normal_dense2(11, n, d)
+    L, _, pnz = oracle.tree_cfg(max(ml, 1), n, d)
+    R, _ = oracle.forest_hyperplanes(5, T, L, pnz, d)
+    so = oracle.stream_forest_dense(X, R, ml, chunk)
+    f = rp.forest(0, L, ml, T, chunk, pnz, d, X, ctx=ctx, hyperplanes=R)
+    assert_stream_equal(f, so, T)
+    assert f.dropped >= n - f.held
+    if chunk >= n:                                   # one chunk = the batch build (:285-295)
+        fb = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R)
+        for t in range(T):
+            got = np.concatenate(rp.leaves(f[t])) if n else np.zeros(0, np.int32)
+            assert np.array_equal(got, fb.perm[t])
+    elif n % chunk == 0:
+        assert f.held == n and all(rp.treeSize(t) == n for t in f)   # RPTreeSpec.hs:93-94
+        fo = oracle.forest_build_dense(X, R, ml)
+        assert not np.array_equal(f.thr[0, 0], fo.thr[0, 0])        # NOT the batch thresholds
+    elif chunk in (33, 3999):
+        assert f.held < n                            # the reference's data-loss quirk, reproduced
+
+
+def test_queries_on_a_streamed_forest(rp, ctx, oracle):
+    """candidates / knn walk whatever tree they are given (RPTree.hs:168-176, 289-314): on the
+    explicit topology of a streamed forest the device answers == the oracle's walk of the same
+    heap arrays; a one-shot generator works as the source (Conduit)."""
+    n, d, T, ml, chunk, k = 6000, 6, 4, 25, 60, 7
+    X = oracle.data_normal_dense2(21, n, d)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(9, T, L, pnz, d)
+    src = (rp.Embed(rp.fromListDv(x), ()) for x in X)
+    f = rp.forest(0, L, ml, T, chunk, pnz, d, src, ctx=ctx, hyperplanes=R)
+    so = oracle.stream_forest_dense(X, R, ml, chunk)
+    assert_stream_equal(f, so, T)
+    Q = oracle.data_normal_dense2(22, 40, d)
+    off, cids = rp.candidatesBatch(f, Q)
+    for dedup in (False, True):
+        ids, dist, cnt = rp.knnBatch(k, f, Q, dedup=dedup)
+        for i in range(len(Q)):
+            for t in range(T):
+                want = oracle.stream_candidates_dense(so, R, Q[i], t)
+                assert np.array_equal(cids[off[i * T + t]:off[i * T + t + 1]], want)
+            wi, wd = oracle.stream_knn_dense(so, R, X, Q[i], k, dedup=int(dedup))
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+            assert np.array_equal(dist[i, :cnt[i]], wd)
+    with pytest.raises(rp.RPTError, match="streamed"):
+        rp.knnHBatch(k, f, Q[:2])
 
 
 # ------------------------------------------------------------------ fallback paths

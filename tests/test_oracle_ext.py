@@ -79,6 +79,22 @@ def test_stream_short_chunk_loses_data(oracle):
     assert lost[3] > 2000 and lost[3999] > 1500
 
 
+def test_stream_queries_on_one_chunk_equal_the_batch_queries(oracle):
+    """candidates / knn over the heap arrays of a streamed forest == over the flat batch forest
+    when the stream was one chunk (same tree, two layouts)."""
+    X, R, L = small(oracle)
+    ml, k = 20, 5
+    fb = oracle.forest_build_dense(X, R, ml)
+    sf = oracle.stream_forest_dense(X, R, ml, chunk=len(X))
+    Q = oracle.data_normal_dense2(4321, 10, X.shape[1])
+    for q in Q:
+        for t in range(R.shape[0]):
+            assert np.array_equal(oracle.stream_candidates_dense(sf, R, q, t),
+                                  oracle.candidates_dense(fb, q, t))
+        a, b = oracle.stream_knn_dense(sf, R, X, q, k), oracle.knn_dense(fb, X, q, k)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 # ---------------------------------------------------------------- counts / keepCounts (8f-4)
 def test_keep_counts(oracle):
     ids = [5, 3, 5, 1, 3, 5, 9]
