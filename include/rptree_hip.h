@@ -238,8 +238,18 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                       const rpt_dataset* queries, int32_t k, int64_t* off_host, int32_t* ids_host,
                       double* dist_host, int64_t cap, int64_t* total);
 
-/* Dense f64 data: the distances returned are metricDDL2's own bits — the rows that reach a result
- * are evaluated as the reference's left fold of (u - v)^2 — and the results are ordered by them. */
+/* Dense f64 data: the distances returned are metricDDL2's left fold of (u - v)^2 (Internal.hs:
+ * 403-406) with every square correctly rounded, and the results are selected and ordered on those
+ * values: candidates are RANKED on a lane-parallel sum (the same value to an ulp), the best
+ * k + 8 of them (or the certified k + max(6, k/2) of the f32 prefilter) are evaluated again as the
+ * fold and the k best of those by (distance, candidate position) are returned — more than 8
+ * DIFFERENT rows within a few ulp of the k-th distance would be needed to change the membership
+ * (copies of one row keep their order under both sums).
+ * `(** 2)` is libm's pow in a GHC build: where pow(t, 2) is correctly rounded these are its bits;
+ * glibc >= 2.28 returns a neighbouring double for about 9 arguments in 10 000, which moves the last
+ * bit of about one distance in a thousand (tests/test_oracle_kat.py measures it on the test box).
+ * RPT_KNN_DEDUP_DISTANCE collapses entries whose distances are equal under both sums; two rows one
+ * ulp apart under one of them and equal under the other may or may not collapse. */
 /* knn (RPTree.hs:168-176) with distf = metricL2 (Internal.hs:318, metricDDL2 :403-406 /
  * true Euclidean distance for CSR data, evaluated as |q|^2 + sum over the row's nonzeros of
  * ((x_j - q_j)^2 - q_j^2): absolute error about 1e-8 |q|): per query the k best (distance, id), stable in

@@ -69,6 +69,8 @@ def lib():
         L.rpo_normal.restype = C.c_double
         L.rpo_keep_counts.restype = C.c_int64
         L.rpo_recall_with_dense_values.restype = C.c_double
+        L.rpo_metric_dd_libm.restype = C.c_double
+        L.rpo_pow2_mismatches.restype = C.c_int64
         L.rpo_stream_candidates_dense.restype = C.c_int64
         L.rpo_stream_knn_dense.restype = C.c_int32
     return _lib
@@ -109,6 +111,17 @@ def metric_dd(u, v):
     u = np.ascontiguousarray(u, dtype=np.float64)
     v = np.ascontiguousarray(v, dtype=np.float64)
     return lib().rpo_metric_dd(C.c_int64(min(len(u), len(v))), _p(u, _f64p), _p(v, _f64p))
+
+
+def metric_dd_libm(u, v):
+    """metricDDL2 with `** 2` through this box's libm pow (see sq() in rptree_oracle.cpp)"""
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    return lib().rpo_metric_dd_libm(C.c_int64(len(u)), _p(u, _f64p), _p(v, _f64p))
+
+
+def pow2_mismatches(seed, n):
+    return int(lib().rpo_pow2_mismatches(C.c_uint64(seed), C.c_int64(n)))
 
 
 def metric_sd(i1, v1, x):

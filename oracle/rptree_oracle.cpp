@@ -58,6 +58,18 @@ int64_t sparse_vg(rpo_gen* g, double p, int32_t d, int32_t* idx, double* val, Ra
 // ------------------------------------------------------------------------------------------
 // Topology: data independent.  Internal.hs:289 (leaf iff level >= maxDepth || n <= minLeaf),
 // :495,503 (left child takes n div 2, right child the rest).
+// `x ** 2` (Internal.hs:391,398,404; Gen.hs circle2d): GHC compiles (**) on Double to a call of
+// the C library's pow.  Where pow(t, 2.0) is correctly rounded it IS t * t (the exact square,
+// rounded once); glibc >= 2.28 is not correctly rounded there — on this image (2.35) 8.5e-4 of
+// random arguments come out one ulp off, which moves the last bit of about one distance in a
+// thousand (tests/test_oracle_kat.py measures both) — older glibc (IBM accurate pow), other
+// platforms' libms and any FMA / non-FMA ifunc variant differ again.  "The reference's bits" of
+// a squared term are therefore a property of the HOST's libm, not of rp-tree.  The oracle — and
+// the device — take the correctly rounded square, explicitly (g++ -O2 had been folding
+// std::pow(t, 2.0) into t * t all along); rpo_metric_dd_libm is the same fold through the real
+// pow of this box, for the measurement.
+inline double sq(double t) { return t * t; }
+
 // ------------------------------------------------------------------------------------------
 inline bool is_leaf(int32_t level, int64_t n, int32_t L, int32_t minLeaf) {
   return level >= L || n <= (int64_t)minLeaf;
@@ -103,7 +115,7 @@ struct DenseDataT {
   double metric(int64_t id, const double* q) const {  // metricDDL2, Internal.hs:403-406
     const E* x = X + id * d;
     double acc = 0.0;
-    for (int32_t j = 0; j < d; ++j) acc = acc + std::pow((double)x[j] - q[j], 2.0);
+    for (int32_t j = 0; j < d; ++j) acc = acc + sq((double)x[j] - q[j]);
     return std::sqrt(acc);
   }
 };
@@ -469,7 +481,7 @@ void rpo_data_circle2d2(uint64_t seed, int64_t n, double* X) {
     for (;;) {
       x = rpo_uniform_r(&g, -r, r);
       y = rpo_uniform_r(&g, -r, r);
-      if (std::pow(x, 2.0) + std::pow(y, 2.0) <= r) break;
+      if (sq(x) + sq(y) <= r) break;
     }
     if (b) {
       X[2 * i] = x;
@@ -569,7 +581,7 @@ double rpo_inner_dd(int64_t n, const double* a, const double* b) {
 // Internal.hs:403-406 metricDDL2 = sqrt $ VG.sum $ VG.map (** 2) (zipWith (-) u v)
 double rpo_metric_dd(int64_t n, const double* u, const double* v) {
   double acc = 0.0;
-  for (int64_t j = 0; j < n; ++j) acc = acc + std::pow(u[j] - v[j], 2.0);
+  for (int64_t j = 0; j < n; ++j) acc = acc + sq(u[j] - v[j]);
   return std::sqrt(acc);
 }
 
@@ -612,7 +624,7 @@ double rpo_metric_sd(int64_t n1, const int32_t* i1, const double* v1, int64_t n2
   std::vector<double> duv((size_t)n2);
   int64_t m = bin_sdd(true, n1, i1, v1, n2, x, duv.data());
   double acc = 0.0;
-  for (int64_t j = 0; j < m; ++j) acc = acc + std::pow(duv[j], 2.0);
+  for (int64_t j = 0; j < m; ++j) acc = acc + sq(duv[j]);
   return std::sqrt(acc);
 }
 
@@ -626,7 +638,7 @@ double rpo_metric_ss(int64_t n1, const int32_t* i1, const double* v1, int64_t n2
     if (i1[a] == i2[b]) y = v1[a++] - v2[b++];  // :448
     else if (i1[a] < i2[b]) y = v1[a++] - 0.0;  // :449
     else y = 0.0 - v2[b++];                     // :450
-    acc = acc + std::pow(y, 2.0);
+    acc = acc + sq(y);
   }
   return std::sqrt(acc);
 }
@@ -1251,6 +1263,33 @@ int32_t rpo_stream_knn_dense(const double* X, int64_t N, int32_t d, const double
     for (int64_t i = 0; i < m; ++i) cs.push_back(DistId{D.metric(buf[i], q), buf[i]});
   }
   return topk_from(cs, k, dedup, out_ids, out_dist);
+}
+
+
+// metricDDL2 with the squares through THIS box's libm pow (what a GHC-compiled reference calls);
+// the exponent is volatile so that the compiler cannot fold the call into a multiplication.
+double rpo_metric_dd_libm(int64_t n, const double* u, const double* v) {
+  volatile double two = 2.0;
+  double acc = 0.0;
+  for (int64_t j = 0; j < n; ++j) acc = acc + std::pow(u[j] - v[j], two);
+  return std::sqrt(acc);
+}
+// how many of n pseudo-random doubles t (SplitMix stream `seed`, exponents in [-40, 40]) have
+// pow(t, 2.0) != t * t on this box's libm
+int64_t rpo_pow2_mismatches(uint64_t seed, int64_t n) {
+  volatile double two = 2.0;
+  rpo_gen g;
+  rpo_gen_init(&g, seed);
+  int64_t bad = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t z = rpo_next_word64(&g);
+    const uint64_t bits = (z & 0x000fffffffffffffULL) | ((uint64_t)(1023 - 40 + (z >> 52) % 81) << 52) |
+                          (z & 0x8000000000000000ULL);
+    double t;
+    std::memcpy(&t, &bits, 8);
+    bad += std::pow(t, two) != t * t;
+  }
+  return bad;
 }
 
 }  // extern "C"

@@ -228,6 +228,11 @@ void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double
                              double* mglo, double* mghi, int64_t* leaf_off, int64_t* leaf_len,
                              int32_t* leaf_ids, int64_t* held);
 
+/* `** 2` is the host libm's pow in the reference; see sq() in the .cpp.  rpo_metric_dd_libm folds
+ * through this box's pow; rpo_pow2_mismatches counts arguments where pow(t, 2.0) != t * t. */
+double rpo_metric_dd_libm(int64_t n, const double* u, const double* v);
+int64_t rpo_pow2_mismatches(uint64_t seed, int64_t n);
+
 /* candidates (RPTree.hs:289-314) / knn (:168-176, metricL2) over the heap arrays of a streamed
  * forest: Tip = kind 2 (payload at leaf_off / leaf_len), Bin = kind 1 */
 int64_t rpo_stream_candidates_dense(const double* q, int32_t d, const double* R, int32_t T,

@@ -431,6 +431,54 @@ __device__ inline double leftfold_distance(const double* __restrict__ x, const d
   return sqrt(acc);
 }
 
+// Entries a dense f64 path that RANKS on butterfly sums keeps beyond k before the final selection:
+// the k + kLfMargin best by (butterfly distance, position) are re-evaluated as the reference's left
+// fold and the k best of THOSE by (fold distance, position) are the answer, so a candidate whose
+// two sums round differently near the k-th distance cannot change the membership of the result
+// (RPTree.hs:174 ranks ALL candidates on the fold).  It would take more than kLfMargin DIFFERENT
+// rows within a few ulp of the k-th distance to defeat this (copies of one row — the same point
+// found by several trees — have equal sums of both kinds and keep their order); the prefiltered
+// path certifies its cut per query instead.
+constexpr int kLfMargin = 8;
+
+// Final stage of those paths: m kept entries (ids / positions in bid / bpos, m <= capacity of lf
+// and order) -> left-fold distances, order by (distance, position), the duplicate rule on the
+// FINAL values (dedup 2 = knnPQ's nub: one entry per distance; dedup 1: the kept ids are distinct
+// already), the first k written.  tid / nthr / sync: the threads that share the arrays.
+template <class Sync>
+__device__ inline void finalize_leftfold(const double* __restrict__ X, int d, const double* qs, int m,
+                                         int k, int dedup, double* lf, int* order, const int* bid,
+                                         const int* bpos, int tid, int nthr, Sync sync, int64_t q,
+                                         int32_t* __restrict__ out_ids, double* __restrict__ out_dist,
+                                         int32_t* __restrict__ out_cnt) {
+  for (int i = tid; i < m; i += nthr) lf[i] = leftfold_distance(X + (int64_t)bid[i] * d, qs, d);
+  sync();
+  for (int i = tid; i < m; i += nthr) {
+    const double di = lf[i];
+    const int pi = bpos[i];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += lf[j] < di || (lf[j] == di && bpos[j] < pi);
+    order[rank] = i;
+  }
+  sync();
+  if (tid == 0) {
+    int w = 0;
+    double last = -1.0;
+    for (int r = 0; r < m && w < k; ++r) {
+      const int i = order[r];
+      if (dedup == 2 && w > 0 && lf[i] == last) continue;
+      out_ids[q * k + w] = bid[i];
+      out_dist[q * k + w] = last = lf[i];
+      ++w;
+    }
+    out_cnt[q] = w;
+    for (; w < k; ++w) {
+      out_ids[q * k + w] = -1;
+      out_dist[q * k + w] = __longlong_as_double(0x7ff0000000000000LL);
+    }
+  }
+}
+
 // dense data.  One block (256 threads) per query.  Candidate list given as ranges.
 // `identity`: the candidate list is the whole dataset in id order (brute force), perm unused.
 template <class TD>
@@ -452,6 +500,8 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
   int best = 0;    // valid best entries at buf[0, best)
   int filled = 0;  // entries in buf (block-uniform)
   const int cap = kBuf;
+  // f64: the running list keeps kLfMargin entries more than k (see kLfMargin)
+  const int kk = std::is_same<TD, double>::value ? (k + kLfMargin < kBuf / 2 ? k + kLfMargin : kBuf / 2) : k;
   const int64_t r0 = identity ? 0 : rng_off[q * T];
   const int64_t r1 = identity ? 1 : rng_off[(q + 1) * T];
   for (int64_t r = r0; r < r1; ++r) {
@@ -496,36 +546,31 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
       done += take;
       __syncthreads();
       if (filled == cap) {
-        best = merge_best(buf, filled, k, dedup, scratch);
+        best = merge_best(buf, filled, kk, dedup, scratch);
         filled = best;
         __syncthreads();
       }
     }
   }
   if (filled > best || best == 0) {
-    best = merge_best(buf, filled, k, dedup, scratch);
+    best = merge_best(buf, filled, kk, dedup, scratch);
     __syncthreads();
   }
   if constexpr (std::is_same<TD, double>::value) {
-    // the results' distances again as the reference's left fold (leftfold_distance), the results
-    // in the order of those values (ties by candidate position)
-    double* lf = reinterpret_cast<double*>(scratch);  // [kBuf] ints = kBuf / 2 doubles >= k
-    for (int i = threadIdx.x; i < best; i += blockDim.x)
-      lf[i] = leftfold_distance(X + (int64_t)buf[i].id * d, qs, d);
-    __syncthreads();
+    // the kept entries' distances again as the reference's left fold, the k best of those in the
+    // order of those values (ties by candidate position): finalize_leftfold
+    double* lf = reinterpret_cast<double*>(scratch);  // [kBuf] ints = kBuf / 2 doubles >= kk
+    int* ids2 = reinterpret_cast<int*>(buf + kBuf / 2);  // the upper half of buf is free now:
+    int* pos2 = ids2 + kBuf / 2;                          // 3 x kBuf / 2 ints fit its 16 KB
+    int* order = pos2 + kBuf / 2;
     for (int i = threadIdx.x; i < best; i += blockDim.x) {
-      const double di = lf[i];
-      const int pi = buf[i].pos;
-      int rank = 0;
-      for (int j = 0; j < best; ++j) rank += lf[j] < di || (lf[j] == di && buf[j].pos < pi);
-      out_ids[q * k + rank] = buf[i].id;
-      out_dist[q * k + rank] = di;
+      ids2[i] = buf[i].id;
+      pos2[i] = buf[i].pos;
     }
-    for (int i = best + threadIdx.x; i < k; i += blockDim.x) {
-      out_ids[q * k + i] = -1;
-      out_dist[q * k + i] = __longlong_as_double(0x7ff0000000000000LL);
-    }
-    if (threadIdx.x == 0) out_cnt[q] = best;
+    __syncthreads();
+    finalize_leftfold(reinterpret_cast<const double*>(X), d, reinterpret_cast<const double*>(qs), best, k,
+                      dedup, lf, order, ids2, pos2, (int)threadIdx.x, (int)blockDim.x,
+                      [] { __syncthreads(); }, q, out_ids, out_dist, out_cnt);
     return;
   }
   for (int i = threadIdx.x; i < k; i += blockDim.x) {
@@ -829,6 +874,7 @@ __device__ __forceinline__ void batch_distances_csr32(const int64_t* __restrict_
 constexpr int kFC = 2048;     // candidates per batch
 constexpr int kFR = 512;      // leaf ranges per query in LDS
 constexpr int kFK = 64;       // largest k served by the arg-min selection
+constexpr int kFKx = kFK + kLfMargin;  // capacity of the running best list (see kLfMargin)
 constexpr int kVoteCap = 16384;  // candidates of one query the voting mode can count (64 KB of LDS)
 
 template <class TD, class TK, bool PRE32, bool CSR = false>
@@ -852,10 +898,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   int* rn = reinterpret_cast<int*>(rpoff + kFR);                   // [kFR]
   int* tcnt = rn + kFR;                                            // [1024] per-tree counts
   int* trng = tcnt + 1024;                                         // [1024]
-  double* bdist = reinterpret_cast<double*>(trng + 1024);          // [kFK]
-  int* bid = reinterpret_cast<int*>(bdist + kFK);                  // [kFK]
-  int* bpos = bid + kFK;                                           // [kFK]
-  TA* qs = reinterpret_cast<TA*>(bpos + kFK);                      // [d]
+  double* bdist = reinterpret_cast<double*>(trng + 1024);          // [kFKx]
+  int* bid = reinterpret_cast<int*>(bdist + kFKx);                 // [kFKx]
+  int* bpos = bid + kFKx;                                          // [kFKx]
+  TA* qs = reinterpret_cast<TA*>(bpos + kFKx);                     // [d]
   float* qs32 = reinterpret_cast<float*>(qs + d);                  // [d] (PRE32)
   // voting mode (dedup_vote >> 8 = v > 0, RPTree.hs:464-478 counts / keepCounts): all candidate
   // ids of the query, sorted, so that the ids found in at least v trees can be picked out
@@ -1170,7 +1216,9 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     __syncthreads();
-    const int nb = PRE32 ? select_packed(fill, k1) : pack32 ? select_packed(fill, k) : select(fill, k, dedup);
+    // dense f64 rows ranked on butterfly sums keep kLfMargin entries more (finalize_leftfold)
+    const int ksel = (!CSR && std::is_same<TD, double>::value) ? k + kLfMargin : k;
+    const int nb = PRE32 ? select_packed(fill, k1) : pack32 ? select_packed(fill, k) : select(fill, ksel, dedup);
     best = nb;
     if (vote > 0 ? vsrc >= nc_tot : r_next >= nr_tot) break;
   }
@@ -1255,24 +1303,12 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     }
   }
   if constexpr (!PRE32 && !CSR && std::is_same<TD, double>::value) {
-    // f64 rows ranked on butterfly sums: the results' distances again as the reference's left
-    // fold, and the results in the order of THOSE values (ties by candidate position)
+    // f64 rows ranked on butterfly sums: the k + kLfMargin kept entries again as the reference's
+    // left fold, the k best of THOSE in the order of those values (finalize_leftfold)
     __syncthreads();
-    for (int i = tid; i < best; i += 256) cdist[i] = leftfold_distance(X + (int64_t)bid[i] * d, qs, d);
-    __syncthreads();
-    for (int i = tid; i < best; i += 256) {
-      const double di = cdist[i];
-      const int pi = bpos[i];
-      int rank = 0;
-      for (int j = 0; j < best; ++j) rank += cdist[j] < di || (cdist[j] == di && bpos[j] < pi);
-      out_ids[q * k + rank] = bid[i];
-      out_dist[q * k + rank] = di;
-    }
-    for (int i = best + tid; i < k; i += 256) {
-      out_ids[q * k + i] = -1;
-      out_dist[q * k + i] = __longlong_as_double(0x7ff0000000000000LL);
-    }
-    if (tid == 0) out_cnt[q] = best;
+    finalize_leftfold(reinterpret_cast<const double*>(X), d, reinterpret_cast<const double*>(qs), best, k,
+                      dedup, cdist, cpos, bid, bpos, tid, 256, [] { __syncthreads(); }, q, out_ids,
+                      out_dist, out_cnt);
     return;
   }
   for (int i = tid; i < k; i += 256) {
@@ -1310,7 +1346,7 @@ __device__ inline void wave_sync() {  // LDS writes of the wave visible to all i
 }
 
 __host__ __device__ inline size_t fused_wave_bytes(int d, size_t acc_size) {
-  const size_t b = (size_t)kWC * 12 + (size_t)kWR * 24 + (size_t)kFK * 16 + (size_t)d * (acc_size + 4);
+  const size_t b = (size_t)kWC * 12 + (size_t)kWR * 24 + (size_t)kFKx * 16 + (size_t)d * (acc_size + 4);
   return (b + 15) & ~(size_t)15;
 }
 
@@ -1333,17 +1369,17 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   const bool pack32 = !PRE32 && sizeof(TA) == 4 && dedup == 0;  // see knn_fused_kernel
   unsigned char* base = smem + (size_t)wave * fused_wave_bytes(d, sizeof(TA));
   double* cdist = reinterpret_cast<double*>(base);                 // [kWC]
-  double* bdist = cdist + kWC;                                     // [kFK]
-  int64_t* rpoff = reinterpret_cast<int64_t*>(bdist + kFK);        // [kWR] compact, tree order
+  double* bdist = cdist + kWC;                                     // [kFKx]
+  int64_t* rpoff = reinterpret_cast<int64_t*>(bdist + kFKx);       // [kWR] compact, tree order
   int64_t* spoff = rpoff + kWR;                                    // [kWR] per-tree slots
   TA* qs = reinterpret_cast<TA*>(spoff + kWR);                     // [d]
-  int* cid = reinterpret_cast<int*>(base + (size_t)kWC * 8 + (size_t)kFK * 8 + (size_t)kWR * 16 +
+  int* cid = reinterpret_cast<int*>(base + (size_t)kWC * 8 + (size_t)kFKx * 8 + (size_t)kWR * 16 +
                                     (((size_t)d * sizeof(TA) + 7) & ~(size_t)7));  // [kWC]
   int* rn = cid + kWC;                                             // [kWR]
   int* sn = rn + kWR;                                              // [kWR]
-  int* bid = sn + kWR;                                             // [kFK]
-  int* bpos = bid + kFK;                                           // [kFK]
-  float* qs32 = reinterpret_cast<float*>(bpos + kFK);              // [d] (PRE32)
+  int* bid = sn + kWR;                                             // [kFKx]
+  int* bpos = bid + kFKx;                                          // [kFKx]
+  float* qs32 = reinterpret_cast<float*>(bpos + kFKx);             // [d] (PRE32)
 
   for (int j = lane; j < d; j += 64) qs[j] = ld<TD>(Q + q * d + j);
   if (PRE32)
@@ -1412,7 +1448,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
 #pragma unroll
     for (int s2 = 0; s2 < E; ++s2) {
       const int i = lane + 64 * s2;
-      const unsigned int pos = i < first_new ? (unsigned int)bpos[i < kFK ? i : 0] : (unsigned int)(pb0 + (i - first_new));
+      const unsigned int pos = i < first_new ? (unsigned int)bpos[i < kFKx ? i : 0] : (unsigned int)(pb0 + (i - first_new));
       key[s2] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | pos : ~0ULL;
     }
     wave_sync();  // bpos is rewritten below
@@ -1528,9 +1564,10 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
     wave_sync();
+    const int ksel = std::is_same<TD, double>::value ? k + kLfMargin : k;  // see kLfMargin
     const int nb = PRE32 ? wselect_packed(fill, first_new, pb0, k1)
                  : pack32 ? wselect_packed(fill, first_new, pb0, k)
-                          : wselect(fill, first_new, pb0, k, dedup);
+                          : wselect(fill, first_new, pb0, ksel, dedup);
     best = nb;
     if (r_next >= nr_tot) break;
   }
@@ -1565,21 +1602,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   }
   if constexpr (!PRE32 && std::is_same<TD, double>::value) {  // see knn_fused_kernel
     wave_sync();
-    for (int i = lane; i < best; i += 64) cdist[i] = leftfold_distance(X + (int64_t)bid[i] * d, qs, d);
-    wave_sync();
-    for (int i = lane; i < best; i += 64) {
-      const double di = cdist[i];
-      const int pi = bpos[i];
-      int rank = 0;
-      for (int j = 0; j < best; ++j) rank += cdist[j] < di || (cdist[j] == di && bpos[j] < pi);
-      out_ids[q * k + rank] = bid[i];
-      out_dist[q * k + rank] = di;
-    }
-    for (int i = best + lane; i < k; i += 64) {
-      out_ids[q * k + i] = -1;
-      out_dist[q * k + i] = kInf;
-    }
-    if (lane == 0) out_cnt[q] = best;
+    finalize_leftfold(reinterpret_cast<const double*>(X), d, reinterpret_cast<const double*>(qs), best, k,
+                      dedup, cdist, cid, bid, bpos, lane, 64, [] { wave_sync(); }, q, out_ids, out_dist,
+                      out_cnt);
     return;
   }
   for (int i = lane; i < k; i += 64) {
@@ -2108,7 +2133,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
     RPT_HIP(hipGetLastError());
     return RPT_OK;
   }
-  const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFK * 16 +
+  const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFKx * 16 +
                       (size_t)data->d * (sizeof(TA) + 4) + 64 +
                       (vote > 0 ? (size_t)kVoteCap * 4 + 16 : 0);
   if constexpr (std::is_same<TD, double>::value) {

@@ -573,6 +573,52 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, option, kind, k):
         assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
 
 
+@pytest.mark.parametrize("path", ["default", "no_pre32", "wave", "general"])
+def test_knn_cut_between_two_candidates_an_ulp_apart(rp, ctx, oracle, option, path):
+    """RPTree.hs:174 ranks ALL candidates on metricDDL2's left fold.  The batched distance passes
+    reduce a row by a lane butterfly — the same value to an ulp, not the same bits — so the device
+    keeps k + 8 candidates by that value, re-evaluates them as the fold and selects on THOSE bits.
+    Here the cut falls, for every odd k, between two DIFFERENT rows whose squared terms are a
+    permutation of each other (mathematically equal distances, sums that round differently): the
+    member the reference keeps must be the one returned, on every f64 query path."""
+    d, npairs, k_values = 128, 36, list(range(1, 64, 2))
+    rng = np.random.default_rng(17)
+    rows = []
+    for j in range(npairs):
+        x = rng.standard_normal(d)
+        x *= (1.0 + 1e-3 * j) / np.linalg.norm(x)            # pair j clearly beyond pair j - 1
+        rows += [x, x[rng.permutation(d)]]
+    far = rng.standard_normal((300, d)) * 3.0
+    X = np.ascontiguousarray(np.vstack([np.array(rows), far]))
+    q = np.zeros((1, d))
+    R = np.zeros((1, 0, d))                                  # maxDepth 0: ONE Tip, every point a candidate
+    fo = oracle.forest_build_dense(X, R, 0)
+    lf = np.array([oracle.metric_dd(x, q[0]) for x in X[:2 * npairs]])
+    differ = int((lf[0::2] != lf[1::2]).sum())
+    swapped = int((lf[1::2] < lf[0::2]).sum())
+    assert differ >= 5 and swapped >= 2, (differ, swapped)   # the data really exercises the cut
+    opts = {"default": {}, "no_pre32": {"knn_no_pre32": 1}, "wave": {"knn_no_pre32": 1, "knn_wave": 1},
+            "general": {"knn_general": 1}}[path]
+    import contextlib
+    with contextlib.ExitStack() as st:
+        for name, v in opts.items():
+            st.enter_context(option(name, v))
+        f = rp.forestBatch(0, 0, 0, 1, 1.0, d, X, ctx=ctx, hyperplanes=R)
+        for k in k_values:
+            for dedup in (0, 1):
+                ids, dist, cnt = rp.knnBatch(k, f, q, dedup=dedup)
+                wi, wd = oracle.knn_dense(fo, X, q[0], k, dedup=dedup)
+                assert cnt[0] == len(wi) and np.array_equal(ids[0, :cnt[0]], wi), (path, k, dedup)
+                assert np.array_equal(dist[0, :cnt[0]], wd), (path, k, dedup)
+            # knnPQ's nub (one entry per distance): two rows an ulp apart under one summation order
+            # and equal under the other may or may not collapse (include/rptree_hip.h); what is
+            # returned is strictly ascending and carries the fold's bits of the rows it names
+            ids, dist, cnt = rp.knnBatch(k, f, q, dedup=rp.RPT_KNN_DEDUP_DISTANCE)
+            m = int(cnt[0])
+            assert m == k and (np.diff(dist[0, :m]) > 0).all()
+            assert all(dist[0, i] == oracle.metric_dd(X[ids[0, i]], q[0]) for i in range(m))
+
+
 def test_knn_f32_prefilter_uncertified_queries_rerun(rp, ctx, oracle):
     """Half of the points are one and the same point: for queries near it every distance at the
     prefilter's cut is equal, nothing can be certified, and exactly those queries are answered
