@@ -75,6 +75,13 @@ extern "C" {
  * M.foldrWithKey in keepCounts), each once, and the k best by (distance, id) are returned.
  * Dense data, k <= 64; or-ed into the knn flags: RPT_KNN_VOTE(v), v in [1, 65535]. */
 #define RPT_KNN_VOTE(v) ((int32_t)(v) << 8)
+/* SVector (CSR) data: distances by the reference's own metricSSL2 (Internal.hs:389-393 over diffSS /
+ * binSS :435-450) — the merge of the two index lists STOPS when either vector is exhausted, so the
+ * tail of the longer one is silently dropped — instead of the true Euclidean
+ * distance, for results identical to `knn metricL2` of the reference on SVector data.  Bit-exact
+ * (left fold in merge order); one thread per candidate, general query path.  Ignored for dense
+ * data (metricDDL2 is what they get anyway). */
+#define RPT_KNN_METRIC_REFERENCE (1 << 24)
 
 typedef struct rpt_ctx rpt_ctx;
 typedef struct rpt_dataset rpt_dataset;

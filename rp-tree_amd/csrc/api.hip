@@ -990,7 +990,7 @@ int32_t rpt_knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
     RPT_ARG(data->n == f->n && data->d == f->d, "data shape differs from the forest's");
     RPT_ARG(data->csr == queries->csr, "data and queries must both be dense or both CSR");
     RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
-    RPT_ARG(flags >= 0 && (flags & ~0xffff03) == 0 && (flags & 3) != 3, "unknown knn flags");
+    RPT_ARG(flags >= 0 && (flags & ~0x1ffff03) == 0 && (flags & 3) != 3, "unknown knn flags");
     RPT_ARG(ids_dev && dist_dev && count_dev, "NULL output");
     return knn_dev(ctx, f, data, queries, k, flags, ids_dev, dist_dev, count_dev);
   });
@@ -1004,7 +1004,7 @@ int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
     RPT_TRY(check_query(ctx, f, queries));
     RPT_ARG(ids_host && dist_host && count_host, "NULL output");
     RPT_ARG(k >= 1 && k <= 1024, "k must be in [1,1024]");
-    RPT_ARG(flags >= 0 && (flags & ~0xffff03) == 0 && (flags & 3) != 3, "unknown knn flags");
+    RPT_ARG(flags >= 0 && (flags & ~0x1ffff03) == 0 && (flags & 3) != 3, "unknown knn flags");
     int64_t nq = queries->n;
     DevBuf<int32_t> ids, cnt;
     DevBuf<double> dist;

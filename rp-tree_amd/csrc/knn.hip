@@ -1623,8 +1623,8 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
     const TD* __restrict__ val, int64_t nnz, int d, const int64_t* __restrict__ qrowptr,
     const int32_t* __restrict__ qcol, const TD* __restrict__ qval,
     const int32_t* __restrict__ perm, const Range* __restrict__ ranges,
-    const int64_t* __restrict__ rng_off, int T, int k, int dedup, int32_t* __restrict__ out_ids,
-    double* __restrict__ out_dist, int32_t* __restrict__ out_cnt) {
+    const int64_t* __restrict__ rng_off, int T, int k, int dedup, int refm /* RPT_KNN_METRIC_REFERENCE */,
+    int32_t* __restrict__ out_ids, double* __restrict__ out_dist, int32_t* __restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Entry* buf = reinterpret_cast<Entry*>(smem);
   int* scratch = reinterpret_cast<int*>(smem + sizeof(Entry) * kBuf);
@@ -1653,6 +1653,37 @@ __global__ __launch_bounds__(256) void topk_csr_kernel(
     while (done < rg.n) {
       int take = rg.n - done;
       if (take > cap - filled) take = cap - filled;
+      // RPT_KNN_METRIC_REFERENCE: metricSSL2 (Internal.hs:389-393) as the reference evaluates it —
+      // diffSS = binSS (-) 0 (:435-450), a merge of the two index lists that STOPS when either is
+      // exhausted (the tail of the longer one is dropped), the squares summed by a left fold in
+      // merge order.  One thread per candidate: the walk is sequential by definition.
+      if (refm) {
+        const int64_t qa = qrowptr[q], qb = qrowptr[q + 1];
+        for (int i = threadIdx.x; i < take; i += blockDim.x) {
+          const int id = perm[rg.poff + done + i];
+          int64_t i1 = rowptr[id];
+          const int64_t b1 = rowptr[id + 1];
+          int64_t i2 = qa;
+          double acc = 0.0;
+          while (i1 < b1 && i2 < qb) {
+            const int il = col[i1], ir = qcol[i2];
+            double df;
+            if (il == ir) {
+              df = (double)val[i1] - (double)qval[i2];
+              ++i1;
+              ++i2;
+            } else if (il < ir) {
+              df = (double)val[i1] - 0.0;
+              ++i1;
+            } else {
+              df = 0.0 - (double)qval[i2];
+              ++i2;
+            }
+            acc = acc + df * df;
+          }
+          buf[filled + i] = Entry{sqrt(acc), rg.pos + done + i, id};
+        }
+      } else
       // sixteen lanes per candidate row, sixteen rows per wave in flight (csr_rows_dist2)
       for (int i0 = wave * 16; i0 < take; i0 += 64) {
         constexpr int U = 4;
@@ -2200,6 +2231,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
   ctx->last_candidates = pl.total_cand;
   if (q->n == 0) return RPT_OK;
   const int dedup = flags & 3;
+  const int refm = (flags & RPT_KNN_METRIC_REFERENCE) ? 1 : 0;
   if (data->csr) {
     const size_t smem = topk_smem(data->d, 8);
     ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
@@ -2210,7 +2242,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
       hipLaunchKernelGGL(topk_csr_kernel<double>, dim3((unsigned)q->n), dim3(256), smem,
                          ctx->stream, data->rowptr, data->col, (const double*)data->val, data->nnz, data->d,
                          q->rowptr, q->col, (const double*)q->val, f->perm.p, pl.ranges.p,
-                         pl.rng_off.p, f->T, k, dedup, ids_dev, dist_dev, count_dev);
+                         pl.rng_off.p, f->T, k, dedup, refm, ids_dev, dist_dev, count_dev);
     } else {
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)topk_csr_kernel<float>,
@@ -2218,7 +2250,7 @@ static int32_t knn_general(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
       hipLaunchKernelGGL(topk_csr_kernel<float>, dim3((unsigned)q->n), dim3(256), smem,
                          ctx->stream, data->rowptr, data->col, (const float*)data->val, data->nnz, data->d,
                          q->rowptr, q->col, (const float*)q->val, f->perm.p, pl.ranges.p,
-                         pl.rng_off.p, f->T, k, dedup, ids_dev, dist_dev, count_dev);
+                         pl.rng_off.p, f->T, k, dedup, refm, ids_dev, dist_dev, count_dev);
     }
     RPT_HIP(hipGetLastError());
   } else if (data->dtype == RPT_F64) {
@@ -2243,9 +2275,11 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   RPT_ARG(proj_dtype(q->dtype) == f->pdtype,
           "query dtype must have the forest's projection type (f64 vs f32/bf16)");
   const int vote = (flags >> 8) & 0xffff;  // RPT_KNN_VOTE(v)
-  // (the fused kernels walk the implicit batch topology: streamed forests take the general path)
+  // (the fused kernels walk the implicit batch topology: streamed forests take the general path;
+  // so do SVector rows under the reference's own truncating metric)
+  const bool refm = data->csr && (flags & RPT_KNN_METRIC_REFERENCE);
   const bool fused = k <= kFK && f->T <= 1024 && (!ctx->opt.knn_general || vote > 0) &&
-                     (size_t)data->d * 8 <= 32 * 1024 && !f->xtopo;
+                     (size_t)data->d * 8 <= 32 * 1024 && !f->xtopo && !refm;
   if (vote > 0 && (!fused || data->csr))
     return fail(RPT_E_UNSUPPORTED, "RPT_KNN_VOTE: dense data, k <= 64 and at most 1024 trees");
   if (!fused || q->n == 0) return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import gen
 from ._lib import (RPT_BF16, RPT_F32, RPT_F64, RPT_KNN_DEDUP, RPT_KNN_DEDUP_DISTANCE,
-                   RPT_KNN_KEEP_DUPLICATES,
+                   RPT_KNN_KEEP_DUPLICATES, RPT_KNN_METRIC_REFERENCE,
                    RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA, RPTError, check, lib)
 
 __all__ = [
@@ -701,12 +701,15 @@ def candidatesBatch(forest, qs):
     return off, ids[:total.value]
 
 
-def knnBatch(k, forest, qs, dedup=False, vote=0):
+def knnBatch(k, forest, qs, dedup=False, vote=0, reference_metric=False):
     """knn for a batch of queries -> (ids[nq][k], dist[nq][k], count[nq]).
     dedup: False = the reference's knn (duplicates kept), True = each id once,
     RPT_KNN_DEDUP_DISTANCE = knnPQ's `nub` (one entry per distance).
     vote = v > 0: only points found by at least v trees are ranked (RPT_KNN_VOTE; the
-    reference's commented-out counts / keepCounts, RPTree.hs:464-478), ties by ascending id."""
+    reference's commented-out counts / keepCounts, RPTree.hs:464-478), ties by ascending id.
+    reference_metric: SVector data are ranked by the reference's own metricSSL2 (Internal.hs:
+    389-393: the merge of the index lists stops at the shorter vector's end) instead of the true
+    Euclidean distance."""
     ctx = forest.ctx
     qd, nq = _query_dataset(ctx, forest.data, qs)
     ids = np.empty((nq, k), dtype=np.int32)
@@ -715,6 +718,8 @@ def knnBatch(k, forest, qs, dedup=False, vote=0):
     flags = (RPT_KNN_DEDUP_DISTANCE if dedup == RPT_KNN_DEDUP_DISTANCE
              else RPT_KNN_DEDUP if dedup else RPT_KNN_KEEP_DUPLICATES)
     flags |= int(vote) << 8                       # RPT_KNN_VOTE(v)
+    if reference_metric:                          # SVector data: the truncating metricSSL2
+        flags |= RPT_KNN_METRIC_REFERENCE
     check(lib().rpt_knn_host(ctx._h, forest._h, forest.data._h, qd._h, int(k), flags, _vp(ids),
                              _vp(dist), _vp(cnt)))
     return ids, dist, cnt

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("RPTREE_HIP_LIB") or os.path.join(PKG_ROOT, "librptree
 RPT_F64, RPT_F32, RPT_BF16 = 0, 1, 2
 RPT_PROJ_AUTO, RPT_PROJ_EXACT, RPT_PROJ_MFMA = 0, 1, 2
 RPT_KNN_KEEP_DUPLICATES, RPT_KNN_DEDUP, RPT_KNN_DEDUP_DISTANCE = 0, 1, 2
+RPT_KNN_METRIC_REFERENCE = 1 << 24
 RPT_COMM_UID_BYTES = 128
 
 i32, i64, f64 = C.c_int32, C.c_int64, C.c_double

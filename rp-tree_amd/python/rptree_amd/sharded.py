@@ -74,6 +74,8 @@ class Comm:
         _lib.check(_lib.lib().rpt_comm_init(int(n_gpus), C.byref(h)))
         c = Comm(h)
         c.contexts = [Context._borrowed(x, g) for g, x in enumerate(c._ctx)]
+        for x in c.contexts:
+            x._owner = c            # the comm owns these rpt_ctx: it must outlive their users
         return c
 
     @staticmethod
@@ -107,9 +109,27 @@ class Comm:
         _lib.check(_lib.lib().rpt_comm_sync(self._h))
 
     def close(self):
-        if self._h is not None:
-            _lib.lib().rpt_comm_destroy(self._h)
-            self._h = None
+        """rpt_comm_destroy.  After rpt_comm_init the communicator OWNS its contexts, and destroying
+        them under a live Dataset / RPForest would leave that handle with a dangling ctx (its own
+        close dereferences it): everything still alive on those contexts is closed first, forests
+        before datasets."""
+        if self._h is None:
+            return
+        mine = [c for c in getattr(self, "contexts", []) if getattr(c, "_owner", None) is self]
+        if mine:
+            objs = [o for o in list(_live) if getattr(o, "ctx", None) in mine or
+                    (type(o).__name__ == "ShardedForest" and o.comm is self)]
+            for kind in ("ShardedForest", "RPStreamForest", "RPForest", "Dataset"):
+                for o in objs:
+                    if type(o).__name__ == kind:
+                        try:
+                            o.close()
+                        except Exception:
+                            pass
+            for c in mine:
+                c._h = None
+        _lib.lib().rpt_comm_destroy(self._h)
+        self._h = None
 
     def __del__(self):
         try:
@@ -178,57 +198,3 @@ class ShardedForest:
             self.close()
         except Exception:
             pass
-
-
-# ---------------------------------------------------------------------------------------------
-# CPU rehearsal of the exchange protocol (tests/test_sharded_gloo.py: world size 2 over gloo, the
-# shards answered by the oracle): the record layout, the shard-major gather and the merge order
-# are the C ABI's; only the transport differs (gloo instead of RCCL).
-# ---------------------------------------------------------------------------------------------
-def gather_topk(ids, dist_, cnt, group=None):
-    """All-gather per-rank top-k lists -> shard-major tensors [G][nq][k], [G][nq][k], [G][nq]."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    outs = []
-    for x in (ids, dist_, cnt):
-        x = x.contiguous()
-        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=group)     # concatenation along dim 0
-        outs.append(out.view((world,) + tuple(x.shape)))
-    return tuple(outs)
-
-
-class ExchangeRecord:
-    """One shard's kNN result as a single byte buffer + typed views into it (dist [nq][k] f64,
-    ids [nq][k] i32, count [nq] i32), in the layout of rpt_knn_record_layout."""
-
-    def __init__(self, nq, k, device):
-        import torch
-        self.nq, self.k = nq, k
-        self.bytes, od, oi, oc = record_layout(nq, k)
-        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)
-        self.dist = self.buf[od:od + nq * k * 8].view(torch.float64).view(nq, k)
-        self.ids = self.buf[oi:oi + nq * k * 4].view(torch.int32).view(nq, k)
-        self.count = self.buf[oc:oc + nq * 4].view(torch.int32)
-
-    @staticmethod
-    def views_of(gathered, g, nq, k):
-        """(ids, dist, count) views of shard g inside an all-gathered [G][bytes] tensor."""
-        import torch
-        _, od, oi, oc = record_layout(nq, k)
-        row = gathered[g]
-        return (row[oi:oi + nq * k * 4].view(torch.int32).view(nq, k),
-                row[od:od + nq * k * 8].view(torch.float64).view(nq, k),
-                row[oc:oc + nq * 4].view(torch.int32))
-
-
-def gather_records(rec, group=None, out=None):
-    """All-gather the ranks' exchange records -> uint8 tensor [G][bytes] (one collective)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    if out is None:
-        out = torch.empty((world, rec.bytes), dtype=torch.uint8, device=rec.buf.device)
-    dist.all_gather_into_tensor(out.view(-1), rec.buf, group=group)
-    return out

@@ -428,6 +428,35 @@ def test_csr_knn_fused_equals_general_path_and_oracle(rp, ctx, oracle, dtype):
                 assert np.array_equal(ids[i, :cnt[i]], wi)
 
 
+def test_csr_knn_with_the_reference_metric_is_bit_identical(rp, ctx, oracle):
+    """RPT_KNN_METRIC_REFERENCE: SVector data ranked by the reference's own metricSSL2
+    (Internal.hs:389-393 over binSS :435-450, which stops at the shorter vector's end) — ids AND
+    distance bits equal `knn metricL2` of the oracle's faithful restatement (true_l2 = False), for
+    every duplicate rule; and they differ from the true-L2 answer, as they should."""
+    n, d, T, ml, k = 20000, 200, 8, 40, 10
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.2)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(9, T, L, pnz, d)
+    f = rp.forestBatch(9, L, ml, T, pnz, d, (rowptr, col, val, d), ctx=ctx, hyperplanes=R)
+    fo = oracle.forest_build_csr(rowptr, col, val, d, R, ml)
+    assert np.array_equal(f.perm, fo.perm)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 48, d, 0.2)
+    qs = (qr, qc, qv, d)
+    differs = 0
+    for dedup in (False, True, rp.RPT_KNN_DEDUP_DISTANCE):
+        ids, dist, cnt = rp.knnBatch(k, f, qs, dedup=dedup, reference_metric=True)
+        for i in range(48):
+            a0, b0 = qr[i], qr[i + 1]
+            wi, wd = oracle.knn_csr(fo, rowptr, col, val, qc[a0:b0], qv[a0:b0], k,
+                                    dedup=(2 if dedup == rp.RPT_KNN_DEDUP_DISTANCE else int(dedup)),
+                                    true_l2=False)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi), (dedup, i)
+            assert np.array_equal(dist[i, :cnt[i]], wd), (dedup, i)
+        t_ids, t_dist, _ = rp.knnBatch(k, f, qs, dedup=dedup)
+        differs += int((t_dist != dist).any())
+    assert differs == 3                     # the truncated tails matter on this data
+
+
 def test_csr_knn_f32_prefilter_is_exact(rp, ctx, oracle):
     """f64 SVector rows, duplicates kept: candidates are ranked on the (u16 column, f32 value)
     shadow of the rows, exact distances for the best k + 6, the cut certified per query on squared

@@ -1,6 +1,7 @@
 """world_size-2 gloo test (CPU) of the multi-GPU protocol: tree -> shard mapping, the
 all-gather layout [G][nq][k] and the stable merge order.  Each rank answers its shard with the
-ORACLE (there is no GPU here); the exchange uses the product's gather_topk; the merged result
+ORACLE (there is no GPU here); the exchange is rehearsed by tests/sharded_rehearsal.py (the
+C ABI's record layout over gloo instead of RCCL); the merged result
 must equal the oracle's knn over the full forest."""
 import os
 import socket
@@ -44,13 +45,14 @@ def merge_reference(gi, gd, gc, k, dedup):
 
 
 def _worker(rank, world, port, out):
-    for p in (ROOT, os.path.join(ROOT, "rp-tree_amd", "python")):
+    for p in (ROOT, os.path.join(ROOT, "rp-tree_amd", "python"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as o
     from rptree_amd import sharded
+    import sharded_rehearsal as rehearsal
     n, d, T, ml, k, nq = 3000, 12, 6, 25, 8, 20
     X = o.data_normal_dense2(1234, n, d)
     L, _, pnz = o.tree_cfg(ml, n, d)
@@ -64,7 +66,7 @@ def _worker(rank, world, port, out):
     for i in range(nq):
         a, b = o.knn_dense(f_local, X, Q[i], k)
         ids[i, :len(a)], dd[i, :len(a)], cnt[i] = a, b, len(a)
-    gi, gd, gc = sharded.gather_topk(torch.from_numpy(ids), torch.from_numpy(dd),
+    gi, gd, gc = rehearsal.gather_topk(torch.from_numpy(ids), torch.from_numpy(dd),
                                      torch.from_numpy(cnt))
     ok = True
     for dedup in (False, True):
@@ -76,14 +78,14 @@ def _worker(rank, world, port, out):
     # shard layout: slot g of the gathered tensor is rank g's list
     ok = ok and np.array_equal(gi[rank].numpy(), ids)
     # the packed exchange record (ONE all-gather): same content, shard-major, layout from the C ABI
-    rec = sharded.ExchangeRecord(nq, k, torch.device("cpu"))
+    rec = rehearsal.ExchangeRecord(nq, k, torch.device("cpu"))
     rec.ids.copy_(torch.from_numpy(ids))
     rec.dist.copy_(torch.from_numpy(dd))
     rec.count.copy_(torch.from_numpy(cnt))
-    gathered = sharded.gather_records(rec)
+    gathered = rehearsal.gather_records(rec)
     ok = ok and tuple(gathered.shape) == (world, rec.bytes)
     for g in range(world):
-        vi, vd, vc = sharded.ExchangeRecord.views_of(gathered, g, nq, k)
+        vi, vd, vc = rehearsal.ExchangeRecord.views_of(gathered, g, nq, k)
         ok = ok and torch.equal(vi, gi[g]) and torch.equal(vd, gd[g]) and torch.equal(vc, gc[g])
     out[rank] = bool(ok)
     dist.barrier()
@@ -101,12 +103,14 @@ def test_tree_shard():
 
 def test_record_layout():
     from rptree_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sharded_rehearsal as rehearsal
     nq, k = 1000, 10
     b, od, oi, oc = sharded.record_layout(nq, k)
     assert (od, oi, oc) == (0, nq * k * 8, nq * k * 12)
     # distances | ids | counts | one int32 status word, rounded up to 16 bytes
     assert b % 16 == 0 and nq * k * 12 + nq * 4 + 4 <= b < nq * k * 12 + nq * 4 + 4 + 16
-    rec = sharded.ExchangeRecord(7, 3, torch.device("cpu"))
+    rec = rehearsal.ExchangeRecord(7, 3, torch.device("cpu"))
     rec.dist.fill_(1.5)
     rec.ids.fill_(-2)
     rec.count.fill_(3)
