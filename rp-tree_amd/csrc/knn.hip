@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -1358,12 +1359,16 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
     unsigned int* ovf_count, unsigned long long* cand_total,
-    const float* __restrict__ Xf, double xmax, int k1 /* PRE32: see knn_fused_kernel */) {
+    const float* __restrict__ Xf, double xmax, int k1 /* PRE32: see knn_fused_kernel */,
+    unsigned long long* dbg /* debug_stamps: phase clocks of one wave */) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t q = (int64_t)blockIdx.x * 4 + wave;
   if (q >= nq) return;  // no workgroup barrier below
+  int dbgi = 0;
+#define KSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) dbg[dbgi++] = clock64(); } while (0)
+  KSTAMP();
   const bool rerun = !PRE32 && k1 == -1;  // second pass: only the queries the prefilter gave up on
   if (rerun && ovf_flags[q] != 2u) return;
   const bool pack32 = !PRE32 && sizeof(TA) == 4 && dedup == 0;  // see knn_fused_kernel
@@ -1409,6 +1414,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     }
   }
   const int nc_tot = __shfl(inc_c, 63), nr_tot = __shfl(inc_r, 63);
+  KSTAMP();  // 1: traversal
   if (nr_tot > kWR) {  // too many leaf ranges for the slab: general path
     if (lane == 0) {
       ovf_flags[q] = 1u;
@@ -1557,6 +1563,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     r_done = rd;
     pos_base = pb;
     wave_sync();
+    KSTAMP();  // batch filled
     if constexpr (PRE32)
       batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, 0, 1, lane);
     else if (pack32)
@@ -1564,11 +1571,13 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
     wave_sync();
+    KSTAMP();  // distances
     const int ksel = std::is_same<TD, double>::value ? k + kLfMargin : k;  // see kLfMargin
     const int nb = PRE32 ? wselect_packed(fill, first_new, pb0, k1)
                  : pack32 ? wselect_packed(fill, first_new, pb0, k)
                           : wselect(fill, first_new, pb0, ksel, dedup);
     best = nb;
+    KSTAMP();  // selection
     if (r_next >= nr_tot) break;
   }
   if constexpr (PRE32) {  // exact distances of the kept entries + certified cut (knn_fused_kernel)
@@ -1587,7 +1596,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
       batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, 0, 1, lane);
     }
     wave_sync();
+    KSTAMP();  // refine distances
     best = wselect(m, m, 0, k, 0);
+    KSTAMP();  // final selection
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
       const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
@@ -1613,6 +1624,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     out_dist[q * k + i] = ok ? (pack32 ? (double)sqrt(bdist[i]) : bdist[i]) : kInf;
   }
   if (lane == 0) out_cnt[q] = best;
+  KSTAMP();
+#undef KSTAMP
 }
 
 // CSR data and CSR queries: the query is densified into LDS; distance of a sparse row x:
@@ -2125,6 +2138,24 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
               (int64_t)f->T * f->min_leaf <= kWaveCandidates;
   if (force >= 0) wave = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
   if (vote > 0 || data->csr) wave = false;
+  // debug_stamps: phase clocks of one wave of the wave kernel, printed after the launch
+  DevBuf<unsigned long long> dbgdev;
+  unsigned long long* dbg = nullptr;
+  if (ctx->opt.debug_stamps && wave && dbgdev.alloc(64) == RPT_OK) {
+    (void)hipMemsetAsync(dbgdev.p, 0, 64 * 8, ctx->stream);
+    dbg = dbgdev.p;
+  }
+  struct DbgPrint {
+    rpt_ctx* ctx;
+    unsigned long long* p;
+    ~DbgPrint() {
+      if (!p) return;
+      unsigned long long hs[64];
+      (void)stream_sync(ctx->stream);
+      if (hipMemcpy(hs, p, sizeof(hs), hipMemcpyDeviceToHost) != hipSuccess) return;
+      for (int i = 1; i < 64 && hs[i]; ++i) fprintf(stderr, "knn wave stamp %d: +%llu\n", i, hs[i] - hs[i - 1]);
+    }
+  } dbgprint{ctx, nullptr};
   ProfScope ps(ctx, RPT_PROF_KNN_TOPK);
   // f64 data, duplicates kept, small k: rank the candidates on the f32 shadow (half the row
   // bytes), exact distances for the best k' only, cut certified per query (see the kernels)
@@ -2137,6 +2168,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                      !ctx->opt.knn_no_pre32 && data->shadow32 && !rerun && !f->prefilter_off &&
                      (!data->csr || data->shadow_col16);
   if (wave) {
+    dbgprint.p = dbg;
     const size_t smem = 4 * wbytes;
     if constexpr (std::is_same<TD, double>::value) {
       if (pre32) {
@@ -2148,7 +2180,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                            (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                            (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
                            cnt, ovf + 1, ovf, cand_total, (const float*)data->shadow32,
-                           data->max_norm, kp + 1);
+                           data->max_norm, kp + 1, dbg);
         RPT_HIP(hipGetLastError());
         return RPT_OK;
       }
@@ -2160,7 +2192,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                        dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
                        (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                        (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
-                       cnt, ovf + 1, ovf, cand_total, (const float*)nullptr, 0.0, rerun ? -1 : 0);
+                       cnt, ovf + 1, ovf, cand_total, (const float*)nullptr, 0.0, rerun ? -1 : 0, dbg);
     RPT_HIP(hipGetLastError());
     return RPT_OK;
   }

@@ -1233,7 +1233,6 @@ __global__ __launch_bounds__(256, 3) void wsub_kernel(
 // grid = ceil(S*T/4) blocks of 256 threads.
 // ---------------------------------------------------------------------------------------
 constexpr int kSPool = 128;  // positions per level a wave can order exactly
-constexpr int kWMaxNodes = 1 << (kWRmax - 1);
 constexpr int kPkBits = 21;  // image bits per level in a packed word (three levels per u64)
 constexpr int kPkLevels = 3;
 
@@ -1243,10 +1242,8 @@ struct WSortSlab {
   // both hold the id by position (bit 31 = node still active) for the coalesced stores.
   unsigned long long store[PK ? kWCap : kWCap / 2];
   double tk[kSPool];
-  unsigned int rkey[kSPool], rout[kSPool];
+  unsigned int rkey[kSPool + 1], rout[kSPool + 1];  // + a dummy slot
   int rid[kSPool];
-  double vthr[kWMaxNodes], vlo[kWMaxNodes];
-  int tlab[kWMaxNodes * 3];
 };
 
 template <int D>
@@ -1550,9 +1547,10 @@ __global__ __launch_bounds__(256, 3) void wsort_kernel(
           break;
         }
         const int base = inc - cnt;
+        // (slot kSPool is a dummy: unconditional LDS accesses instead of sixteen divergent regions)
 #pragma unroll
         for (int r = 0; r < kWE; ++r)
-          if (bits & (1u << r)) W.rkey[base + __popc(bits & ((1u << r) - 1u))] = k[r];
+          W.rkey[(bits & (1u << r)) ? base + __popc(bits & ((1u << r) - 1u)) : kSPool] = k[r];
         wsync();
         // by pool slot from here on: the true key of every member, fetched again by id
         for (int sl = lane; sl < tot; sl += 64) {
@@ -1576,53 +1574,56 @@ __global__ __launch_bounds__(256, 3) void wsort_kernel(
         }
         wsync();
 #pragma unroll
-        for (int r = 0; r < kWE; ++r)
-          if (bits & (1u << r)) k[r] = W.rout[base + __popc(bits & ((1u << r) - 1u))];
+        for (int r = 0; r < kWE; ++r) {
+          const unsigned int v = W.rout[(bits & (1u << r)) ? base + __popc(bits & ((1u << r) - 1u)) : kSPool];
+          k[r] = (bits & (1u << r)) ? v : k[r];
+        }
         wsync();
       }
     }
     // ---- d. thresholds and margins: the keys at positions nh, nh - 1, nh + 1 of every node
-    // (Internal.hs:496-501; n == 2 -> (p'[0], p'[1]); n == 1 -> p'[0] for all three).  The
-    // positions post their local index, one lane per (node, value) fetches and writes ----
-    if (lane < kWMaxNodes * 3) W.tlab[lane] = -1;
-    if (lane < kWMaxNodes) {
-      W.vthr[lane] = __builtin_huge_val();
-      W.vlo[lane] = -__builtin_huge_val();
-    }
-    wsync();
-#pragma unroll
-    for (int r = 0; r < kWE; ++r) {
-      const int p = lane * kWE + r;
-      const int off = (int)(info[r] & 2047u), n = (int)((info[r] >> 11) & 2047u);
-      const int rel = p - off, nh = n >> 1;
-      const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
-      const int j = (int)((info[r] >> 22) & 31u);
-      const bool a = p < n_top && !(info[r] & kWsLeaf);
-      const int lab = (int)(k[r] & 1023u) | (nh > 0 ? 1 << 16 : 0);
-      if (a && rel == nh) W.tlab[j * 3] = lab;
-      if (a && rel == il) W.tlab[j * 3 + 1] = lab;
-      if (a && rel == ih) W.tlab[j * 3 + 2] = lab;
-    }
-    wsync();
-    if (lane < 3 << depth) {
-      const int lab = W.tlab[lane];
-      if (lab >= 0) {
-        const int j = lane / 3, which = lane - 3 * j;
-        const double v = (double)Pl[id_of((unsigned int)lab & 1023u)];
-        const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
-        if (which == 0) {
-          thr[h] = v;
-          W.vthr[j] = v;
-        } else if (which == 1) {
-          mglo[h] = v;
-          if (lab >> 16) W.vlo[j] = v;
+    // (Internal.hs:496-501; n == 2 -> (p'[0], p'[1]); n == 1 -> p'[0] for all three).  One lane
+    // per (node, value): it works out the node's range from (n_top, depth, j) — the nodes of a
+    // depth are all Bins or all beyond a Tip of an ancestor, and sizes differ by at most one —,
+    // fetches the sort key at the position it needs by sixteen lane reads (its register index is
+    // data) and the true key by id ----
+    {
+      const int j = lane / 3, which = lane - 3 * j;
+      int off = 0, n = n_top;
+      bool bin = lane < (3 << depth);
+      for (int b = depth - 1; b >= 0; --b) {  // the path of node j from the top node
+        bin = bin && !is_leaf_dev(level - 1 - b, n, L, min_leaf);
+        const int nhb = n >> 1;
+        if ((j >> b) & 1) {
+          off += nhb;
+          n -= nhb;
         } else {
-          mghi[h] = v;
+          n = nhb;
         }
       }
+      bin = bin && !is_leaf_dev(level, n, L, min_leaf);
+      const int nh = n >> 1;
+      const int il = nh > 0 ? nh - 1 : 0, ih = nh + 1 < n ? nh + 1 : n - 1;
+      const int pt = off + (which == 0 ? nh : which == 1 ? il : ih);
+      const int srcl = bin ? pt >> 4 : lane, srcr = pt & 15;
+      unsigned int kt = 0;
+#pragma unroll
+      for (int r = 0; r < kWE; ++r) {
+        const unsigned int v = (unsigned int)__shfl((int)k[r], srcl);
+        kt = srcr == r ? v : kt;
+      }
+      double v = 0.0;
+      if (bin) {
+        v = (double)Pl[id_of(kt & 1023u)];
+        const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
+        if (which == 0) thr[h] = v;
+        else if (which == 1) mglo[h] = v;
+        else mghi[h] = v;
+      }
+      // a cut that straddles a tie (statistics): p'[nh - 1] == p'[nh]
+      const double vthr = __shfl(v, j * 3 < 64 ? j * 3 : 0), vlo = __shfl(v, j * 3 + 1 < 64 ? j * 3 + 1 : 0);
+      if (bin && which == 0 && nh > 0 && !(vlo < vthr)) atomicAdd(tie_count, 1ULL);
     }
-    wsync();
-    if (lane < (1 << depth) && !(W.vlo[lane] < W.vthr[lane])) atomicAdd(tie_count, 1ULL);
     // ---- e. every position one level down ----
 #pragma unroll
     for (int r = 0; r < kWE; ++r) info[r] = ws_step(info[r], lane * kWE + r, level + 1, L, min_leaf);

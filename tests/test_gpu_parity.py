@@ -411,8 +411,12 @@ def test_knn_merge_shards(rp, ctx, small_forest, oracle):
 def test_knn_merge_records_equals_merge(rp, ctx, small_forest):
     """rpt_knn_merge_records_dev over packed exchange records (one all-gather) == rpt_knn_merge_dev
     over the three shard-major arrays; the record is filled directly by rpt_knn_dev."""
+    import os
+    import sys
     import torch
     from rptree_amd import _lib, sharded
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_rehearsal import ExchangeRecord
     X, f, fo, Q = small_forest
     k, nq = 10, len(Q)
     R = f.R
@@ -422,7 +426,7 @@ def test_knn_merge_records_equals_merge(rp, ctx, small_forest):
     L_ = _lib.lib()
     recs = []
     for sh in shards:
-        rec = sharded.ExchangeRecord(nq, k, torch.device("cuda", 0))
+        rec = ExchangeRecord(nq, k, torch.device("cuda", 0))
         _lib.check(L_.rpt_knn_dev(ctx._h, sh._h, ds._h, qs._h, k, 0, rec.ids.data_ptr(),
                                   rec.dist.data_ptr(), rec.count.data_ptr()))
         recs.append(rec)
@@ -431,7 +435,7 @@ def test_knn_merge_records_equals_merge(rp, ctx, small_forest):
     gathered = torch.stack([r.buf for r in recs]).contiguous()       # what the all-gather returns
     for g, sh in enumerate(shards):                                  # the views address shard g
         want = rp.knnBatch(k, sh, Q)
-        vi, vd, vc = sharded.ExchangeRecord.views_of(gathered, g, nq, k)
+        vi, vd, vc = ExchangeRecord.views_of(gathered, g, nq, k)
         assert np.array_equal(vi.cpu().numpy(), want[0]) and np.array_equal(vd.cpu().numpy(), want[1])
         assert np.array_equal(vc.cpu().numpy(), want[2])
     outs = []
