@@ -6,11 +6,11 @@
 -- It shows the binding a maintainer would add next to src/Data/RPTree/Batch.hs; the tested
 -- mirrors of exactly this call sequence are rp-tree_amd/python/rptree_amd/__init__.py and
 -- rp-tree_amd/host/rptree.hpp.
-module Data.RPTree.HIP (forestBatchHIP, knnHIP, FlatForest(..)) where
+module Data.RPTree.HIP (forestBatchHIP, forestHIP, withDeviceForest, knnHIP, FlatForest(..), DeviceForest(..)) where
 
 import Control.Exception (Exception, bracket, throwIO)
 import Control.Monad (when)
-import Data.Int (Int32, Int64)
+import Data.Int (Int8, Int32, Int64)
 import Data.Word (Word64)
 import Foreign.C.String (CString, peekCString)
 import Foreign.Marshal.Alloc (alloca)
@@ -39,6 +39,9 @@ foreign import ccall safe "rpt_forest_build"        c_forest_build   :: Ptr Ctx 
 foreign import ccall safe "rpt_forest_free"         c_forest_free    :: Ptr Forest -> IO Int32
 foreign import ccall safe "rpt_forest_get_perm"     c_forest_perm    :: Ptr Forest -> Ptr Int32 -> IO Int32
 foreign import ccall safe "rpt_forest_get_nodes"    c_forest_nodes   :: Ptr Forest -> Ptr Double -> Ptr Double -> Ptr Double -> IO Int32
+-- forest / tree (Conduit.hs:58-121): the fold of insert over chunks, Internal.hs:245-297
+foreign import ccall safe "rpt_forest_stream_build" c_stream_build   :: Ptr Ctx -> Ptr Dataset -> Ptr Double -> Int32 -> Int32 -> Int32 -> Int64 -> Int32 -> Ptr (Ptr Forest) -> IO Int32
+foreign import ccall safe "rpt_forest_get_topology" c_forest_topo    :: Ptr Forest -> Ptr Int64 -> Ptr Int8 -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> IO Int32
 foreign import ccall safe "rpt_knn_host"            c_knn_host       :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Int32 -> Ptr Int32 -> Ptr Double -> Ptr Int32 -> IO Int32
 -- knnH (RPTree.hs:199-217): two calls, the first with null outputs returns the result size
 foreign import ccall safe "rpt_knnh_host"           c_knnh_host      :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int32 -> Ptr Int64 -> Ptr Int32 -> Ptr Double -> Int64 -> Ptr Int64 -> IO Int32
@@ -107,6 +110,64 @@ rebuild ff src t = go 0 0 0 (ffN ff)
           let nh = m `div` 2; ix = t * nodes + h
           in Bin () (ffThr ff VS.! ix) (Margin (Max (ffLo ff VS.! ix)) (Min (ffHi ff VS.! ix)))
                  (go (lev + 1) (2 * h + 1) off nh) (go (lev + 1) (2 * h + 2) (off + nh) (m - nh))
+
+-- | Drop-in for 'Data.RPTree.Conduit.forest' (Conduit.hs:104-121) on dense data once the conduit
+-- has been sunk into a vector (@src <- runConduit (source .| C.sinkVector)@): the reference's fold
+-- of 'insert' over chunks of @chunk@ points runs on the device (rpt_forest_stream_build) and the
+-- explicit topology it returns (kind 1 = Bin, 2 = Tip per heap slot, the same for every tree) is
+-- turned back into ordinary 'RPT' values.
+forestHIP :: Word64 -> Int -> Int -> Int -> Int -> Double -> Int
+          -> V.Vector (Embed DVector Double x)
+          -> RPForest Double (V.Vector (Embed DVector Double x))
+forestHIP seed maxd minl ntrees chunk pnz dim src = unsafePerformIO $ do
+  let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))  -- Conduit.hs:116-118
+      rflat = VS.concat [ denseOf dim r | rvs <- V.toList rvss, r <- V.toList rvs ]
+      xflat = VS.concat [ VS.convert v | Embed (DV v) _ <- V.toList src ]
+      n = V.length src
+      slots = 2 ^ (maxd + 1) - 1
+      acquire mk = alloca $ \pp -> mk pp >>= check >> peek pp
+  (perm, thr, lo, hi, kind, loff, llen) <-
+    bracket (acquire (c_ctx_create 0)) c_ctx_destroy $ \ctx ->
+    bracket (acquire (\pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral n) (fromIntegral dim) 0 pp)))
+            c_dataset_free $ \ds ->
+    bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_stream_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) (fromIntegral chunk) 0 pp)))
+            c_forest_free $ \f -> do
+      perm <- VSM.new (ntrees * n); thr <- VSM.new (ntrees * slots); lo <- VSM.new (ntrees * slots); hi <- VSM.new (ntrees * slots)
+      kind <- VSM.new slots; loff <- VSM.new slots; llen <- VSM.new slots
+      VSM.unsafeWith perm (c_forest_perm f) >>= check
+      VSM.unsafeWith thr (\a -> VSM.unsafeWith lo (\b -> VSM.unsafeWith hi (c_forest_nodes f a b))) >>= check
+      alloca $ \ps -> alloca $ \ph -> alloca $ \pd ->
+        VSM.unsafeWith kind (\k -> VSM.unsafeWith loff (\o -> VSM.unsafeWith llen (\l -> c_forest_topo f ps k o l ph pd))) >>= check
+      (,,,,,,) <$> VS.freeze perm <*> VS.freeze thr <*> VS.freeze lo <*> VS.freeze hi
+               <*> VS.freeze kind <*> VS.freeze loff <*> VS.freeze llen
+  let tree t = go 0
+        where
+          go h | kind VS.! h == 1 =
+                   let ix = t * slots + h
+                   in Bin () (thr VS.! ix) (Margin (Max (lo VS.! ix)) (Min (hi VS.! ix))) (go (2 * h + 1)) (go (2 * h + 2))
+               | otherwise =            -- Tip (kind 2; an absent slot never hangs below a Bin)
+                   Tip () (V.generate (fromIntegral (llen VS.! h))
+                             (\i -> src V.! fromIntegral (perm VS.! (t * n + fromIntegral (loff VS.! h) + i))))
+  pure $ IM.fromList [ (t, RPTree (rvss V.! t) (tree t)) | t <- [0 .. ntrees - 1] ]
+
+-- | A forest that STAYS on the device, for hosts that build once and query many times (what the
+-- north star means by "host code stays Haskell": the handle is the currency, as 'RPForest' is in
+-- the reference).  The context, the packed dataset and the forest live for the extent of the
+-- callback; queries go through 'knnHIP' without re-uploading anything.
+data DeviceForest = DeviceForest { dfCtx :: Ptr Ctx, dfData :: Ptr Dataset, dfForest :: Ptr Forest }
+
+withDeviceForest :: Word64 -> Int -> Int -> Int -> Double -> Int -> V.Vector (Embed DVector Double x)
+                 -> (DeviceForest -> IO a) -> IO a
+withDeviceForest seed maxd minl ntrees pnz dim src act = do
+  let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))
+      rflat = VS.concat [ denseOf dim r | rvs <- V.toList rvss, r <- V.toList rvs ]
+      xflat = VS.concat [ VS.convert v | Embed (DV v) _ <- V.toList src ]
+      acquire mk = alloca $ \pp -> mk pp >>= check >> peek pp
+  bracket (acquire (c_ctx_create 0)) c_ctx_destroy $ \ctx ->
+    bracket (acquire (\pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral (V.length src)) (fromIntegral dim) 0 pp)))
+            c_dataset_free $ \ds ->
+    bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) 0 pp)))
+            c_forest_free $ \f -> act (DeviceForest ctx ds f)
 
 -- | 'knn metricL2 k' (RPTree.hs:168-176) for a batch of dense queries: ids and distances.
 knnHIP :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int -> Int -> IO (VS.Vector Int32, VS.Vector Double, VS.Vector Int32)

@@ -35,6 +35,16 @@ int main() {
       if (std::fabs(metricL2(xs[(size_t)h.second], fromListDv({0, 0})) - h.first) > 1e-12)
         return std::printf("FAIL metric\n"), 1;
     std::printf("ok: %d trees hold all %d points; knn max distance %.4f < 1\n", ntrees, n, mx);
+    // the streaming build, RPTreeSpec.hs:87-106: `forest` with rpTreeCfg's chunk size (n / 100)
+    RPForest tts2 = forest(ctx, 42, cfg.fpMaxTreeDepth, minLeaf, ntrees, cfg.fpDataChunkSize, 1.0, dim, dats);
+    for (int t = 0; t < ntrees; ++t)
+      if (tts2.treeSize(t) != n) return std::printf("FAIL streaming treeSize %lld\n", (long long)tts2.treeSize(t)), 1;
+    auto hits2 = knn(tts2, k, fromListDv({0, 0}));
+    double mx2 = 0;
+    for (auto& h : hits2) mx2 = h.first > mx2 ? h.first : mx2;
+    if ((int)hits2.size() != k || !(mx2 < 1.0)) return std::printf("FAIL streaming knn max dist %g\n", mx2), 1;
+    std::printf("ok: streaming forest (chunks of %lld) holds all points; knn max distance %.4f < 1\n",
+                (long long)cfg.fpDataChunkSize, mx2);
   } catch (const RPTError& e) {
     std::printf("RPTError %d: %s\n", e.code, e.what());
     return 2;

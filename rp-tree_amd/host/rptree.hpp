@@ -150,8 +150,11 @@ class RPForest {
   const Dataset* data;
   std::vector<std::vector<SVector>> rpVectors;  // _rpVectors of every tree (one per level)
   int T, L, minLeaf;
+  bool streamed = false;  // built by the chunk fold of `forest` (explicit topology)
+  // chunk == 0: the batch build (createMulti); chunk > 0: the streaming build, `insert` folded over
+  // chunks of `chunk` points (Conduit.hs:147-176 over Internal.hs:245-297)
   RPForest(Context& c, const Dataset& ds, std::vector<std::vector<SVector>> rvss, int maxd,
-           int minl)
+           int minl, int64_t chunk = 0)
       : ctx(&c), data(&ds), rpVectors(std::move(rvss)), T((int)rpVectors.size()), L(maxd),
         minLeaf(minl) {
     std::vector<double> R((size_t)T * L * ds.d, 0.0);  // dense-ified [T][L][d]
@@ -159,7 +162,12 @@ class RPForest {
       for (int l = 0; l < L; ++l)
         for (auto& iv : rpVectors[(size_t)t][(size_t)l].svVec)
           R[((size_t)t * L + l) * ds.d + (size_t)iv.first] = iv.second;
-    check(rpt_forest_build(c.get(), ds.get(), R.data(), T, L, minl, RPT_PROJ_AUTO, &h_));
+    if (chunk > 0) {
+      check(rpt_forest_stream_build(c.get(), ds.get(), R.data(), T, L, minl, chunk, RPT_PROJ_AUTO, &h_));
+      streamed = true;
+    } else {
+      check(rpt_forest_build(c.get(), ds.get(), R.data(), T, L, minl, RPT_PROJ_AUTO, &h_));
+    }
   }
   ~RPForest() { rpt_forest_free(h_); }
   RPForest(const RPForest&) = delete;
@@ -172,6 +180,11 @@ class RPForest {
   }
   // treeSize (RPTree.hs:362-363): sum of the leaf sizes of tree t
   int64_t treeSize(int) const {
+    if (streamed) {  // points held by the Tips (less than n after the data-loss branch, :277)
+      int64_t held = 0;
+      check(rpt_forest_get_topology(h_, nullptr, nullptr, nullptr, nullptr, &held, nullptr));
+      return held;
+    }
     int64_t cnt = 0, nrec = 0;
     check(rpt_topology(data->n, L, minLeaf, nullptr, 0, &nrec));
     std::vector<int64_t> rec((size_t)nrec * 5);
@@ -195,6 +208,19 @@ inline RPForest forestBatch(Context& ctx, uint64_t seed, int maxd, int minl, int
 inline RPForest treeBatch(Context& ctx, uint64_t seed, int maxDepth, int minLeaf, double pnz, int dim,
                           const Dataset& src) {
   return forestBatch(ctx, seed, maxDepth, minLeaf, 1, pnz, dim, src);
+}
+// forest :: Word64 -> Int -> Int -> Int -> Int -> Double -> Int -> source -> RPForest
+// (Conduit.hs:104-121): seed, max depth, min leaf, trees, CHUNK SIZE, density, dimension, data —
+// the reference's streaming semantics (same hyperplane draw order, Conduit.hs:116-118)
+inline RPForest forest(Context& ctx, uint64_t seed, int maxd, int minl, int ntrees, int64_t chunksize,
+                       double pnz, int dim, const Dataset& src) {
+  if (dim != src.d) throw RPTError(RPT_E_ARG, "projection vector dimension != data dimension");
+  if (chunksize < 1) throw RPTError(RPT_E_ARG, "chunk size must be >= 1");
+  SMGen g(seed);
+  std::vector<std::vector<SVector>> rvss((size_t)ntrees);
+  for (int t = 0; t < ntrees; ++t)
+    for (int l = 0; l < maxd; ++l) rvss[(size_t)t].push_back(sparse(g, pnz, dim));
+  return RPForest(ctx, src, std::move(rvss), maxd, minl, chunksize);
 }
 
 // knn metricL2 k forest q  (RPTree.hs:168-176): (distance, point id), duplicates kept
