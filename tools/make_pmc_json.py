@@ -37,7 +37,7 @@ def rw(e):  # FETCH_SIZE / WRITE_SIZE are KB of 1024 B; gfx950 reports 1/2 of wi
 
 
 out = {"note": "rocprofv3 --kernel-trace --pmc <set>, one pass per line of tools/pmc_sets_bench.txt, of "
-               "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline` (tools/prof_cmd.sh); mean over "
+               "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --other-configs none` (tools/prof_cmd.sh); mean over "
                "the full-size launches of a kernel (tools/pmc_mean.py); FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads), WRITE_SIZE as is, "
                "unit KB = 1024 B",
@@ -73,7 +73,9 @@ for name, e in kn.items():
     if key == "f32_prefilter":
         out["knn_fused"] = {"hbm_bytes_per_launch": rw(e)["hbm_bytes_per_launch"], "kernel": name}
 out["split"] = {}
-for pre in ("wsub_kernel", "stream_assign", "stream_hist", "stream_to_perm", "stream_mid"):
+for pre in ("wsub_kernel", "wsort_kernel", "wpack_kernel", "stream_assign", "stream_hist", "stream_to_perm", "stream_mid"):
+    if not [k for k in tab if k[0].startswith(pre)]:
+        continue
     for name, e in full(pre).items():
         out["split"][name] = rw(e)
 json.dump(out, open(dst + "_pmc_traffic.json", "w"), indent=1)

@@ -19,7 +19,7 @@ for name, cname, val, grid in db.execute(
     if cname not in counters:
         continue
     k = short(name)
-    if not (k.startswith("proj_") or k.startswith("stream_") or k.startswith("wsub") or k.startswith("wsort") or k.startswith("wpack") or k.startswith("knn_")):
+    if not (k.startswith("proj_") or k.startswith("stream_") or k.startswith(("wsub", "wsort", "wpack", "knn_", "subtree", "hist_kernel", "scatter_kernel", "sample_kernel", "mid_kernel"))):
         continue
     acc.setdefault(k, {}).setdefault(grid, {}).setdefault(cname, []).append(val)
 rows = ["kernel,grid,launches," + ",".join(counters)]
