@@ -1285,7 +1285,21 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, wave, 4, lane);
     }
     __syncthreads();
-    best = select(m, k, 0);
+    {  // the k best of the m <= 63 refined entries by (distance, position): rank by counting
+      const bool mine = tid < m;
+      const double di = mine ? cdist[tid] : 0.0;
+      const int pi = mine ? cpos[tid] : 0, ii = mine ? cid[tid] : -1;
+      int rank = 0;
+      if (mine)
+        for (int j = 0; j < m; ++j) rank += cdist[j] < di || (cdist[j] == di && cpos[j] < pi);
+      if (mine && rank < k) {
+        bdist[rank] = di;
+        bid[rank] = ii;
+        bpos[rank] = pi;
+      }
+      __syncthreads();
+      best = m < k ? m : k;
+    }
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
       // + sqrt(d) * 4e-23: products in the f32 subnormal range lose relative accuracy
@@ -1597,7 +1611,22 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     }
     wave_sync();
     KSTAMP();  // refine distances
-    best = wselect(m, m, 0, k, 0);
+    {  // the k best of the m <= 63 refined entries by (distance, position): every lane ranks its
+       // own entry by counting (no selection rounds), the winners go to bdist / bid / bpos
+      const bool mine = lane < m;
+      const double di = mine ? cdist[lane] : kInf;
+      const int pi = mine ? bpos[lane] : 0x7fffffff, ii = mine ? bid[lane] : -1;
+      int rank = 0;
+      for (int j = 0; j < m; ++j) rank += cdist[j] < di || (cdist[j] == di && bpos[j] < pi);
+      wave_sync();
+      if (mine && rank < k) {
+        bdist[rank] = di;
+        bid[rank] = ii;
+        bpos[rank] = pi;
+      }
+      wave_sync();
+      best = m < k ? m : k;
+    }
     KSTAMP();  // final selection
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
