@@ -41,6 +41,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # v_mfma_f64_16x16x4_f64 = 2048 flop per 64 cycles per SIMD (32 flop/clk/SIMD, half the f32
 # 16x16x4 rate of the guide's table) x 1024 SIMDs x 2.4 GHz = 78.6e12.
 MFMA_F64_PEAK_TF = 78.6
+# ... and what a chain-free stream of v_mfma_f64_16x16x4_f64 on every SIMD sustains on the chip
+# (tools/mfma_f64_peak.hip, profiles/r03_mfma_f64_peak.txt: 44-47 TFLOP/s at 2 and 4 waves per
+# SIMD, over 0.4 ms and over 72 ms).  Reported next to the data-sheet figure, never as `peak`.
+MFMA_F64_STREAM_TF = 46.2
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix = FP32 vector rate
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (no sparsity)
 PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
@@ -834,6 +838,12 @@ def main():
                          "frac": mfma_frac,
                          "peak_source": "AMD MI355X data sheet, FP64 matrix; = 2048 flop / 64 clk "
                                         "/ SIMD x 1024 SIMDs x 2.4 GHz",
+                         "measured_stream_peak": MFMA_F64_STREAM_TF,
+                         "frac_of_measured_stream": mfma_achieved / MFMA_F64_STREAM_TF
+                         if args.mode == "mfma" else 0.0,
+                         "measured_stream_source": "profiles/r03_mfma_f64_peak.txt: independent "
+                                                   "v_mfma_f64_16x16x4_f64 on every SIMD sustain "
+                                                   "44-47 TFLOP/s (108-115 cycles per MFMA)",
                          # rocprofv3 --pmc MfmaUtil of the same launches (profiles/), not live
                          "mfma_busy_pmc_pct": mfma_busy},
             # the reference formulation projects one tree level (32 hyperplanes) per read of X:
