@@ -105,7 +105,7 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  * documented tolerances of the MFMA projections).  rpt_ctx_create seeds them ONCE from the
  * environment (RPT_<NAME>, upper case); no entry point reads the environment afterwards.
  *   no_stream, stream_maxnodes, stream_minper, no_wmid, no_midselect, stream_big_node, no_wsub,
- *   no_wsort, no_wpack
+ *   no_wsort, no_wpack, no_codes, no_pcodes
  *       median split: which regime handles which level
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
  *   knn_wave (-1 auto, 0, 1), knn_kp, knn_no_pre32, knn_csr_pre32, knn_general

@@ -223,6 +223,7 @@ const OptDesc kOptions[] = {
     {"no_wsort", &rpt_options::no_wsort},
     {"no_wpack", &rpt_options::no_wpack},
     {"no_codes", &rpt_options::no_codes},
+    {"no_pcodes", &rpt_options::no_pcodes},
     {"proj_narrow", &rpt_options::proj_narrow},
     {"proj_bf16_f32", &rpt_options::proj_bf16_f32},
     {"knn_wave", &rpt_options::knn_wave},

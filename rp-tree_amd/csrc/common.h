@@ -136,6 +136,7 @@ struct rpt_options {
   int64_t no_wsort = 0;         // split: the wave kernel selects by histograms (round 2) instead of sorting
   int64_t no_wpack = 0;         // split: the sorting wave kernel gathers a key per level, no packed images
   int64_t no_codes = 0;         // split: stream on the keys themselves, no 16-bit codes
+  int64_t no_pcodes = 0;        // split: no codes for projection kernels without a code epilogue
   int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only
   int64_t proj_bf16_f32 = 0;    // projection: bf16 rows through the f32-MFMA kernels
   int64_t knn_wave = -1;        // kNN: -1 auto, 0 workgroup-per-query, 1 wave-per-query kernel

@@ -3389,6 +3389,54 @@ __global__ __launch_bounds__(256) void sample_range_kernel(const TIn* __restrict
 
 // start-of-build initialisation in ONE launch: NaN node records (not a Bin), zero counters and
 // flags.  (Each separate fill / memset costs a ~4 us dispatch; a 4-tree shard builds in 1.3 ms.)
+// ---- codes AFTER the projection (round 3), for the projection kernels that have no code epilogue
+// (bf16 rows on the bf16 matrix pipe, CSR rows): the geometry from a strided sample of the
+// streamed P columns themselves, then one coalesced pass P -> 16-bit codes.  The codes are a
+// function of the stored keys, so "code(x) < code(y) => key(x) < key(y)" holds by construction.
+template <class TK>
+__global__ __launch_bounds__(256) void pcode_range_kernel(const TK* __restrict__ P, int64_t N, int L,
+                                                          int Lc, unsigned long long* mm) {
+  const int c = blockIdx.x;
+  if (c % L >= Lc) return;
+  const TK* col = P + (int64_t)c * N;
+  const int64_t m = N < 4096 ? N : 4096;
+  unsigned long long mn = ~0ULL, mx = 0ULL;
+  for (int64_t i = threadIdx.x; i < m; i += 256) {
+    const unsigned long long o = ord_of(col[i * N / m]);
+    mn = o < mn ? o : mn;
+    mx = o > mx ? o : mx;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(mm, mn);
+    atomicMax(mm + 1, mx);
+  }
+}
+
+template <class TK>
+__global__ __launch_bounds__(256) void pcode_kernel(const TK* __restrict__ P, int64_t N, int L, int Lc,
+                                                    const unsigned long long* __restrict__ mm,
+                                                    uint16_t* __restrict__ codes) {
+  const int c = blockIdx.y;
+  if (c % L >= Lc) return;
+  const CodeGeo<TK> g = code_geo<TK>(mm[0], mm[1]);
+  const TK* col = P + (int64_t)c * N;
+  uint16_t* out = codes + (int64_t)c * N;
+  const int64_t n8 = N / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    struct alignas(16) V8 { uint16_t v[8]; } o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = code_of(col[i * 8 + e], g);
+    *reinterpret_cast<V8*>(out + i * 8) = o;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n8 * 8 + threadIdx.x; i < N; i += 256) out[i] = code_of(col[i], g);
+}
+
 __global__ void build_init_kernel(double* thr, double* mglo, double* mghi, int64_t n,
                                   unsigned long long* counters /*[2]*/, unsigned int* sflags /*[4]*/) {
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
@@ -3619,8 +3667,25 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   DevBuf<uint16_t> codes;
   DevBuf<unsigned long long> code_mm;
   uint16_t* Cd = nullptr;  // [T][L][N], the columns of levels < Lc only
-  if (Lc > 0 && Lused == L && N >= ((int64_t)1 << 17) && !ctx->opt.no_codes &&
-      project_writes_codes(ctx, ds, mode)) {
+  const bool codes_wanted = Lc > 0 && Lused == L && N >= ((int64_t)1 << 17) && !ctx->opt.no_codes;
+  if (codes_wanted && !project_writes_codes(ctx, ds, mode) && !ctx->opt.no_pcodes &&
+      (N % 8) == 0) {
+    // no code epilogue in this projection kernel (bf16 rows on the bf16 pipe, CSR rows): project,
+    // then derive the codes from the stored keys in one coalesced pass (pcode_kernel)
+    RPT_TRY(project_columns(ctx, ds, f->R.p, T * L, mode, P));
+    RPT_TRY(code_mm.alloc(2));
+    RPT_TRY(codes.alloc((size_t)T * L * N));
+    ProfScope ps(ctx, RPT_PROF_SPLIT);  // the pass is split work: it exists for the streamed levels
+    hipLaunchKernelGGL(stream_init_kernel, dim3(1), dim3(64), 0, st, code_mm.p, code_mm.p + 1, 1,
+                       (unsigned int*)nullptr, 0);  // (~0, 0)
+    hipLaunchKernelGGL(pcode_range_kernel<TK>, dim3((unsigned)(T * L)), dim3(256), 0, st,
+                       (const TK*)P, N, L, Lc, code_mm.p);
+    const unsigned pb = (unsigned)std::min<int64_t>((N / 8 + 255) / 256, (int64_t)ctx->n_cu * 4);
+    hipLaunchKernelGGL(pcode_kernel<TK>, dim3(pb > 0 ? pb : 1, (unsigned)(T * L)), dim3(256), 0, st,
+                       (const TK*)P, N, L, Lc, (const unsigned long long*)code_mm.p, codes.p);
+    RPT_HIP(hipGetLastError());
+    Cd = codes.p;
+  } else if (codes_wanted && project_writes_codes(ctx, ds, mode)) {
     // geometry: the range of ALL streamed columns over a strided sample of the rows (a few
     // columns are not enough: on clustered data a hyperplane's range depends on how it separates
     // the clusters, and a column that leaves the range clamps half its points into one code),
