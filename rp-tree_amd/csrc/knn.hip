@@ -912,7 +912,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   __shared__ double s_qn;
   __shared__ double s_red_d[8];
   __shared__ int s_red_p[8], s_red_i[8];
-  __shared__ unsigned long long s_red64[8];
+  __shared__ unsigned long long wb_key[4][kFK];  // select_packed: every wave's winners
+  __shared__ int wb_id[4][kFK];
   __shared__ int s_wk[4];
   const int vote = PRE32 ? 0 : (dedup_vote >> 8);
   const int dedup = vote > 0 ? 0 : (dedup_vote & 3);  // kept ids are distinct
@@ -1037,6 +1038,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   // The f32 pass ranks SQUARED f32 distances (exact float values): (value bits << 32 | position)
   // is one 64-bit key whose unsigned order is the (distance, position) order — half the
   // cross-lane traffic per round, and the owner of the winner writes it out itself.
+  // Round 3: the ksel rounds are WAVE-local (shuffles only, no LDS, no barrier): every wave takes
+  // the ksel smallest of its own quarter of the batch, the four lists meet in LDS and the ksel
+  // smallest of those 4 x ksel keys — the batch's ksel smallest are among them — are ranked by
+  // counting.  Two barriers per batch instead of one per round (C2: 17 rounds per 2048 entries).
   auto select_packed = [&](int fill, int ksel) -> int {
     constexpr int E = kFC / 256;
     unsigned long long key[E];
@@ -1046,8 +1051,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       key[e] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | (unsigned int)cpos[i]
                         : ~0ULL;
     }
-    int nb = 0, par = 0;
-    while (nb < ksel) {
+    for (int r = 0; r < ksel; ++r) {
       unsigned long long m = key[0];
 #pragma unroll
       for (int e = 1; e < E; ++e) m = key[e] < m ? key[e] : m;
@@ -1055,24 +1059,41 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
         const unsigned long long t2 = __shfl_xor(m, o);
         m = t2 < m ? t2 : m;
       }
-      if (lane == 0) s_red64[par * 4 + wave] = m;
-      __syncthreads();
-      m = s_red64[par * 4];
-      for (int w = 1; w < 4; ++w) m = s_red64[par * 4 + w] < m ? s_red64[par * 4 + w] : m;
-      par ^= 1;
-      if (m == ~0ULL) break;  // candidates exhausted
+      if (m == ~0ULL) {  // this wave's entries are exhausted (wave-uniform)
+        if (lane == 0)
+          for (int r2 = r; r2 < ksel; ++r2) wb_key[wave][r2] = ~0ULL;
+        break;
+      }
 #pragma unroll
       for (int e = 0; e < E; ++e)
         if (key[e] == m) {  // keys are unique (positions are): exactly one owner
           key[e] = ~0ULL;
-          bdist[nb] = (double)__uint_as_float((unsigned int)(m >> 32));
-          bid[nb] = cid[tid + 256 * e];
-          bpos[nb] = (int)(unsigned int)m;
+          wb_key[wave][r] = m;
+          wb_id[wave][r] = cid[tid + 256 * e];
         }
-      ++nb;
     }
     __syncthreads();
-    return nb;
+    const int tot = 4 * ksel;  // <= 4 * kFK = 256 threads
+    unsigned long long mine = ~0ULL;
+    int mid = -1;
+    if (tid < tot) {
+      mine = wb_key[tid / ksel][tid % ksel];
+      mid = wb_id[tid / ksel][tid % ksel];
+    }
+    int rank = 0x7fffffff;
+    if (tid < tot && mine != ~0ULL) {
+      rank = 0;
+      for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < ksel; ++r) rank += wb_key[w][r] < mine;
+    }
+    if (rank < ksel) {
+      bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
+      bid[rank] = mid;
+      bpos[rank] = (int)(unsigned int)mine;
+    }
+    // entries in all = the valid keys of the four lists, at most ksel are kept
+    const int nvalid = __syncthreads_count(tid < tot && mine != ~0ULL);
+    return nvalid < ksel ? nvalid : ksel;
   };
   auto select = [&](int fill, int ksel, int dedup) -> int {
     constexpr int E = kFC / 256;
