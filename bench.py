@@ -587,6 +587,8 @@ def main():
     _lib.check(L_.rpt_knn_last_candidates(ctx._h, C.byref(cand_total)))
     uncertified = C.c_int64()
     _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(uncertified)))
+    knn_tier = C.c_int32()         # 0 all-f64, 1 f32 shadow, 2 IEEE-half shadow (timed batches)
+    _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(knn_tier)))
 
     # ---- recall (untimed) ----
     nq_eval = min(nq, 500)
@@ -858,20 +860,24 @@ def main():
         })
         # second roofline object: the query kernel against the bytes it really gathers
         cand_q = cand_total.value / float(max(nq, 1))
-        pre32 = (not ctx.get_option("knn_no_pre32")) and k + max(6, k // 2) + 1 <= 64
-        kp = k + max(6, k // 2)
+        tier = knn_tier.value
+        pre32 = tier > 0
+        sb = 2 if tier == 2 else 4                      # bytes per element of the ranking shadow
+        kp = k + max(8, k // 2) if tier == 2 else k + max(6, k // 2)
         topk_ms = prof["knn_topk"][0] / max(prof["knn_topk"][1], 1)
-        knn_bytes = nq * (cand_q * d * 4 + kp * d * 8) if pre32 else nq * cand_q * d * 8
+        knn_bytes = nq * (cand_q * d * sb + kp * d * 8) if pre32 else nq * cand_q * d * 8
+        if tier == 2:
+            knn_traffic = None                          # the committed PMC passes are the f32 tier's
         knn_ach = knn_bytes / (topk_ms * 1e-3) / 1e9 if topk_ms > 0 else 0.0
         roof_knn = {"bound": "hbm", "achieved": knn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": knn_ach / HBM_PEAK_GBS, "traffic": knn_traffic,
                     "traffic_source": traffic_source if knn_traffic else None,
-                    "kernel": "knn_fused (f32-shadow ranking + exact f64 distances of the best k')"
-                    if pre32 else "knn_fused (all-f64 distances)",
+                    "kernel": "knn_fused (%s-shadow ranking + exact f64 distances of the best k')"
+                    % ("half" if tier == 2 else "f32") if pre32 else "knn_fused (all-f64 distances)",
                     "avg_launch_ms": topk_ms,
                     "algorithmic_bytes_per_launch": knn_bytes,
-                    "bytes_formula": "nq x (candidates x d x 4 B shadow rows + k' x d x 8 B exact "
-                                     "rows), k' = k + max(6, k/2)" if pre32 else
+                    "bytes_formula": "nq x (candidates x d x %d B shadow rows + k' x d x 8 B exact "
+                                     "rows), k' = %d" % (sb, kp) if pre32 else
                                      "nq x candidates x d x 8 B (SURVEY 8d)",
                     "candidates_per_query": cand_q}
         out = {
@@ -908,10 +914,11 @@ def main():
                     "topk_kernel_ms": topk_ms,
                     "plan_ms": prof["knn_plan"][0] / max(prof["knn_plan"][1], 1),
                     "prefilter_uncertified_queries": uncertified.value,
+                    "ranking_tier": tier,
                     "method": "all-f64 distances" if not pre32 else
-                    "candidates ranked on an f32 shadow of X, exact f64 distances for the best "
-                    "k+6, cut certified per query (exact fallback); results identical to the "
-                    "all-f64 kernel",
+                    "candidates ranked on %s of X, exact left-fold f64 distances for the best %d, "
+                    "cut certified per query (exact fallback); results identical to the all-f64 "
+                    "kernel" % ("an IEEE-half shadow" if tier == 2 else "an f32 shadow", kp),
                     "exchange": None if world == 1 else
                     "one ncclAllGather of %d B records per rank on the ctx streams "
                     "(rpt_knn_sharded_dev), merge on every device" % sharded.record_layout(nq, k)[0],

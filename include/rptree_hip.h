@@ -108,7 +108,7 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  *   no_wsort, no_wpack, no_codes, no_pcodes
  *       median split: which regime handles which level
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
- *   knn_wave (-1 auto, 0, 1), knn_kp, knn_no_pre32, knn_csr_pre32, knn_general
+ *   knn_wave (-1 auto, 0, 1), knn_kp, knn_kp16, knn_no_pre32, knn_no_pre16, knn_csr_pre32, knn_general
  *       query kernels
  *   comm_force_exchange            sharded kNN on a ONE-rank communicator still runs record ->
  *                                  ncclAllGather -> merge (set on the communicator's first ctx)
@@ -264,8 +264,10 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
  * number of valid entries (< k when fewer candidates).  Unused slots: id -1, dist +inf. */
 /* Memory note: the first rpt_knn_* call with duplicates kept (flags 0) and k <= 42 on a dense
  * f64 dataset builds an f32 copy of it on the device (+50 % of the dataset's size, freed with the
- * dataset): candidates are ranked on it, exact f64 distances are computed for the best k + max(6, k/2),
- * and a per-query error bound certifies the cut (uncertifiable queries take the all-f64 path).
+ * dataset), and an IEEE-half copy (+25 %) when its elements fit the half range: candidates are
+ * ranked on the half copy (k + max(8, k/2) kept) or the f32 copy (k + max(6, k/2) kept), exact f64
+ * distances are computed for the kept ones, and a per-query error bound certifies the cut
+ * (uncertifiable queries take the all-f64 path).
  * Results are identical either way.  A dataset borrowed with rpt_dataset_dense_dev must not be
  * modified while the library holds it. */
 int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
@@ -279,6 +281,11 @@ int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total);
 /* ... and how many of its queries the f32 prefilter could not certify (equal distances at its
  * cut) and were answered again with all-f64 distances; 0 when the prefilter was not used */
 int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total);
+/* ... and the shadow its candidates were ranked on: 0 = none (all-f64 distances), 1 = the f32 copy
+ * of the dataset, 2 = its IEEE-half copy (round 3: a quarter of the f64 bytes; keeps k + max(8, k / 2)
+ * entries for the exact pass, same certificate with the half rounding in the error bound; a forest
+ * on which more than a quarter of a batch cannot be certified drops one tier for later batches) */
+int32_t rpt_knn_last_tier(rpt_ctx* ctx, int32_t* tier);
 
 /* multi-GPU merge: G per-shard results (shard g holds trees [g*T/G, (g+1)*T/G)), gathered
  * shard-major as ids_dev[G][nq][k] etc. (e.g. by an RCCL all-gather), merged into the

@@ -229,6 +229,8 @@ const OptDesc kOptions[] = {
     {"knn_wave", &rpt_options::knn_wave},
     {"knn_kp", &rpt_options::knn_kp},
     {"knn_no_pre32", &rpt_options::knn_no_pre32},
+    {"knn_no_pre16", &rpt_options::knn_no_pre16},
+    {"knn_kp16", &rpt_options::knn_kp16},
     {"knn_csr_pre32", &rpt_options::knn_csr_pre32},
     {"knn_general", &rpt_options::knn_general},
     {"comm_force_exchange", &rpt_options::comm_force_exchange},
@@ -613,6 +615,7 @@ int32_t rpt_dataset_free(rpt_dataset* ds) {
     if (ds) dev_set_stream(ds->ctx->stream);
     if (!ds) return RPT_OK;
     if (ds->shadow32) dev_free(ds->shadow32);
+    if (ds->shadow16) dev_free(ds->shadow16);
     if (ds->shadow_col16) dev_free(ds->shadow_col16);
     if (ds->csr_split) dev_free(ds->csr_split);
     if (ds->owns) {
@@ -1036,6 +1039,14 @@ int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total) {
   return guarded([&]() -> int32_t {
     RPT_ARG(ctx && total, "NULL argument");
     *total = ctx->last_uncertified;
+    return RPT_OK;
+  });
+}
+
+int32_t rpt_knn_last_tier(rpt_ctx* ctx, int32_t* tier) {
+  return guarded([&]() -> int32_t {
+    RPT_ARG(ctx && tier, "NULL argument");
+    *tier = ctx->last_tier;
     return RPT_OK;
   });
 }

@@ -142,6 +142,8 @@ struct rpt_options {
   int64_t knn_wave = -1;        // kNN: -1 auto, 0 workgroup-per-query, 1 wave-per-query kernel
   int64_t knn_kp = 0;           // kNN: entries the f32 prefilter keeps (0 = k + max(6, k/2))
   int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
+  int64_t knn_no_pre16 = 0;     // kNN: the prefilter ranks on the f32 shadow, never on the f16 one
+  int64_t knn_kp16 = 0;         // kNN: entries the f16 prefilter keeps (0 = k + max(8, k / 2))
   int64_t knn_csr_pre32 = 0;    // kNN: rank CSR f64 rows on their (u16 column, f32 value) shadow
   int64_t knn_general = 0;      // kNN: unfused general path
   int64_t comm_force_exchange = 0;  // sharded kNN: a one-rank communicator runs record -> all-gather -> merge too
@@ -160,6 +162,7 @@ struct rpt_ctx {
   size_t pin_cap = 0, pin_off = 0;
   int64_t last_uncertified = 0;  // queries of the last kNN call re-run with all-f64 distances
   int64_t last_candidates = 0;
+  int32_t last_tier = 0;  // ranking tier of the last fused kNN call: 0 exact, 1 f32 shadow, 2 half
   int32_t n_cu = 256;
   bool prof = false;
   std::vector<rpt_prof_span> spans;
@@ -206,6 +209,10 @@ struct rpt_dataset {
   // lazily built by the first kNN call on dense f64 data: f32 copy of X (the fused kernel ranks
   // candidates on it before it computes exact distances of the survivors) and the largest row norm
   mutable float* shadow32 = nullptr;        // dense: X as f32; CSR: val as f32
+  // round 3: X as IEEE half (dense f64 data whose elements fit its range): the first-tier ranking
+  // shadow, a quarter of the f64 bytes; shadow16_state: 0 = not tried, 1 = there, -1 = unusable
+  mutable uint16_t* shadow16 = nullptr;
+  mutable int shadow16_state = 0;
   mutable uint16_t* shadow_col16 = nullptr;  // CSR (d <= 65536): col as u16
   mutable int64_t max_rowlen = 0;            // CSR: the longest row
   mutable double max_norm = -1.0;
@@ -225,6 +232,7 @@ struct rpt_forest {
   // equal distances: e.g. the queries are data points, found once per tree): later batches on this
   // forest go straight to the all-f64 kernel
   bool prefilter_off = false;
+  bool pre16_off = false;  // ... the same one tier up: the f16 shadow failed too many cuts here
   int64_t nodes = 0;         // 2^L - 1
   rpt::DevBuf<int32_t> perm;  // [T][N] final leaf-ordered permutation
   rpt::DevBuf<double> thr, mglo, mghi;  // [T][nodes]

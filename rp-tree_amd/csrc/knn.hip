@@ -887,9 +887,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
     unsigned int* ovf_count, unsigned long long* cand_total,
-    const float* __restrict__ Xf /* PRE32: f32 shadow of X */, double xmax /* max row norm */,
-    int k1 /* PRE32: entries kept by the f32 pass, the last one = the first excluded */,
-    CsrPtrs csr /* CSR: X / Q are null, rows and queries are SVectors */) {
+    const void* __restrict__ Xf /* PRE32: f32 (or, sh16, IEEE half) shadow of X */,
+    double xmax /* max row norm */,
+    int k1 /* PRE32: entries kept by the shadow pass, the last one = the first excluded */,
+    CsrPtrs csr /* CSR: X / Q are null, rows and queries are SVectors */, int sh16 = 0) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* cdist = reinterpret_cast<double*>(smem);                 // [kFC]
@@ -1231,9 +1232,14 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     else if constexpr (CSR)
       batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), csr.nnz, cid,
                               cdist, qsd, s_qn, first_new, fill, wave, lane);
-    else if constexpr (PRE32)
-      batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, wave, 4, lane);
-    else if (pack32)
+    else if constexpr (PRE32) {
+      if (sh16)  // half rows: a quarter of the f64 bytes (the query stays f32)
+        batch_distances<_Float16, float, 16, false>(static_cast<const _Float16*>(Xf), d, cid, cdist, qs32,
+                                                    first_new, fill, wave, 4, lane);
+      else
+        batch_distances<float, float, 16, false>(static_cast<const float*>(Xf), d, cid, cdist, qs32,
+                                                 first_new, fill, wave, 4, lane);
+    } else if (pack32)
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8), false>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
@@ -1325,7 +1331,11 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       const double u = 5.9604644775390625e-08;
       // + sqrt(d) * 4e-23: products in the f32 subnormal range lose relative accuracy
       // (absolute error 2^-150 each; |sqrt a - sqrt b| <= sqrt |a - b|)
-      const double err = 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
+      // half shadow: |x~ - x| <= 2^-11 |x| + sqrt(d) 2^-25 (subnormal halves), the query and the
+      // arithmetic stay f32
+      const double err = sh16 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * s_qn + (double)(d + 2) * u * F +
+                                    sqrt((double)d) * 3.1e-8
+                              : 2.1 * u * (xmax + s_qn) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
       // (norms whose squares leave the f32 range — inf - inf = NaN entries are never ranked —
       // fail the test through s_qn; the dataset side is checked when the shadow is built)
       // F must be finite: an overflowed f32 sum (inf) orders nothing among the dropped
@@ -1394,8 +1404,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     int L, int min_leaf, int64_t N, int k, int dedup, int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
     unsigned int* ovf_count, unsigned long long* cand_total,
-    const float* __restrict__ Xf, double xmax, int k1 /* PRE32: see knn_fused_kernel */,
-    unsigned long long* dbg /* debug_stamps: phase clocks of one wave */) {
+    const void* __restrict__ Xf, double xmax, int k1 /* PRE32: see knn_fused_kernel */,
+    unsigned long long* dbg /* debug_stamps: phase clocks of one wave */, int sh16 = 0) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1599,9 +1609,14 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     pos_base = pb;
     wave_sync();
     KSTAMP();  // batch filled
-    if constexpr (PRE32)
-      batch_distances<float, float, 16, false>(Xf, d, cid, cdist, qs32, first_new, fill, 0, 1, lane);
-    else if (pack32)
+    if constexpr (PRE32) {
+      if (sh16)
+        batch_distances<_Float16, float, 16, false>(static_cast<const _Float16*>(Xf), d, cid, cdist, qs32,
+                                                    first_new, fill, 0, 1, lane);
+      else
+        batch_distances<float, float, 16, false>(static_cast<const float*>(Xf), d, cid, cdist, qs32,
+                                                 first_new, fill, 0, 1, lane);
+    } else if (pack32)
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8), false>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, 0, 1, lane);
@@ -1651,7 +1666,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     KSTAMP();  // final selection
     if (cut && best > 0) {
       const double u = 5.9604644775390625e-08;
-      const double err = 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
+      const double err = sh16 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * sqrt(qn) + (double)(d + 2) * u * F +
+                                    sqrt((double)d) * 3.1e-8
+                              : 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
       if (!(sqrt(qn) < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
         if (lane == 0) {
           ovf_flags[q] = 2u;
@@ -2105,6 +2122,62 @@ static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
   return RPT_OK;
 }
 
+// IEEE-half shadow of a dense f64 dataset (one wave per row) + the largest |element| (bits in
+// max_bits[0]); built after the f32 shadow, whose row norm it shares
+__global__ __launch_bounds__(256) void shadow16_kernel(const double* __restrict__ X, int64_t n, int d,
+                                                       _Float16* __restrict__ Xh,
+                                                       unsigned long long* __restrict__ max_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  double mx = 0.0;
+  for (int64_t r = row0; r < n; r += (int64_t)gridDim.x * 4)
+    for (int j = lane; j < d; j += 64) {
+      const double v = X[r * d + j];
+      Xh[r * d + j] = (_Float16)(float)v;
+      const double a = fabs(v);
+      if (!(a <= mx)) mx = a == a ? a : __longlong_as_double(0x7ff0000000000000LL);
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(mx, o);
+    mx = t > mx ? t : mx;
+  }
+  if (lane == 0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+// The half shadow, once per dataset: allowed to fail like the f32 one (no memory, elements outside
+// the half range): the f32 tier then ranks.
+static int32_t ensure_shadow16(rpt_ctx* ctx, const rpt_dataset* data) {
+  if (data->shadow16_state != 0) return RPT_OK;
+  data->shadow16_state = -1;
+  void* p = nullptr;
+  DevBuf<unsigned long long> mb;
+  unsigned long long bits = 0;
+  auto give_up = [&]() {
+    if (p) dev_free(p);
+    (void)hipGetLastError();
+    return RPT_OK;
+  };
+  if (dev_alloc(&p, (size_t)data->n * data->d * 2 + 16) != hipSuccess) {
+    p = nullptr;
+    return give_up();
+  }
+  if (mb.alloc(1) != RPT_OK) return give_up();
+  if (hipMemsetAsync(mb.p, 0, 8, ctx->stream) != hipSuccess) return give_up();
+  int64_t blocks = (data->n + 3) / 4;
+  if (blocks > (int64_t)ctx->n_cu * 16) blocks = (int64_t)ctx->n_cu * 16;
+  hipLaunchKernelGGL(shadow16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                     (const double*)data->X, data->n, data->d, (_Float16*)p, mb.p);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (hipMemcpyAsync(&bits, mb.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
+  double mabs;
+  std::memcpy(&mabs, &bits, 8);
+  if (!(mabs < 6.0e4)) return give_up();  // beyond the half range (or NaN / inf)
+  data->shadow16 = (uint16_t*)p;
+  data->shadow16_state = 1;
+  return RPT_OK;
+}
+
 // (u16 column, f32 value) shadow of a CSR f64 dataset, its largest squared row norm and longest row
 __global__ __launch_bounds__(256) void shadow_csr_kernel(const int64_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col,
@@ -2178,7 +2251,8 @@ template <class TD, class TK>
 static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                             const rpt_dataset* q, const void* Pq, int32_t k, int dedup,
                             int32_t* ids, double* dist, int32_t* cnt, unsigned int* ovf,
-                            unsigned long long* cand_total, bool rerun = false) {
+                            unsigned long long* cand_total, bool rerun = false,
+                            int* tier = nullptr /* out: 0 exact, 1 f32 shadow, 2 half shadow */) {
   typedef typename AccOf<TD>::type TA;
   // small shards (few trees => a few hundred candidates per query): one wave per query
   const int64_t force = ctx->opt.knn_wave;  // -1 auto
@@ -2213,10 +2287,20 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // entries the f32 pass keeps: every one costs a selection round per batch (16 of them: 0.75 ms
   // per 10 000 queries at C2), too few and cuts fail their certificate (re-run per query): k + 6
   // certifies 10 000 of 10 000 C2 queries
-  const int kp = kp_env > k && kp_env < kFK ? kp_env : prefilter_keep(k);
+  int kp = kp_env > k && kp_env < kFK ? kp_env : prefilter_keep(k);
   const bool pre32 = std::is_same<TD, double>::value && dedup == 0 && kp + 1 <= kFK &&
                      !ctx->opt.knn_no_pre32 && data->shadow32 && !rerun && !f->prefilter_off &&
                      (!data->csr || data->shadow_col16);
+  // first tier: rank on the HALF shadow (a quarter of the f64 bytes); its rounding is coarser, so it
+  // keeps a few more entries for the exact pass: k + max(8, k / 2) (C2: 10 000 of 10 000 queries
+  // certified with 18 kept, 2.55 ms per batch against 4.10 ms on the f32 shadow; 26 kept 2.70 ms)
+  const int kp16_env = (int)ctx->opt.knn_kp16;
+  const int kp16 = kp16_env > k && kp16_env < kFK ? kp16_env : k + (k / 2 > 8 ? k / 2 : 8);
+  const bool sh16 = pre32 && !data->csr && data->shadow16 && !ctx->opt.knn_no_pre16 && !f->pre16_off &&
+                    kp16 + 1 <= kFK;
+  if (sh16) kp = kp16;
+  if (tier) *tier = sh16 ? 2 : pre32 ? 1 : 0;
+  const void* shadow = sh16 ? (const void*)data->shadow16 : (const void*)data->shadow32;
   if (wave) {
     dbgprint.p = dbg;
     const size_t smem = 4 * wbytes;
@@ -2229,8 +2313,8 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                            dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
                            (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                            (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
-                           cnt, ovf + 1, ovf, cand_total, (const float*)data->shadow32,
-                           data->max_norm, kp + 1, dbg);
+                           cnt, ovf + 1, ovf, cand_total, shadow, data->max_norm, kp + 1, dbg,
+                           sh16 ? 1 : 0);
         RPT_HIP(hipGetLastError());
         return RPT_OK;
       }
@@ -2242,7 +2326,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                        dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
                        (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                        (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
-                       cnt, ovf + 1, ovf, cand_total, (const float*)nullptr, 0.0, rerun ? -1 : 0, dbg);
+                       cnt, ovf + 1, ovf, cand_total, (const void*)nullptr, 0.0, rerun ? -1 : 0, dbg);
     RPT_HIP(hipGetLastError());
     return RPT_OK;
   }
@@ -2260,7 +2344,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                          smem, ctx->stream, (const TD*)nullptr, data->d, (const TD*)nullptr,
                          f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n,
                          f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf,
-                         cand_total, (const float*)nullptr, data->max_norm, kp + 1, cp);
+                         cand_total, (const void*)nullptr, data->max_norm, kp + 1, cp);
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -2272,7 +2356,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                          ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                          f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                          f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                         (const float*)data->shadow32, data->max_norm, kp + 1, CsrPtrs{});
+                         shadow, data->max_norm, kp + 1, CsrPtrs{}, sh16 ? 1 : 0);
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -2288,7 +2372,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                          smem, ctx->stream, (const TD*)nullptr, data->d, (const TD*)nullptr,
                          f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n,
                          f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf,
-                         cand_total, (const float*)nullptr, 0.0, rerun ? -1 : 0, cp);
+                         cand_total, (const void*)nullptr, 0.0, rerun ? -1 : 0, cp);
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -2300,7 +2384,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                      ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                      f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                      f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                     (const float*)nullptr, 0.0, rerun ? -1 : 0, CsrPtrs{});
+                     (const void*)nullptr, 0.0, rerun ? -1 : 0, CsrPtrs{});
   RPT_HIP(hipGetLastError());
   return RPT_OK;
 }
@@ -2383,7 +2467,10 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   }
   if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !ctx->opt.knn_no_pre32 &&
       !f->prefilter_off) {  // (dedup carries the vote threshold too: no prefilter when voting)
-    if (!data->csr) RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
+    if (!data->csr) {
+      RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
+      if (data->shadow32 && !ctx->opt.knn_no_pre16 && !f->pre16_off) RPT_TRY(ensure_shadow16(ctx, data));
+    }
     // CSR rows: the (u16, f32) shadow halves the bytes of the ranking pass but NOT its time — at C3
     // the exact kernel already gathers rows at 6.4 TB/s and the f32 pass, with its 17 selection
     // rounds per batch, is bound by its serial phases (14.3 ms against 13.8 ms per 10 000 queries):
@@ -2391,10 +2478,11 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     else if (ctx->opt.knn_csr_pre32 && data->dtype == RPT_F64 && data->d <= 65536)
       RPT_TRY(ensure_shadow_csr(ctx, data));
   }
+  int tier = 0;
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
       return launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                          count_dev, ovf_p, ctot_p, rerun);
+                                          count_dev, ovf_p, ctot_p, rerun, rerun ? nullptr : &tier);
     if (data->dtype == RPT_F32)
       return launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
                                         count_dev, ovf_p, ctot_p, rerun);
@@ -2415,7 +2503,13 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
                 "RPT_KNN_VOTE: a query reaches more than 16384 candidates or 512 leaves");
   if (novf)  // some query reached more leaf ranges than the LDS slab holds: general path
     return knn_general(ctx, f, data, q, k, flags, ids_dev, dist_dev, count_dev);
-  if (tot[1] * 4 > (unsigned long long)nq) f->prefilter_off = true;  // not worth it on this forest
+  // too many uncertified cuts: one tier down for the later batches on this forest (half -> f32
+  // shadow -> all-f64)
+  if (tot[1] * 4 > (unsigned long long)nq) {
+    if (tier == 2) f->pre16_off = true;
+    else f->prefilter_off = true;
+  }
+  ctx->last_tier = tier;
   if (tot[1]) {  // queries with equal distances at the prefilter's cut: the all-f64 kernel, them only
     RPT_TRY(launch(true));
     RPT_HIP(stream_sync(ctx->stream));  // Pq / ovf are released on return

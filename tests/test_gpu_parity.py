@@ -569,6 +569,10 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, option, kind, k):
         ref = rp.knnBatch(k, f, Q)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+    with option("knn_no_pre16", 1):          # the f32 shadow alone (the default ranks on the half one)
+        g32 = rp.knnBatch(k, f, Q)
+    for a, b in zip(g32, ref):
+        assert np.array_equal(a, b)
     fo = oracle.forest_build_dense(X, R, ml)
     ids, dist, cnt = got
     for i in range(0, len(Q), 4):
@@ -577,7 +581,7 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, option, kind, k):
         assert np.allclose(dist[i, :cnt[i]], wd, rtol=1e-12, atol=1e-15)
 
 
-@pytest.mark.parametrize("path", ["default", "no_pre32", "wave", "general"])
+@pytest.mark.parametrize("path", ["default", "pre32", "no_pre32", "wave", "general"])
 def test_knn_cut_between_two_candidates_an_ulp_apart(rp, ctx, oracle, option, path):
     """RPTree.hs:174 ranks ALL candidates on metricDDL2's left fold.  The batched distance passes
     reduce a row by a lane butterfly — the same value to an ulp, not the same bits — so the device
@@ -601,7 +605,8 @@ def test_knn_cut_between_two_candidates_an_ulp_apart(rp, ctx, oracle, option, pa
     differ = int((lf[0::2] != lf[1::2]).sum())
     swapped = int((lf[1::2] < lf[0::2]).sum())
     assert differ >= 5 and swapped >= 2, (differ, swapped)   # the data really exercises the cut
-    opts = {"default": {}, "no_pre32": {"knn_no_pre32": 1}, "wave": {"knn_no_pre32": 1, "knn_wave": 1},
+    opts = {"default": {}, "pre32": {"knn_no_pre16": 1}, "no_pre32": {"knn_no_pre32": 1},
+            "wave": {"knn_no_pre32": 1, "knn_wave": 1},
             "general": {"knn_general": 1}}[path]
     import contextlib
     with contextlib.ExitStack() as st:
@@ -649,28 +654,32 @@ def test_knn_f32_prefilter_uncertified_queries_rerun(rp, ctx, oracle):
 
 def test_knn_f32_prefilter_switches_itself_off_on_self_queries(rp, ctx, oracle):
     """Queries that ARE data points are found once per tree with equal distances; when more than a
-    quarter of a batch cannot be certified the forest stops using the prefilter (the next batch
-    reports 0 uncertified because it never tries), and the answers stay the oracle's."""
+    quarter of a batch cannot be certified the forest drops one ranking tier for the later batches
+    (half shadow -> f32 shadow -> none: the third batch reports 0 uncertified because it never
+    tries), and the answers stay the oracle's."""
     import ctypes as C
     from rptree_amd import _lib
-    n, d, T, ml, k = 8000, 8, 12, 100, 4
+    n, d, T, ml, k = 8000, 8, 24, 100, 4      # 24 copies of the query's own point: more than either tier keeps
     X = oracle.data_normal_dense2(17, n, d)
     Q = X[:24].copy()
     L, _, pnz = oracle.tree_cfg(ml, n, d)
     R, _ = oracle.forest_hyperplanes(6, T, L, pnz, d)
     f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
     fo = oracle.forest_build_dense(X, R, ml)
-    seen = []
-    for rnd in range(2):
+    seen, tiers = [], []
+    for rnd in range(3):
         ids, dist, cnt = rp.knnBatch(k, f, Q)
-        unc = C.c_int64(-1)
+        unc, tier = C.c_int64(-1), C.c_int32(-1)
         _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
         seen.append(unc.value)
+        tiers.append(tier.value)
         for i in range(len(Q)):
             wi, wd = oracle.knn_dense(fo, X, Q[i], k)
             assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
             assert np.array_equal(dist[i, :cnt[i]], wd)
-    assert seen[0] > len(Q) // 4 and seen[1] == 0
+    assert tiers == [2, 1, 0], tiers
+    assert seen[0] > len(Q) // 4 and seen[1] > len(Q) // 4 and seen[2] == 0
 
 
 def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle):
