@@ -278,6 +278,11 @@ def other_configs(which, steps, with_cpu):
                                                         min_leaf, k, steps)
             w_ms, w_n = pb["project_wide"]
             cols = T * maxd / max(w_n / steps, 1)
+            tier, unc = C.c_int32(), C.c_int64()
+            _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
+            _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+            kp = k + max(8, k // 2)
+            row_b = d * 2 + min(1.0, kp / max(cand, 1.0)) * d * 4 if tier.value == 2 else d * 4
             res = {"workload": "C4 shard: %d x %d f32 two-Gaussian mixture, %d of %d trees (one of %d GPUs), "
                                "minLeaf %d, maxDepth %d, pnz %.4f, k=%d, %d queries" %
                                (n, d, T, Tall, G, min_leaf, maxd, pnz, k, nq),
@@ -291,9 +296,14 @@ def other_configs(which, steps, with_cpu):
                                      w_ms / max(w_n, 1), int(w_n / steps),
                                      n * d * 4 + d * cols * 8 + n * cols * 4, 2.0 * n * d * cols,
                                      MFMA_F32_PEAK_TF, "SURVEY 8d formula at the hyperplanes one launch covers"),
-                   "roofline_knn": _roof("knn_fused_wave<float> (one wave per query)",
+                   "knn_ranking_tier": tier.value, "knn_uncertified": unc.value,
+                   "roofline_knn": _roof("knn_fused_wave<float> (one wave per query%s)" %
+                                         (", candidates ranked on the IEEE-half shadow, f32 distances for "
+                                          "the best %d" % kp if tier.value == 2 else ""),
                                          pq["knn_topk"][0] / max(pq["knn_topk"][1], 1), pq["knn_topk"][1],
-                                         nq * cand * d * 4, 0.0, 0.0, "nq x candidates x d x 4 B")}
+                                         nq * cand * row_b, 0.0, 0.0,
+                                         "nq x (candidates x d x 2 B + %d x d x 4 B)" % kp
+                                         if tier.value == 2 else "nq x candidates x d x 4 B")}
             if with_cpu:
                 from oracle import oracle as orc
                 Xh = Xd.cpu().numpy()

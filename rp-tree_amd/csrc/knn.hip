@@ -1339,7 +1339,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       // (norms whose squares leave the f32 range — inf - inf = NaN entries are never ranked —
       // fail the test through s_qn; the dataset side is checked when the shadow is built)
       // F must be finite: an overflowed f32 sum (inf) orders nothing among the dropped
-      if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
+      // f32 DATA ranked on their half shadow: what the cut is compared with is the f32 distance the
+      // all-f32 kernel ranks on, itself within (d + 2) u dist of the exact one
+      const double err2 = std::is_same<TD, double>::value ? err : err + (double)(d + 2) * u * (F + err) * 1.01;
+      if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err2 > bdist[best - 1])) {
         if (tid == 0) {  // flag 2: the host re-runs this query with the all-f64 kernel
           ovf_flags[q] = 2u;
           atomicAdd(cand_total + 1, 1ULL);
@@ -1669,7 +1672,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
       const double err = sh16 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * sqrt(qn) + (double)(d + 2) * u * F +
                                     sqrt((double)d) * 3.1e-8
                               : 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
-      if (!(sqrt(qn) < 1e18) || !(F < 1e30) || !(F - err > bdist[best - 1])) {
+      const double err2 = std::is_same<TD, double>::value ? err : err + (double)(d + 2) * u * (F + err) * 1.01;
+      if (!(sqrt(qn) < 1e18) || !(F < 1e30) || !(F - err2 > bdist[best - 1])) {
         if (lane == 0) {
           ovf_flags[q] = 2u;
           atomicAdd(cand_total + 1, 1ULL);
@@ -2124,24 +2128,33 @@ static int32_t ensure_shadow(rpt_ctx* ctx, const rpt_dataset* data) {
 
 // IEEE-half shadow of a dense f64 dataset (one wave per row) + the largest |element| (bits in
 // max_bits[0]); built after the f32 shadow, whose row norm it shares
-__global__ __launch_bounds__(256) void shadow16_kernel(const double* __restrict__ X, int64_t n, int d,
+template <class TIn>
+__global__ __launch_bounds__(256) void shadow16_kernel(const TIn* __restrict__ X, int64_t n, int d,
                                                        _Float16* __restrict__ Xh,
                                                        unsigned long long* __restrict__ max_bits) {
   const int lane = threadIdx.x & 63;
   const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  double mx = 0.0;
-  for (int64_t r = row0; r < n; r += (int64_t)gridDim.x * 4)
+  double mx = 0.0, mn2 = 0.0;  // largest |element|, largest squared row norm
+  for (int64_t r = row0; r < n; r += (int64_t)gridDim.x * 4) {
+    double s2 = 0.0;
     for (int j = lane; j < d; j += 64) {
-      const double v = X[r * d + j];
+      const double v = (double)X[r * d + j];
       Xh[r * d + j] = (_Float16)(float)v;
       const double a = fabs(v);
       if (!(a <= mx)) mx = a == a ? a : __longlong_as_double(0x7ff0000000000000LL);
+      s2 += v * v;
     }
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    if (!(s2 <= mn2)) mn2 = s2 == s2 ? s2 : __longlong_as_double(0x7ff0000000000000LL);
+  }
   for (int o = 32; o > 0; o >>= 1) {
     const double t = __shfl_xor(mx, o);
     mx = t > mx ? t : mx;
   }
-  if (lane == 0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));
+  if (lane == 0) {
+    atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));
+    atomicMax(max_bits + 1, (unsigned long long)__double_as_longlong(mn2));
+  }
 }
 
 // The half shadow, once per dataset: allowed to fail like the f32 one (no memory, elements outside
@@ -2151,28 +2164,39 @@ static int32_t ensure_shadow16(rpt_ctx* ctx, const rpt_dataset* data) {
   data->shadow16_state = -1;
   void* p = nullptr;
   DevBuf<unsigned long long> mb;
-  unsigned long long bits = 0;
+  unsigned long long bits[2] = {0, 0};
   auto give_up = [&]() {
     if (p) dev_free(p);
     (void)hipGetLastError();
     return RPT_OK;
   };
+  if (data->dtype == RPT_BF16 || data->csr) return RPT_OK;
   if (dev_alloc(&p, (size_t)data->n * data->d * 2 + 16) != hipSuccess) {
     p = nullptr;
     return give_up();
   }
-  if (mb.alloc(1) != RPT_OK) return give_up();
-  if (hipMemsetAsync(mb.p, 0, 8, ctx->stream) != hipSuccess) return give_up();
+  if (mb.alloc(2) != RPT_OK) return give_up();
+  if (hipMemsetAsync(mb.p, 0, 16, ctx->stream) != hipSuccess) return give_up();
   int64_t blocks = (data->n + 3) / 4;
   if (blocks > (int64_t)ctx->n_cu * 16) blocks = (int64_t)ctx->n_cu * 16;
-  hipLaunchKernelGGL(shadow16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                     (const double*)data->X, data->n, data->d, (_Float16*)p, mb.p);
+  if (data->dtype == RPT_F64)
+    hipLaunchKernelGGL(shadow16_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const double*)data->X, data->n, data->d, (_Float16*)p, mb.p);
+  else
+    hipLaunchKernelGGL(shadow16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const float*)data->X, data->n, data->d, (_Float16*)p, mb.p);
   if (hipGetLastError() != hipSuccess) return give_up();
-  if (hipMemcpyAsync(&bits, mb.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return give_up();
+  if (hipMemcpyAsync(bits, mb.p, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return give_up();
   if (stream_sync(ctx->stream) != hipSuccess) return give_up();
-  double mabs;
-  std::memcpy(&mabs, &bits, 8);
+  double mabs, mn2;
+  std::memcpy(&mabs, &bits[0], 8);
+  std::memcpy(&mn2, &bits[1], 8);
   if (!(mabs < 6.0e4)) return give_up();  // beyond the half range (or NaN / inf)
+  if (data->max_norm < 0.0) {             // f32 data: no f32 shadow pass has measured the norms
+    if (data->max_norm == -2.0) return give_up();
+    data->max_norm = std::sqrt(mn2) * (1.0 + 1e-12);
+    if (!(data->max_norm < 1e18)) return give_up();
+  }
   data->shadow16 = (uint16_t*)p;
   data->shadow16_state = 1;
   return RPT_OK;
@@ -2296,16 +2320,19 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // certified with 18 kept, 2.55 ms per batch against 4.10 ms on the f32 shadow; 26 kept 2.70 ms)
   const int kp16_env = (int)ctx->opt.knn_kp16;
   const int kp16 = kp16_env > k && kp16_env < kFK ? kp16_env : k + (k / 2 > 8 ? k / 2 : 8);
-  const bool sh16 = pre32 && !data->csr && data->shadow16 && !ctx->opt.knn_no_pre16 && !f->pre16_off &&
-                    kp16 + 1 <= kFK;
+  // (f32 data: the half shadow is the only ranking tier; the kept rows are refined with the very
+  // f32 distance the all-f32 kernel ranks on, so the answers are identical)
+  const bool base16 = !data->csr && data->shadow16 && !ctx->opt.knn_no_pre16 && !f->pre16_off &&
+                      kp16 + 1 <= kFK && dedup == 0 && !rerun && !ctx->opt.knn_no_pre32;
+  const bool sh16 = base16 && (pre32 || std::is_same<TD, float>::value);
   if (sh16) kp = kp16;
   if (tier) *tier = sh16 ? 2 : pre32 ? 1 : 0;
   const void* shadow = sh16 ? (const void*)data->shadow16 : (const void*)data->shadow32;
   if (wave) {
     dbgprint.p = dbg;
     const size_t smem = 4 * wbytes;
-    if constexpr (std::is_same<TD, double>::value) {
-      if (pre32) {
+    if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
+      if (pre32 || sh16) {
         if (smem > 64 * 1024)
           RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_wave_kernel<TD, TK, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2333,6 +2360,20 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFKx * 16 +
                       (size_t)data->d * (sizeof(TA) + 4) + 64 +
                       (vote > 0 ? (size_t)kVoteCap * 4 + 16 : 0);
+  if constexpr (std::is_same<TD, float>::value) {
+    if (sh16) {  // f32 rows ranked on their half shadow
+      if (smem > 64 * 1024)
+        RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL((knn_fused_kernel<TD, TK, true>), dim3((unsigned)q->n), dim3(256), smem,
+                         ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
+                         f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
+                         f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
+                         shadow, data->max_norm, kp + 1, CsrPtrs{}, 1);
+      RPT_HIP(hipGetLastError());
+      return RPT_OK;
+    }
+  }
   if constexpr (std::is_same<TD, double>::value) {
     if (pre32 && data->csr) {  // SVector rows ranked on their (u16, f32) shadow
       const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val,
@@ -2479,13 +2520,16 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
       RPT_TRY(ensure_shadow_csr(ctx, data));
   }
   int tier = 0;
+  if (data->dtype == RPT_F32 && !data->csr && dedup == 0 && !ctx->opt.knn_no_pre16 &&
+      !ctx->opt.knn_no_pre32 && !f->pre16_off)
+    RPT_TRY(ensure_shadow16(ctx, data));
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
       return launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
                                           count_dev, ovf_p, ctot_p, rerun, rerun ? nullptr : &tier);
     if (data->dtype == RPT_F32)
       return launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                        count_dev, ovf_p, ctot_p, rerun);
+                                        count_dev, ovf_p, ctot_p, rerun, rerun ? nullptr : &tier);
     return launch_fused<__hip_bfloat16, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
                                                count_dev, ovf_p, ctot_p, rerun);
   };

@@ -836,6 +836,43 @@ def test_knn_f32_data(rp, ctx, oracle):
     assert (bi[:, 0] == np.arange(50)).all()
 
 
+@pytest.mark.parametrize("shape", [(20000, 16, 12, 100), (20000, 16, 6, 100), (12000, 200, 8, 200)])
+@pytest.mark.parametrize("kind", ["cont", "ties", "self"])
+def test_knn_f32_data_half_shadow_tier_changes_nothing(rp, ctx, option, oracle, shape, kind):
+    """f32 data are ranked on an IEEE-half shadow first; the kept rows get the f32 distance the
+    all-f32 kernel ranks every candidate on and the cut is certified per query (uncertified
+    queries are answered again by the all-f32 kernel).  ids, distances and counts are the
+    all-f32 kernel's bit for bit — workgroup kernel, wave kernel, long rows; continuous data,
+    rounded data (many equal distances), queries that are data points."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, ml = shape
+    X = oracle.data_normal_dense2(77, n, d).astype(np.float32)
+    if kind == "ties":
+        X = (np.round(X * 2) / 2).astype(np.float32)
+    rng = np.random.default_rng(5)
+    Q = X[rng.integers(0, n, 64)].copy()
+    if kind != "self":
+        Q = (Q + np.float32(0.003)).astype(np.float32)
+    cfg = rp.rpTreeCfg(ml, n, d)
+    f = rp.forestBatch(9, cfg.fpMaxTreeDepth, ml, T, cfg.fpProjNzDensity, d, X, ctx=ctx)
+    for k in (1, 10, 24):
+        got = rp.knnBatch(k, f, Q)
+        tier, unc = C.c_int32(-1), C.c_int64(-1)
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+        if k == 1:
+            assert tier.value == 2                       # the half tier ran
+        if kind == "cont" and k == 24:
+            assert unc.value <= len(Q) // 8
+        with option("knn_no_pre16", 1):
+            ref = rp.knnBatch(k, f, Q)
+            _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+            assert tier.value == 0
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (k, kind)
+
+
 # ------------------------------------------------------------------ knnH / knnPQ (SURVEY 8f-3)
 def test_knnh_matches_oracle(rp, ctx, small_forest, oracle):
     """knnH (RPTree.hs:199-217): whole buckets of the lowest-margin-priority leaves, the bucket
