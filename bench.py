@@ -199,6 +199,13 @@ def other_configs(which, steps, with_cpu):
             f, b_ms, q_ms, pb, pq, cand, _ = _timed_leg(rp, _lib, L_, C, torch, ctx, ds, qs, R, maxd,
                                                         min_leaf, k, steps)
             nnz = int(val.numel())
+            tier, unc = C.c_int32(), C.c_int64()
+            _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
+            _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+            kp = k + max(8, k // 2)
+            ell_w = (int((rowptr[1:] - rowptr[:-1]).max().item()) + 3) & ~3     # slots per row of the half table
+            row_b = (cand * ell_w * 4 + min(kp, cand) * (nnz / float(n)) * 12 if tier.value == 2
+                     else cand * (nnz / float(n)) * 12)
             p_ms, p_n = pb["project"]
             per_build = p_n / steps
             passes = T * maxd / 32.0
@@ -217,10 +224,16 @@ def other_configs(which, steps, with_cpu):
                                      2.0 * nnz * 32, 0.0,
                                      "per PASS (SURVEY 8d: nnz*12 + (N+1)*8 + N*32*8 bytes, 2*nnz*32 flops); the "
                                      "kernel is instruction-issue bound, not HBM bound (DESIGN 4.1)"),
-                   "roofline_knn": _roof("knn_fused<CSR> (exact f64 distances over SVector rows)",
+                   "knn_ranking_tier": tier.value, "knn_uncertified": unc.value,
+                   "roofline_knn": _roof("knn_fused<CSR> (%s)" %
+                                         ("candidates ranked on the fixed-width half table, exact f64 "
+                                          "distances for the best %d" % kp if tier.value == 2
+                                          else "exact f64 distances over SVector rows"),
                                          pq["knn_topk"][0] / max(pq["knn_topk"][1], 1), pq["knn_topk"][1],
-                                         nq * cand * (nnz / float(n)) * 12, 0.0, 0.0,
-                                         "nq x candidates x mean row nonzeros x 12 B")}
+                                         nq * row_b, 0.0, 0.0,
+                                         "nq x (candidates x %d slots x 4 B + %d x mean row nonzeros x 12 B)"
+                                         % (ell_w, kp) if tier.value == 2
+                                         else "nq x candidates x mean row nonzeros x 12 B")}
             if with_cpu:
                 from oracle import oracle as orc
                 hr, hc, hv = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()

@@ -617,6 +617,7 @@ int32_t rpt_dataset_free(rpt_dataset* ds) {
     if (ds->shadow32) dev_free(ds->shadow32);
     if (ds->shadow16) dev_free(ds->shadow16);
     if (ds->shadow_col16) dev_free(ds->shadow_col16);
+    if (ds->shadow_ell) dev_free(ds->shadow_ell);
     if (ds->csr_split) dev_free(ds->csr_split);
     if (ds->owns) {
       (void)hipSetDevice(ds->ctx->device);

@@ -215,6 +215,13 @@ struct rpt_dataset {
   mutable int shadow16_state = 0;
   mutable uint16_t* shadow_col16 = nullptr;  // CSR (d <= 65536): col as u16
   mutable int64_t max_rowlen = 0;            // CSR: the longest row
+  // round 3: CSR f64 rows again as a fixed-width table of (u16 column | IEEE-half value << 16)
+  // slots, ell_w slots per row (the longest row rounded up to 4; absent slots are 0 = column 0,
+  // value 0, which adds nothing to a distance): the first-tier ranking shadow of SVector data, 4
+  // instead of 12 bytes per nonzero and no rowptr step in the walk; ell_state as shadow16_state
+  mutable uint32_t* shadow_ell = nullptr;
+  mutable int ell_w = 0;
+  mutable int ell_state = 0;
   mutable double max_norm = -1.0;
   // lazily built by the first projection of a CSR dataset whose hyperplane tile does not fit LDS
   // whole: index of every row's first nonzero with column >= csr_split_k (project.hip)

@@ -676,6 +676,9 @@ struct CsrPtrs {
   const uint16_t* col16;
   const float* val32;
   int64_t max_rowlen;
+  // half tier: the rows as a fixed-width table of (u16 column | half value << 16) slots
+  const uint32_t* ell;
+  int ell_w;
 };
 
 // Squared-distance sums of U CSR rows per 16-lane group against the dense-ified query qs (LDS):
@@ -855,6 +858,64 @@ __device__ __forceinline__ void batch_distances_csr32(const int64_t* __restrict_
     csr_rows_dist2_f32<U>(col16, val32, nnz, ra, rb, qs32, l16, s);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      const float t = qn2 + s[u];
+      const int i = i0 + u * 4 + grp;
+      if (l16 == 0 && i < fill) cdist[i] = (double)(t > 0.f ? t : 0.f);
+    }
+  }
+}
+
+// f32 SQUARED distances (clamped at 0) of the CSR candidates [first, fill) from the fixed-width
+// half shadow (rpt_dataset::shadow_ell): row id -> id * W slots, no rowptr step; sixteen lanes
+// per row, a lane takes the 16-byte chunks l16, l16 + 16, .. (four slots each), the chunks of all
+// four row slots of the group and of up to four steps are loaded before the first is used (W <=
+// 256: ONE round of loads per sixteen rows of the wave).  A slot adds x (x - 2 q_col) = (x - q)^2
+// - q^2 with two roundings (explicit FMAs); an absent slot (column 0, x = 0) adds 0.
+__device__ __forceinline__ void batch_distances_ell16(const uint32_t* __restrict__ ell, int W,
+                                                      const int* cid, double* cdist,
+                                                      const float* qs32, float qn2, int first,
+                                                      int fill, int wave, int lane) {
+  constexpr int U = 4, S = 4;
+  const int grp = lane >> 4, l16 = lane & 15;
+  const int chunks = W >> 2;
+  for (int i0 = first + wave * 4 * U; i0 < fill; i0 += 4 * 4 * U) {
+    const uint4* row[U];
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 4 + grp;
+      const int id = cid[i < fill ? i : first];
+      row[u] = reinterpret_cast<const uint4*>(ell + (int64_t)id * W);
+      s[u] = 0.f;
+    }
+    for (int c0 = 0; c0 < chunks; c0 += 16 * S) {
+      uint4 v[U][S];
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        const int c = c0 + st * 16 + l16;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u][st] = c < chunks ? row[u][c] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const unsigned int w4[4] = {v[u][st].x, v[u][st].y, v[u][st].z, v[u][st].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned short hb = (unsigned short)(w4[e] >> 16);
+            _Float16 h;
+            __builtin_memcpy(&h, &hb, 2);
+            const float x = (float)h;
+            const float qj = qs32[w4[e] & 0xffffu];
+            s[u] = __builtin_fmaf(x, __builtin_fmaf(-2.f, qj, x), s[u]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      for (int o = 8; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
       const float t = qn2 + s[u];
       const int i = i0 + u * 4 + grp;
       if (l16 == 0 && i < fill) cdist[i] = (double)(t > 0.f ? t : 0.f);
@@ -1225,11 +1286,15 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     pos_base = pb;
     __syncthreads();
     // ---- distances of the new candidates ----
-    if constexpr (CSR && PRE32)
-      batch_distances_csr32(csr.rowptr, csr.col16, csr.val32, csr.nnz, cid, cdist,
-                            reinterpret_cast<const float*>(qsd + d), (float)s_qn, first_new, fill,
-                            wave, lane);
-    else if constexpr (CSR)
+    if constexpr (CSR && PRE32) {
+      if (sh16)
+        batch_distances_ell16(csr.ell, csr.ell_w, cid, cdist, reinterpret_cast<const float*>(qsd + d),
+                              (float)s_qn, first_new, fill, wave, lane);
+      else
+        batch_distances_csr32(csr.rowptr, csr.col16, csr.val32, csr.nnz, cid, cdist,
+                              reinterpret_cast<const float*>(qsd + d), (float)s_qn, first_new, fill,
+                              wave, lane);
+    } else if constexpr (CSR)
       batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), csr.nnz, cid,
                               cdist, qsd, s_qn, first_new, fill, wave, lane);
     else if constexpr (PRE32) {
@@ -1276,7 +1341,18 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       const double chain = (double)(4 * ((csr.max_rowlen + 63) / 64) + 5);
       const double E2 = (chain + 8.0) * u * (2.0 * xmax * xmax + 4.0 * s_qn) * 1.01 + 1e-37;
       const double dk = bdist[best - 1];
-      if (!(s_qn < 1e36) || !(F2 < 1e37) || !(F2 - E2 > dk * dk * (1.0 + 1e-14))) {
+      bool certified = (s_qn < 1e36) && (F2 < 1e37) && (F2 - E2 > dk * dk * (1.0 + 1e-14));
+      if (sh16) {
+        // half shadow: E2 (taken at the norm of the rounded rows, <= 1.001 xmax) bounds the f32
+        // value against the squared distance of the ROUNDED row x_h; |x - x_h| <= 2^-11 |x| (+ 2^-25
+        // per element in the half subnormal range; 1.05: the f64 -> f32 -> half double rounding), so
+        // the exact distance of every dropped row is >= sqrt(F2 - E2') - emax
+        const double E2h = E2 * 1.003;
+        const double emax = 1.05 * 4.8828125e-4 * xmax + sqrt((double)csr.max_rowlen) * 3.1e-8;
+        const double lo = F2 - E2h;
+        certified = (s_qn < 1e36) && (F2 < 1e37) && lo > 0.0 && sqrt(lo) - emax > dk * (1.0 + 1e-13);
+      }
+      if (!certified) {
         if (tid == 0) {  // flag 2: the host re-runs this query with exact distances only
           ovf_flags[q] = 2u;
           atomicAdd(cand_total + 1, 1ULL);
@@ -2271,6 +2347,107 @@ static int32_t ensure_shadow_csr(rpt_ctx* ctx, const rpt_dataset* data) {
   return RPT_OK;
 }
 
+// CSR f64 rows: largest squared row norm, longest row, largest |value| (one thread per row)
+__global__ __launch_bounds__(256) void csr_stats_kernel(const int64_t* __restrict__ rowptr,
+                                                        const double* __restrict__ val, int64_t n,
+                                                        unsigned long long* __restrict__ max_bits) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  double mx = 0.0, ma = 0.0;
+  long long ml = 0;
+  for (int64_t r = gtid; r < n; r += gsz) {
+    const int64_t a = rowptr[r], b = rowptr[r + 1];
+    double s2 = 0.0;
+    for (int64_t j = a; j < b; ++j) {
+      const double v = val[j], av = fabs(v);
+      s2 += v * v;
+      if (!(av <= ma)) ma = av == av ? av : inf;
+    }
+    if (!(s2 <= mx)) mx = s2 == s2 ? s2 : inf;  // NaN -> +inf
+    if (b - a > ml) ml = b - a;
+  }
+  atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));
+  atomicMax(max_bits + 1, (unsigned long long)ml);
+  atomicMax(max_bits + 2, (unsigned long long)__double_as_longlong(ma));
+}
+
+// the fixed-width half table: sixteen lanes per row, a lane writes whole 16-byte chunks
+__global__ __launch_bounds__(256) void ell_fill_kernel(const int64_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const double* __restrict__ val, int64_t n,
+                                                       int W, uint32_t* __restrict__ ell) {
+  const int l16 = threadIdx.x & 15;
+  const int chunks = W >> 2;
+  for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += (int64_t)gridDim.x * 16) {
+    const int64_t a = rowptr[r], b = rowptr[r + 1];
+    uint4* out = reinterpret_cast<uint4*>(ell + r * W);
+    for (int c = l16; c < chunks; c += 16) {
+      unsigned int w4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t j = a + 4 * (int64_t)c + e;
+        w4[e] = 0u;
+        if (j < b) {
+          const _Float16 h = (_Float16)(float)val[j];
+          unsigned short hb;
+          __builtin_memcpy(&hb, &h, 2);
+          w4[e] = (unsigned int)col[j] | ((unsigned int)hb << 16);
+        }
+      }
+      out[c] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+  }
+}
+
+// The half tier's table of a CSR f64 dataset, once per dataset; allowed to fail (no memory, values
+// beyond the half range, rows so uneven that the padding would exceed twice the nonzeros).
+static int32_t ensure_shadow_ell(rpt_ctx* ctx, const rpt_dataset* data) {
+  if (data->ell_state != 0) return RPT_OK;
+  data->ell_state = -1;
+  if (!data->csr || data->dtype != RPT_F64 || data->d > 65536 || data->n == 0 ||
+      data->max_norm == -2.0)
+    return RPT_OK;
+  void* p = nullptr;
+  DevBuf<unsigned long long> mb;
+  unsigned long long bits[3] = {0, 0, 0};
+  auto give_up = [&]() {
+    if (p) dev_free(p);
+    (void)hipGetLastError();
+    return RPT_OK;
+  };
+  if (mb.alloc(3) != RPT_OK) return give_up();
+  if (hipMemsetAsync(mb.p, 0, 24, ctx->stream) != hipSuccess) return give_up();
+  hipLaunchKernelGGL(csr_stats_kernel, dim3((unsigned)ctx->n_cu * 8), dim3(256), 0, ctx->stream,
+                     data->rowptr, (const double*)data->val, data->n, mb.p);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (hipMemcpyAsync(bits, mb.p, 24, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
+  double m2, mabs;
+  std::memcpy(&m2, &bits[0], 8);
+  std::memcpy(&mabs, &bits[2], 8);
+  const double mn = std::sqrt(m2) * (1.0 + 1e-12);
+  if (!(mn < 1e18) || !(mabs < 6.0e4)) return give_up();
+  const int64_t W = (((int64_t)bits[1] + 3) & ~(int64_t)3) > 4 ? (((int64_t)bits[1] + 3) & ~(int64_t)3) : 4;
+  if (W > 4096 || (double)data->n * (double)W > 3.0 * (double)data->nnz + 1048576.0) return give_up();
+  if (dev_alloc(&p, (size_t)data->n * (size_t)W * 4 + 16) != hipSuccess) {
+    p = nullptr;
+    return give_up();
+  }
+  int64_t blocks = (data->n + 15) / 16;
+  if (blocks > (int64_t)ctx->n_cu * 32) blocks = (int64_t)ctx->n_cu * 32;
+  hipLaunchKernelGGL(ell_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, data->rowptr,
+                     data->col, (const double*)data->val, data->n, (int)W, (uint32_t*)p);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
+  if (data->max_norm < 0.0) data->max_norm = mn;
+  if (data->max_rowlen == 0) data->max_rowlen = (int64_t)bits[1];
+  data->shadow_ell = (uint32_t*)p;
+  data->ell_w = (int)W;
+  data->ell_state = 1;
+  return RPT_OK;
+}
+
 template <class TD, class TK>
 static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
                             const rpt_dataset* q, const void* Pq, int32_t k, int dedup,
@@ -2325,8 +2502,12 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const bool base16 = !data->csr && data->shadow16 && !ctx->opt.knn_no_pre16 && !f->pre16_off &&
                       kp16 + 1 <= kFK && dedup == 0 && !rerun && !ctx->opt.knn_no_pre32;
   const bool sh16 = base16 && (pre32 || std::is_same<TD, float>::value);
-  if (sh16) kp = kp16;
-  if (tier) *tier = sh16 ? 2 : pre32 ? 1 : 0;
+  // SVector rows: the fixed-width half table is their first tier (the f32 CSR shadow is opt-in)
+  const bool ell = std::is_same<TD, double>::value && data->csr && data->shadow_ell &&
+                   !ctx->opt.knn_no_pre16 && !f->pre16_off && !f->prefilter_off && kp16 + 1 <= kFK &&
+                   dedup == 0 && !rerun && !ctx->opt.knn_no_pre32;
+  if (sh16 || ell) kp = kp16;
+  if (tier) *tier = (sh16 || ell) ? 2 : pre32 ? 1 : 0;
   const void* shadow = sh16 ? (const void*)data->shadow16 : (const void*)data->shadow32;
   if (wave) {
     dbgprint.p = dbg;
@@ -2375,9 +2556,10 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
     }
   }
   if constexpr (std::is_same<TD, double>::value) {
-    if (pre32 && data->csr) {  // SVector rows ranked on their (u16, f32) shadow
+    if ((pre32 || ell) && data->csr) {  // SVector rows ranked on their half table / (u16, f32) shadow
       const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val,
-                       data->shadow_col16, data->shadow32, data->max_rowlen};
+                       data->shadow_col16, data->shadow32, ell ? (int64_t)data->ell_w : data->max_rowlen,
+                       data->shadow_ell, data->ell_w};
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2385,7 +2567,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                          smem, ctx->stream, (const TD*)nullptr, data->d, (const TD*)nullptr,
                          f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n,
                          f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf,
-                         cand_total, (const void*)nullptr, data->max_norm, kp + 1, cp);
+                         cand_total, (const void*)nullptr, data->max_norm, kp + 1, cp, ell ? 1 : 0);
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -2405,7 +2587,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
     if (data->csr) {  // SVector rows: the same kernel, distances over CSR rows
       const CsrPtrs cp{data->rowptr, data->col, data->val, data->nnz, q->rowptr, q->col, q->val,
-                       nullptr, nullptr, 0};
+                       nullptr, nullptr, 0, nullptr, 0};
       if (smem > 64 * 1024)
         RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, false, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2516,8 +2698,10 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     // the exact kernel already gathers rows at 6.4 TB/s and the f32 pass, with its 17 selection
     // rounds per batch, is bound by its serial phases (14.3 ms against 13.8 ms per 10 000 queries):
     // opt-in (knn_csr_pre32), kept for bandwidth-poorer configurations and pinned by a test
-    else if (ctx->opt.knn_csr_pre32 && data->dtype == RPT_F64 && data->d <= 65536)
-      RPT_TRY(ensure_shadow_csr(ctx, data));
+    else if (data->dtype == RPT_F64 && data->d <= 65536) {
+      if (ctx->opt.knn_csr_pre32) RPT_TRY(ensure_shadow_csr(ctx, data));
+      if (!ctx->opt.knn_no_pre16 && !f->pre16_off) RPT_TRY(ensure_shadow_ell(ctx, data));
+    }
   }
   int tier = 0;
   if (data->dtype == RPT_F32 && !data->csr && dedup == 0 && !ctx->opt.knn_no_pre16 &&

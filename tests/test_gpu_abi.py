@@ -518,25 +518,76 @@ def test_csr_knn_f32_prefilter_is_exact(rp, ctx, oracle):
     col3, val3 = np.concatenate([col] + [blk_c] * 40), np.concatenate([val] + [blk_v] * 40)
     cases = [("continuous", rowptr, col, val, qv), ("rounded", rowptr, col, np.round(val, 1) + 0.05, np.round(qv, 1) + 0.05),
              ("every row twice", rp2, col2, val2, qv), ("forty copies", rp3, col3, val3, qv)]
+    import ctypes as C
+    from rptree_amd import _lib
     for name, rptr, cc, vv, qvv in cases:
         f = rp.forestBatch(9, L, ml, T, pnz, d, (rptr, cc, vv, d), ctx=ctx, hyperplanes=R)
-        on = ctx.set_option("knn_csr_pre32", 1)      # opt-in: no faster than the exact kernel at C3
-        try:
-            a = rp.knnBatch(k, f, (qr, qc, qvv, d))
-        finally:
-            ctx.set_option("knn_csr_pre32", on)
-        unc = rp.knn_last_uncertified(ctx)
         old = ctx.set_option("knn_no_pre32", 1)
         try:
             b = rp.knnBatch(k, f, (qr, qc, qvv, d))
         finally:
             ctx.set_option("knn_no_pre32", old)
+        # the (u16, f32) shadow: opt-in, no faster than the exact kernel at C3
+        on, no16 = ctx.set_option("knn_csr_pre32", 1), ctx.set_option("knn_no_pre16", 1)
+        try:
+            a = rp.knnBatch(k, f, (qr, qc, qvv, d))
+        finally:
+            ctx.set_option("knn_csr_pre32", on)
+            ctx.set_option("knn_no_pre16", no16)
+        unc = rp.knn_last_uncertified(ctx)
+        tier = C.c_int32(-1)
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        assert tier.value == 1
         for x, y in zip(a, b):
             assert np.array_equal(x, y), name
         if name == "continuous":
             assert unc == 0
         if name == "forty copies":
             assert unc > 0          # the copies tie across the prefilter's cut: the re-run path
+        # the default: the fixed-width half table ranks first
+        h = rp.knnBatch(k, f, (qr, qc, qvv, d))
+        unc = rp.knn_last_uncertified(ctx)
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        assert tier.value == 2, name
+        for x, y in zip(h, b):
+            assert np.array_equal(x, y), name
+        if name == "continuous":
+            assert unc <= 2
+        if name == "forty copies":
+            assert unc > 0
+        f.close()
+
+
+def test_csr_half_table_is_skipped_when_it_cannot_hold_the_rows(rp, ctx, oracle):
+    """Values beyond the half range, or one row so long that padding every row to its length would
+    more than triple the nonzeros: no half table, the exact kernel answers (tier 0), same results
+    as with the tier switched off."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, ml, k = 6000, 300, 6, 40, 5
+    rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.05)
+    qr, qc, qv = oracle.data_normal_sparse2(6, 32, d, 0.05)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(9, T, L, pnz, d)
+    # (a) a value of 1e5; (b) a full row in an otherwise 5 % dense set (n * 300 > 3 nnz + 2^20)
+    big = val.copy()
+    big[7] = 1e5
+    rp2 = np.concatenate([rowptr, [rowptr[-1] + d]])
+    col2 = np.concatenate([col, np.arange(d, dtype=col.dtype)])
+    val2 = np.concatenate([val, np.full(d, 0.25)])
+    tier = C.c_int32(-1)
+    for name, rptr, cc, vv in (("huge value", rowptr, col, big), ("one full row", rp2, col2, val2)):
+        f = rp.forestBatch(9, L, ml, T, pnz, d, (rptr, cc, vv, d), ctx=ctx, hyperplanes=R)
+        a = rp.knnBatch(k, f, (qr, qc, qv, d))
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        assert tier.value == 0, name
+        old = ctx.set_option("knn_no_pre32", 1)
+        try:
+            b = rp.knnBatch(k, f, (qr, qc, qv, d))
+        finally:
+            ctx.set_option("knn_no_pre32", old)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), name
         f.close()
 
 

@@ -79,9 +79,11 @@ mq = rq.random((nq2, d)) < dens
 qr2 = np.zeros(nq2 + 1, dtype=np.int64); qr2[1:] = np.cumsum(mq.sum(axis=1))
 qc2 = np.nonzero(mq)[1].astype(np.int32)
 qv2 = 1.0 - rq.random(qr2[-1])
-for label, opt in (("f32 prefilter", 0), ("all exact", 1)):
-    ctx.set_option("knn_no_pre32", opt)
-    ctx.set_option("knn_csr_pre32", 1 - opt)
+keep = None
+for label, opts in (("half table", {}), ("f32 prefilter", {"knn_csr_pre32": 1, "knn_no_pre16": 1}),
+                    ("all exact", {"knn_no_pre32": 1})):
+    for kk, vv in opts.items():
+        ctx.set_option(kk, vv)
     g = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)   # a fresh forest: prefilter state
     rp.knnBatch(10, g, (qr2, qc2, qv2, d))
     _lib.check(L_.rpt_prof_reset(ctx._h)); _lib.check(L_.rpt_prof_enable(ctx._h, 1))
@@ -91,12 +93,15 @@ for label, opt in (("f32 prefilter", 0), ("all exact", 1)):
     ms, c = C.c_double(), C.c_int64()
     _lib.check(L_.rpt_prof_get(ctx._h, 3, C.byref(ms), C.byref(c)))
     _lib.check(L_.rpt_prof_enable(ctx._h, 0))
-    print("knn %d queries, %s: %.2f ms = %.3f M queries/s (host call); distance / top-k kernel %.2f ms = %.3f M queries/s; uncertified %d"
-          % (nq2, label, dt * 1e3, nq2 / dt / 1e6, ms.value, nq2 / ms.value / 1e3, rp.knn_last_uncertified(ctx)))
-    if opt == 0:
+    tier = C.c_int32(-1)
+    _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
+    print("knn %d queries, %s (tier %d): %.2f ms = %.3f M queries/s (host call); distance / top-k kernel %.2f ms = %.3f M queries/s; uncertified %d"
+          % (nq2, label, tier.value, dt * 1e3, nq2 / dt / 1e6, ms.value, nq2 / ms.value / 1e3, rp.knn_last_uncertified(ctx)))
+    if keep is None:
         keep = (i2.copy(), d2.copy(), c2.copy())
     else:
         assert np.array_equal(keep[0], i2) and np.array_equal(keep[1], d2) and np.array_equal(keep[2], c2)
     g.close()
-ctx.set_option("knn_no_pre32", 0)
+    for kk in opts:
+        ctx.set_option(kk, 0)
 print("prefiltered answers identical to the exact kernel's")
