@@ -222,6 +222,7 @@ const OptDesc kOptions[] = {
     {"no_wsub", &rpt_options::no_wsub},
     {"no_wsort", &rpt_options::no_wsort},
     {"no_wpack", &rpt_options::no_wpack},
+    {"no_csub", &rpt_options::no_csub},
     {"no_codes", &rpt_options::no_codes},
     {"no_pcodes", &rpt_options::no_pcodes},
     {"proj_narrow", &rpt_options::proj_narrow},

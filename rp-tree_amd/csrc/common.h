@@ -135,6 +135,8 @@ struct rpt_options {
   int64_t no_wsub = 0;          // split: block-level subtree kernel instead of the wave kernel
   int64_t no_wsort = 0;         // split: the wave kernel selects by histograms (round 2) instead of sorting
   int64_t no_wpack = 0;         // split: the sorting wave kernel gathers a key per level, no packed images
+  int64_t no_csub = 0;          // split: nodes of 1025 .. 8192 points take the general / LDS-subtree kernels
+                                // instead of the block kernel that selects on packed 16-bit codes
   int64_t no_codes = 0;         // split: stream on the keys themselves, no 16-bit codes
   int64_t no_pcodes = 0;        // split: no codes for projection kernels without a code epilogue
   int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only

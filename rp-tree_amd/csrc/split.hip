@@ -1971,6 +1971,334 @@ __global__ __launch_bounds__(256) void mid_kernel(int32_t* __restrict__ dst, int
 }
 
 // ---------------------------------------------------------------------------------------
+// Mid-size nodes on packed codes (round 3): one workgroup per (tree, node of kWCap < n <= kCsCap
+// points) runs the r <= 4 levels that bring its children under the wave kernel's size, none of
+// which produces a Tip.  Where subtree_kernel gathers an exact key per point and level (a 64-byte
+// sector for 4 or 8 bytes), this kernel gathers ONE 8-byte word per point — the 16-bit codes
+// (codes.h) of the r levels, packed in id order by cpack_kernel — and selects every level's
+// median on the codes: code(x) < code(y) implies x < y, so a two-pass radix histogram (high byte,
+// low byte) finds the code of the median element, the points of smaller / larger codes go left /
+// right, and exact keys are fetched only for the points that SHARE the pivot code (ranked with
+// the lexicographic tie-break, Keys::less) and for those of the nearest occupied codes below and
+// above it (the margins, Internal.hs:497-499).  No element moves until the end, where the
+// points are written grouped by child (their order inside a child is irrelevant: the wave kernel
+// that takes the children orders by keys and ids).  A node whose pivot codes hold more points
+// than the pool (heavy ties) is flagged and run again by the general kernels.
+// grid = (S, T), kCsThreads threads.
+// ---------------------------------------------------------------------------------------
+constexpr int kCsCap = 8192;
+constexpr int kCsThreads = 512;
+constexpr int kCsMaxR = 4;                 // levels per launch = 16-bit codes per packed word
+constexpr int kCsMaxM = 1 << (kCsMaxR - 1);
+constexpr int kCsPool = 1024;              // points sharing their node's pivot code, per level
+
+// the codes of levels level0 .. level0 + r - 1 of every point, packed: one coalesced pass
+__global__ __launch_bounds__(256) void cpack_kernel(const uint16_t* __restrict__ Cd, int64_t N, int L,
+                                                    int level0, int r,
+                                                    unsigned long long* __restrict__ pk) {
+  const int t = blockIdx.y;
+  const uint16_t* c = Cd + ((int64_t)t * L + level0) * N;
+  unsigned long long* o = pk + (int64_t)t * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    unsigned long long w = 0;
+    for (int dd = 0; dd < r; ++dd) w |= (unsigned long long)c[(int64_t)dd * N + i] << (16 * dd);
+    o[i] = w;
+  }
+}
+
+struct CsNode {
+  int n, nh, hb, cL, cMid, pc, poff;
+};
+
+template <class TK, int E_>
+__global__ __launch_bounds__(kCsThreads, (E_ <= 8 ? 6 : 4)) void csub_kernel(
+    const int32_t* __restrict__ src, int32_t* __restrict__ nxt, int64_t N, const TK* __restrict__ P,
+    const unsigned long long* __restrict__ pk, int L, int level0, int r,
+    const Seg* __restrict__ segs, double* thr, double* mglo, double* mghi, int64_t nodes,
+    unsigned long long* tie_count, unsigned int* flags /* [0] count, [1 + seg] */) {
+  __shared__ unsigned int hist[kCsMaxM * 256], hist2[kCsMaxM * 256];
+  __shared__ CsNode sn[kCsMaxM];
+  __shared__ int s_lowc[kCsMaxM], s_highc[kCsMaxM], pcur[kCsMaxM];
+  __shared__ unsigned long long s_maxL[kCsMaxM], s_minR[kCsMaxM];
+  __shared__ __attribute__((aligned(16))) TK pkey[kCsPool];
+  __shared__ int pid[kCsPool];
+  __shared__ int pown[kCsPool];               // (owner thread << 8) | (slot << 4) | node
+  __shared__ unsigned int sidew[kCsThreads];  // per thread: the sides of its pooled slots
+  __shared__ int ccur[1 << kCsMaxR];
+  __shared__ int s_fail, s_total;
+  __shared__ unsigned int s_ties;  // added to the global statistic only if the node completes
+
+  const Seg sg = segs[blockIdx.x];
+  const int t = blockIdx.y;
+  const int n_top = sg.n;
+  if (n_top <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TK* Pt = P + (int64_t)t * L * N;
+  const int32_t* s = src + (int64_t)t * N + sg.off;
+  const unsigned long long* pkt = pk + (int64_t)t * N;
+
+  int id[E_];
+  unsigned long long w[E_];
+  unsigned long long node4 = 0;  // 4 bits per slot: the slot's node at the current depth
+#pragma unroll
+  for (int e = 0; e < E_; ++e) {
+    const int pos = e * kCsThreads + tid;
+    id[e] = pos < n_top ? s[pos] : -1;
+  }
+#pragma unroll
+  for (int e = 0; e < E_; ++e) w[e] = id[e] >= 0 ? pkt[id[e]] : 0ULL;
+  if (tid == 0) {
+    s_fail = 0;
+    s_ties = 0;
+  }
+
+  for (int depth = 0; depth < r; ++depth) {
+    const int level = level0 + depth;
+    const int M = 1 << depth;
+    Keys<TK> K{Pt, N, level, nullptr};
+    const TK* Pl = Pt + (int64_t)level * N;
+    // ---- a. high-byte histogram ----
+    for (int i = tid; i < M * 256; i += kCsThreads) {
+      hist[i] = 0;
+      hist2[i] = 0;
+    }
+    if (tid < M) {
+      s_lowc[tid] = -1;
+      s_highc[tid] = 65536;
+      pcur[tid] = 0;
+      s_maxL[tid] = 0ULL;
+      s_minR[tid] = ~0ULL;
+    }
+    __syncthreads();
+    auto code_of_slot = [&](int e) { return (int)((w[e] >> (16 * depth)) & 0xffffULL); };
+#pragma unroll
+    for (int e = 0; e < E_; ++e)
+      if (id[e] >= 0) atomicAdd(&hist[(int)((node4 >> (4 * e)) & 15ULL) * 256 + (code_of_slot(e) >> 8)], 1u);
+    __syncthreads();
+    // ---- b. the high byte of the median's code: one wave per node ----
+    auto pick = [&](const unsigned int* h, unsigned int target, int& bin, int& before, int& cnt) {
+      unsigned int c4[4], loc = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c4[i] = h[lane * 4 + i];
+        loc += c4[i];
+      }
+      unsigned int inc = loc;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      unsigned int run = inc - loc;
+      int pb = -1, cb = 0, cc = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (run <= target && target < run + c4[i]) {
+          pb = lane * 4 + i;
+          cb = (int)run;
+          cc = (int)c4[i];
+        }
+        run += c4[i];
+      }
+      const unsigned long long own = __ballot(pb >= 0);
+      const int sl = own ? __ffsll((long long)own) - 1 : 0;
+      bin = __shfl(pb, sl);
+      before = __shfl(cb, sl);
+      cnt = __shfl(cc, sl);
+    };
+    if (wave < M) {
+      const int j = wave;
+      CsNode a;
+      a.n = sub_node_size(n_top, depth, j);
+      a.nh = a.n >> 1;
+      int hb, before, cnt;
+      pick(hist + j * 256, (unsigned int)a.nh, hb, before, cnt);
+      a.hb = hb;
+      a.cL = before;
+      a.cMid = cnt;
+      a.pc = 0;
+      a.poff = 0;
+      if (lane == 0) sn[j] = a;
+    }
+    __syncthreads();
+    // ---- c. low-byte histogram of the points in that high byte ----
+#pragma unroll
+    for (int e = 0; e < E_; ++e)
+      if (id[e] >= 0) {
+        const int j = (int)((node4 >> (4 * e)) & 15ULL);
+        const int c = code_of_slot(e);
+        if ((c >> 8) == sn[j].hb) atomicAdd(&hist2[j * 256 + (c & 255)], 1u);
+      }
+    __syncthreads();
+    if (wave < M) {
+      const int j = wave;
+      const CsNode a = sn[j];
+      int lb, before, cnt;
+      pick(hist2 + j * 256, (unsigned int)(a.nh - a.cL), lb, before, cnt);
+      if (lane == 0) {
+        sn[j].pc = (a.hb << 8) | lb;
+        sn[j].cL = a.cL + before;
+        sn[j].cMid = cnt;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int j = 0; j < M; ++j) {
+        sn[j].poff = run;
+        run += sn[j].cMid;
+        if (sn[j].hb < 0 || sn[j].cMid <= 0) s_fail = 1;  // cannot happen on a consistent histogram
+      }
+      if (run > kCsPool) s_fail = 1;
+      s_total = run;
+    }
+    // ---- d. nearest occupied codes around the pivot code: first among the points that share its
+    // high byte (a few dozen), all points only where that finds nothing ----
+#pragma unroll
+    for (int e = 0; e < E_; ++e)
+      if (id[e] >= 0) {
+        const int j = (int)((node4 >> (4 * e)) & 15ULL);
+        const int pc = sn[j].pc, c = code_of_slot(e);
+        if ((c >> 8) == (pc >> 8)) {
+          if (c < pc) atomicMax(&s_lowc[j], c);
+          if (c > pc) atomicMin(&s_highc[j], c);
+        }
+      }
+    __syncthreads();
+    if (s_fail) {  // uniform: heavy ties -> the general kernels run this node again
+      if (tid == 0) {
+        flags[1 + blockIdx.x] = 1u;
+        atomicAdd(flags, 1u);
+      }
+      return;
+    }
+    {
+      bool need = false;
+      for (int j = 0; j < M; ++j) {
+        const CsNode a = sn[j];
+        need = need || (s_lowc[j] < 0 && a.cL > 0) || (s_highc[j] > 65535 && a.cL + a.cMid < a.n);
+      }
+      if (need) {  // uniform (LDS values read after the barrier)
+#pragma unroll
+        for (int e = 0; e < E_; ++e)
+          if (id[e] >= 0) {
+            const int j = (int)((node4 >> (4 * e)) & 15ULL);
+            const int pc = sn[j].pc, c = code_of_slot(e);
+            if ((c >> 8) != (pc >> 8)) {
+              if (c < pc) atomicMax(&s_lowc[j], c);
+              if (c > pc) atomicMin(&s_highc[j], c);
+            }
+          }
+        __syncthreads();
+      }
+    }
+    // ---- e. exact keys: the pivot-code points into the pool (with their owner slot), the
+    // neighbours' extremes ----
+    sidew[tid] = 0u;
+#pragma unroll
+    for (int e = 0; e < E_; ++e) {
+      if (id[e] < 0) continue;
+      const int j = (int)((node4 >> (4 * e)) & 15ULL);
+      const int pc = sn[j].pc;
+      const int c = (int)((w[e] >> (16 * depth)) & 0xffffULL);
+      if (c == pc) {
+        const int p = sn[j].poff + atomicAdd(&pcur[j], 1);
+        pkey[p] = Pl[id[e]];
+        pid[p] = id[e];
+        pown[p] = (tid << 8) | (e << 4) | j;
+      } else if (c == s_lowc[j]) {
+        atomicMax(&s_maxL[j], ord_of(Pl[id[e]]));
+      } else if (c == s_highc[j]) {
+        atomicMin(&s_minR[j], ord_of(Pl[id[e]]));
+      }
+    }
+    __syncthreads();
+    // ---- f. exact rank inside the pivot code (one thread per pooled point); thresholds and
+    // margins; the side of a pooled point goes to its owner's word ----
+    for (int q = tid; q < s_total; q += kCsThreads) {
+      const int ow = pown[q];
+      const int j = ow & 15;
+      const CsNode a = sn[j];
+      const TK kq = pkey[q];
+      const int iq = pid[q];
+      int rank = 0;
+      for (int o = a.poff; o < a.poff + a.cMid; ++o)
+        if (o != q && K.less(pkey[o], pid[o], kq, iq)) ++rank;
+      const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + j);
+      if (rank == a.nh - a.cL) thr[h] = (double)kq;
+      if (rank == il - a.cL) mglo[h] = (double)kq;
+      if (rank == ih - a.cL) mghi[h] = (double)kq;
+      if (rank >= a.nh - a.cL) atomicOr(&sidew[ow >> 8], 1u << ((ow >> 4) & 15));
+    }
+    if (tid < M) {
+      const CsNode a = sn[tid];
+      const int il = a.nh > 0 ? a.nh - 1 : 0, ih = a.nh + 1 < a.n ? a.nh + 1 : a.n - 1;
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + tid);
+      if (il < a.cL) mglo[h] = (double)ord_to(s_maxL[tid], TK());
+      if (ih >= a.cL + a.cMid) mghi[h] = (double)ord_to(s_minR[tid], TK());
+    }
+    __syncthreads();
+    unsigned int sidebits = sidew[tid];
+#pragma unroll
+    for (int e = 0; e < E_; ++e) {
+      const int j = (int)((node4 >> (4 * e)) & 15ULL);
+      const int c = (int)((w[e] >> (16 * depth)) & 0xffffULL);
+      sidebits |= (id[e] >= 0 && c > sn[j].pc ? 1u : 0u) << e;
+    }
+    // ---- g. descend ----
+    {
+      unsigned long long nn = 0;
+#pragma unroll
+      for (int e = 0; e < E_; ++e) {
+        const unsigned long long j = (node4 >> (4 * e)) & 15ULL;
+        nn |= ((2 * j + ((sidebits >> e) & 1u)) & 15ULL) << (4 * e);
+      }
+      node4 = nn;
+    }
+    __syncthreads();
+    if (tid < M && sn[tid].n > 1) {  // ties straddling the cut (statistics)
+      const int64_t h = (int64_t)t * nodes + ((((int64_t)sg.heap + 1) << depth) - 1 + tid);
+      __threadfence_block();
+      if (!(mglo[h] < thr[h])) atomicAdd(&s_ties, 1u);
+    }
+  }
+
+  // ---- the points grouped by child, any order inside a child ----
+  const int C = 1 << r;
+  if (tid < C) ccur[tid] = 0;
+  __syncthreads();
+  if (tid == 0 && s_ties) atomicAdd(tie_count, (unsigned long long)s_ties);
+  int32_t* on = nxt + (int64_t)t * N + sg.off;
+#pragma unroll
+  for (int e = 0; e < E_; ++e) {
+    const int c = (int)((node4 >> (4 * e)) & 15ULL);
+    const bool live = id[e] >= 0;
+    int slot = 0;
+    for (int j = 0; j < C; ++j) {
+      const unsigned long long m = __ballot(live && c == j);
+      if (!m) continue;
+      int base = 0;
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ccur[j], __popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1);
+      if (live && c == j) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+    }
+    if (live) {
+      int toff = 0, tn = n_top;
+      for (int b = r - 1; b >= 0; --b) {
+        const int nh = tn >> 1;
+        if ((c >> b) & 1) {
+          toff += nh;
+          tn -= nh;
+        } else {
+          tn = nh;
+        }
+      }
+      on[toff + slot] = id[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // streaming path for the top levels (every node of the level is a Bin, <= kStreamMaxNodes
 // nodes per tree): elements never move.  node_of[t][id] holds the in-level node index of
 // every point; one level =
@@ -3664,9 +3992,28 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
       nmin /= 2;
     }
   }
+  // ... and of the levels csub_kernel will run right below them: after Lc levels the nodes hold
+  // N / 2^Lc points; between the wave kernel's 1024 and kCsCap they take r more levels on codes
+  int Lcodes = Lc;
+  if (Lc > 0 && !ctx->opt.no_csub) {
+    int64_t nmax = N, nmin = N;
+    for (int l = 0; l < Lc; ++l) {
+      nmax -= nmax / 2;
+      nmin /= 2;
+    }
+    if (nmax > kWCap && nmax <= kCsCap) {
+      int r = 0;
+      while (nmax > kWCap) {
+        nmax -= nmax / 2;
+        nmin /= 2;
+        ++r;
+      }
+      if (r <= kCsMaxR && Lc + r < L && nmin > (int64_t)f->min_leaf) Lcodes = Lc + r;
+    }
+  }
   DevBuf<uint16_t> codes;
   DevBuf<unsigned long long> code_mm;
-  uint16_t* Cd = nullptr;  // [T][L][N], the columns of levels < Lc only
+  uint16_t* Cd = nullptr;  // [T][L][N], the columns of levels < Lcodes only
   const bool codes_wanted = Lc > 0 && Lused == L && N >= ((int64_t)1 << 17) && !ctx->opt.no_codes;
   if (codes_wanted && !project_writes_codes(ctx, ds, mode) && !ctx->opt.no_pcodes &&
       (N % 8) == 0) {
@@ -3679,10 +4026,10 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     hipLaunchKernelGGL(stream_init_kernel, dim3(1), dim3(64), 0, st, code_mm.p, code_mm.p + 1, 1,
                        (unsigned int*)nullptr, 0);  // (~0, 0)
     hipLaunchKernelGGL(pcode_range_kernel<TK>, dim3((unsigned)(T * L)), dim3(256), 0, st,
-                       (const TK*)P, N, L, Lc, code_mm.p);
+                       (const TK*)P, N, L, Lcodes, code_mm.p);
     const unsigned pb = (unsigned)std::min<int64_t>((N / 8 + 255) / 256, (int64_t)ctx->n_cu * 4);
     hipLaunchKernelGGL(pcode_kernel<TK>, dim3(pb > 0 ? pb : 1, (unsigned)(T * L)), dim3(256), 0, st,
-                       (const TK*)P, N, L, Lc, (const unsigned long long*)code_mm.p, codes.p);
+                       (const TK*)P, N, L, Lcodes, (const unsigned long long*)code_mm.p, codes.p);
     RPT_HIP(hipGetLastError());
     Cd = codes.p;
   } else if (codes_wanted && project_writes_codes(ctx, ds, mode)) {
@@ -3699,20 +4046,20 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     const dim3 sgrid((unsigned)((C + 15) / 16), (unsigned)((S + 255) / 256));
     if (ds->dtype == RPT_F64)
       hipLaunchKernelGGL((sample_range_kernel<double, TK>), sgrid, dim3(256), 0, st,
-                         (const double*)ds->X, stride, S, f->d, f->R.p, C, L, Lc, code_mm.p);
+                         (const double*)ds->X, stride, S, f->d, f->R.p, C, L, Lcodes, code_mm.p);
     else if (ds->dtype == RPT_F32)
       hipLaunchKernelGGL((sample_range_kernel<float, TK>), sgrid, dim3(256), 0, st,
-                         (const float*)ds->X, stride, S, f->d, f->R.p, C, L, Lc, code_mm.p);
+                         (const float*)ds->X, stride, S, f->d, f->R.p, C, L, Lcodes, code_mm.p);
     else
       hipLaunchKernelGGL((sample_range_kernel<uint16_t, TK>), sgrid, dim3(256), 0, st,
-                         (const uint16_t*)ds->X, stride, S, f->d, f->R.p, C, L, Lc, code_mm.p);
+                         (const uint16_t*)ds->X, stride, S, f->d, f->R.p, C, L, Lcodes, code_mm.p);
     RPT_TRY(codes.alloc((size_t)T * L * N));
     CodeOut co;
     co.codes = codes.p;
     co.mm = code_mm.p;
     co.ld = N;
     co.L = L;
-    co.Lc = Lc;
+    co.Lc = Lcodes;
     bool written = false;
     RPT_TRY(project_columns(ctx, ds, f->R.p, C, mode, P, &co, &written));
     if (written) Cd = codes.p;
@@ -4022,6 +4369,9 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
 
   DevBuf<double> wgeo;                 // wsort_kernel's packed images: geometry and words
   DevBuf<unsigned long long> wpacked;
+  DevBuf<unsigned long long> cpacked;  // csub_kernel's packed codes
+  DevBuf<unsigned int> csflags;
+  DevBuf<Seg> dsegs_cs;
   // wsub_kernel launches whose overflow flags have not been looked at yet
   struct Deferred {
     int level = 0, b = 0;
@@ -4034,13 +4384,75 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
 
   for (int level = 0; level < Lused; ++level) {
     for (int b = 0; b < 2; ++b) {
-      std::vector<Seg> small, big;
+      std::vector<Seg> small, big, mid;
+      // nodes between the wave kernel's size and kCsCap whose next r levels have codes and end in
+      // split nodes: csub_kernel
+      int cs_r = 0;
+      if (Cd && !ctx->opt.no_csub) {
+        int nmax = 0, nmin = 0x7fffffff;
+        for (const PNode& pn : pending[(size_t)level])
+          if (pn.buf == b && pn.seg.n > kWCap && pn.seg.n <= kCsCap) {
+            nmax = pn.seg.n > nmax ? pn.seg.n : nmax;
+            nmin = pn.seg.n < nmin ? pn.seg.n : nmin;
+          }
+        if (nmax > 0) {
+          int r = 0;
+          while (nmax > kWCap) {
+            nmax -= nmax / 2;
+            nmin /= 2;
+            ++r;
+          }
+          if (r <= kCsMaxR && level + r <= Lcodes && !is_leaf(level + r, nmin, L, f->min_leaf)) cs_r = r;
+        }
+      }
       for (const PNode& pn : pending[(size_t)level])
-        if (pn.buf == b) (pn.seg.n > kSmallCap ? big : small).push_back(pn.seg);
-      if (small.empty() && big.empty()) continue;
+        if (pn.buf == b) {
+          if (cs_r > 0 && pn.seg.n > kWCap && pn.seg.n <= kCsCap) mid.push_back(pn.seg);
+          else (pn.seg.n > kSmallCap ? big : small).push_back(pn.seg);
+        }
+      if (small.empty() && big.empty() && mid.empty()) continue;
       ProfScope ps(ctx, RPT_PROF_SPLIT);
       int32_t* cur = bufs[b];
       int32_t* nxt = bufs[1 - b];
+      if (!mid.empty()) {
+        const unsigned S = (unsigned)mid.size();
+        RPT_TRY(upload(mid, dsegs_cs));
+        RPT_TRY(csflags.ensure((size_t)S + 1));
+        RPT_HIP(hipMemsetAsync(csflags.p, 0, ((size_t)S + 1) * 4, st));
+        RPT_TRY(cpacked.ensure((size_t)T * N));
+        const unsigned pb = (unsigned)std::min<int64_t>((N + 1023) / 1024, (int64_t)ctx->n_cu * 8);
+        hipLaunchKernelGGL(cpack_kernel, dim3(pb, T), dim3(256), 0, st, (const uint16_t*)Cd, N, L, level,
+                           cs_r, cpacked.p);
+        int csmax = 0;
+        for (const Seg& sgm : mid) csmax = sgm.n > csmax ? sgm.n : csmax;
+#define RPT_CSUB(E)                                                                              \
+  hipLaunchKernelGGL((csub_kernel<TK, E>), dim3(S, T), dim3(kCsThreads), 0, st, cur, nxt, N, P,  \
+                     (const unsigned long long*)cpacked.p, L, level, cs_r, dsegs_cs.p, f->thr.p, \
+                     f->mglo.p, f->mghi.p, f->nodes, tie_count, csflags.p)
+        // point slots per thread: fewer slots, fewer registers, more workgroups per CU
+        if (csmax <= 8 * kCsThreads) RPT_CSUB(8);
+        else if (csmax <= 12 * kCsThreads) RPT_CSUB(12);
+        else RPT_CSUB(16);
+#undef RPT_CSUB
+        RPT_HIP(hipGetLastError());
+        unsigned int nfl = 0;
+        RPT_HIP(hipMemcpyAsync(&nfl, csflags.p, 4, hipMemcpyDeviceToHost, st));
+        RPT_HIP(ctx_sync(ctx));
+        std::vector<unsigned int> fl;
+        if (nfl) {  // pivot codes shared by more points than the pool holds: the general kernels
+          fl.resize((size_t)S + 1);
+          RPT_HIP(hipMemcpy(fl.data(), csflags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+        }
+        for (unsigned i = 0; i < S; ++i) {
+          if (nfl && fl[1 + i]) {
+            (mid[i].n > kSmallCap ? big : small).push_back(mid[i]);
+            continue;
+          }
+          std::vector<Seg> rest;
+          descend(mid[i], level, 0, cs_r, rest);
+          for (const Seg& sgm : rest) pending[(size_t)level + cs_r].push_back(PNode{sgm, 1 - b});
+        }
+      }
 
       // small nodes: n <= kWCap -> one wave per subtree; kWCap < n <= kSmallCap -> one block
       std::vector<Seg> wsmall, bsmall;

@@ -962,3 +962,38 @@ def test_more_than_4096_bins_per_node(rp, ctx, oracle, option):
     with option("stream_big_node", 1000):
         f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R)
     assert_forest_equal(f, fo)
+
+
+@pytest.mark.parametrize("dtype,mode", [(np.float64, "exact"), (np.float64, "mfma"), (np.float32, "auto")])
+@pytest.mark.parametrize("n,maxnodes,kind", [
+    (300000, 32, "cont"),     # 64 nodes of 4687 points after 6 streamed levels: three levels on codes
+    (300000, 64, "cont"),     # 2343 points: two levels
+    (300001, 128, "cont"),    # 1171 / 1172 points: one level, uneven sizes
+    (262144, 16, "cont"),     # 8192 points: the kernel's capacity
+    (300000, 32, "ties"),     # rounded keys: pivot codes shared by many points (pool, then the flagged redo)
+    (300000, 32, "clump"),    # 3000 identical points: their node's pivot code overflows the pool (flagged redo)
+])
+def test_mid_size_nodes_on_packed_codes(rp, ctx, oracle, option, dtype, mode, n, maxnodes, kind):
+    """Nodes between the wave kernel's 1024 points and 8192 (10 M-point shards after their
+    streamed levels; here a smaller set with the streamed levels capped) select their medians on
+    packed 16-bit codes (csub_kernel): perm, thresholds and margins identical to the oracle's and
+    to the build with the kernel switched off, tie statistics included."""
+    d, T, min_leaf = 8, 2, 40
+    X = oracle.data_normal_dense2(4242, n, d)
+    if kind == "ties":
+        X = np.round(X * 8) / 8
+    elif kind == "clump":
+        X[:3000] = 0.5
+    X = X.astype(dtype)
+    L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
+    R, _ = oracle.forest_hyperplanes(77, T, L, 1.0 if kind != "cont" else pnz, d)
+    pm = {"exact": rp.RPT_PROJ_EXACT, "mfma": rp.RPT_PROJ_MFMA, "auto": rp.RPT_PROJ_AUTO}[mode]
+    with option("stream_maxnodes", maxnodes):
+        f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R, mode=pm)
+        with option("no_csub", 1):
+            g = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R, mode=pm)
+    assert_forest_equal(f, g)
+    assert f.stats() == g.stats()
+    if mode == "exact":
+        fo = oracle.forest_build_dense(X.astype(np.float64), R, min_leaf)
+        assert_forest_equal(f, fo)
