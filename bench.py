@@ -150,6 +150,9 @@ def other_configs(which, steps, with_cpu):
     from rptree_amd import _lib, gen
     L_ = _lib.lib()
     ctx = rp.default_context()
+    for kv in os.environ.get("RPT_BENCH_OPTIONS", "").split(","):   # A/B experiments: name=value,...
+        if "=" in kv:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     dev = torch.device("cuda", ctx.device)
     ncores = _ncores(0)
     out = {"note": "BASELINE configs[2..4] on ONE GPU: C3 whole, C4 / C5 as the tree shard of one of "

@@ -286,6 +286,11 @@ int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total);
  * entries for the exact pass, same certificate with the half rounding in the error bound; a forest
  * on which more than a quarter of a batch cannot be certified drops one tier for later batches) */
 int32_t rpt_knn_last_tier(rpt_ctx* ctx, int32_t* tier);
+/* diagnostics of the last rpt_forest_build on this context: split nodes of 1025 .. 8192 points that
+ * the packed-code kernel handed back to the general kernels (heavy ties: more than 1024 points of a
+ * node share the 16-bit code of its median; the result does not depend on it), and how many of those
+ * because a code histogram contradicted the node sizes (a defect if ever non-zero; tested to be 0) */
+int32_t rpt_build_last_handed_back(rpt_ctx* ctx, int64_t* nodes, int64_t* inconsistent);
 
 /* multi-GPU merge: G per-shard results (shard g holds trees [g*T/G, (g+1)*T/G)), gathered
  * shard-major as ids_dev[G][nq][k] etc. (e.g. by an RCCL all-gather), merged into the

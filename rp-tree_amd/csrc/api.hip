@@ -1045,6 +1045,15 @@ int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total) {
   });
 }
 
+int32_t rpt_build_last_handed_back(rpt_ctx* ctx, int64_t* nodes, int64_t* inconsistent) {
+  return guarded([&]() -> int32_t {
+    RPT_ARG(ctx && nodes && inconsistent, "NULL argument");
+    *nodes = ctx->last_csub_redo;
+    *inconsistent = ctx->last_csub_bad;
+    return RPT_OK;
+  });
+}
+
 int32_t rpt_knn_last_tier(rpt_ctx* ctx, int32_t* tier) {
   return guarded([&]() -> int32_t {
     RPT_ARG(ctx && tier, "NULL argument");

@@ -165,6 +165,10 @@ struct rpt_ctx {
   int64_t last_uncertified = 0;  // queries of the last kNN call re-run with all-f64 distances
   int64_t last_candidates = 0;
   int32_t last_tier = 0;  // ranking tier of the last fused kNN call: 0 exact, 1 f32 shadow, 2 half
+  // last build: nodes csub_kernel handed back to the general kernels (pivot codes shared by more
+  // points than its pool), and how many of those for a histogram that contradicted the node
+  // sizes (a defect: always 0)
+  int64_t last_csub_redo = 0, last_csub_bad = 0;
   int32_t n_cu = 256;
   bool prof = false;
   std::vector<rpt_prof_span> spans;

@@ -2146,9 +2146,9 @@ __global__ __launch_bounds__(kCsThreads, (E_ <= 8 ? 6 : 4)) void csub_kernel(
       for (int j = 0; j < M; ++j) {
         sn[j].poff = run;
         run += sn[j].cMid;
-        if (sn[j].hb < 0 || sn[j].cMid <= 0) s_fail = 1;  // cannot happen on a consistent histogram
+        if (sn[j].hb < 0 || sn[j].cMid <= 0) s_fail = 2;  // cannot happen on a consistent histogram
       }
-      if (run > kCsPool) s_fail = 1;
+      if (run > kCsPool && !s_fail) s_fail = 1;
       s_total = run;
     }
     // ---- d. nearest occupied codes around the pivot code: first among the points that share its
@@ -2166,7 +2166,7 @@ __global__ __launch_bounds__(kCsThreads, (E_ <= 8 ? 6 : 4)) void csub_kernel(
     __syncthreads();
     if (s_fail) {  // uniform: heavy ties -> the general kernels run this node again
       if (tid == 0) {
-        flags[1 + blockIdx.x] = 1u;
+        flags[1 + blockIdx.x] = (unsigned int)s_fail | ((unsigned int)depth << 8) | ((unsigned int)s_total << 12);
         atomicAdd(flags, 1u);
       }
       return;
@@ -2177,7 +2177,8 @@ __global__ __launch_bounds__(kCsThreads, (E_ <= 8 ? 6 : 4)) void csub_kernel(
         const CsNode a = sn[j];
         need = need || (s_lowc[j] < 0 && a.cL > 0) || (s_highc[j] > 65535 && a.cL + a.cMid < a.n);
       }
-      if (need) {  // uniform (LDS values read after the barrier)
+      __syncthreads();  // every thread has read s_lowc / s_highc before any of them changes
+      if (need) {       // uniform
 #pragma unroll
         for (int e = 0; e < E_; ++e)
           if (id[e] >= 0) {
@@ -3949,6 +3950,7 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
   const int T = f->T, L = f->L;
   hipStream_t st = ctx->stream;
   f->mode = mode;
+  ctx->last_csub_redo = ctx->last_csub_bad = 0;
 
   // deepest level that still splits a node: the largest node of level l has ceil(N / 2^l) points
   int Lused = 0;
@@ -4442,6 +4444,10 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
         if (nfl) {  // pivot codes shared by more points than the pool holds: the general kernels
           fl.resize((size_t)S + 1);
           RPT_HIP(hipMemcpy(fl.data(), csflags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+          for (unsigned i = 0; i < S; ++i) {
+            ctx->last_csub_redo += fl[1 + i] != 0;
+            ctx->last_csub_bad += (fl[1 + i] & 255u) == 2u;
+          }
         }
         for (unsigned i = 0; i < S; ++i) {
           if (nfl && fl[1 + i]) {

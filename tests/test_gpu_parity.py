@@ -988,8 +988,14 @@ def test_mid_size_nodes_on_packed_codes(rp, ctx, oracle, option, dtype, mode, n,
     L, _, pnz = oracle.tree_cfg(min_leaf, n, d)
     R, _ = oracle.forest_hyperplanes(77, T, L, 1.0 if kind != "cont" else pnz, d)
     pm = {"exact": rp.RPT_PROJ_EXACT, "mfma": rp.RPT_PROJ_MFMA, "auto": rp.RPT_PROJ_AUTO}[mode]
+    import ctypes as C
+    from rptree_amd import _lib
     with option("stream_maxnodes", maxnodes):
         f = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R, mode=pm)
+        back, bad = C.c_int64(-1), C.c_int64(-1)
+        _lib.check(_lib.lib().rpt_build_last_handed_back(ctx._h, C.byref(back), C.byref(bad)))
+        assert bad.value == 0
+        assert (back.value > 0) == (kind == "clump"), back.value
         with option("no_csub", 1):
             g = rp.forestBatch(0, L, min_leaf, T, 0, d, X, ctx=ctx, hyperplanes=R, mode=pm)
     assert_forest_equal(f, g)
