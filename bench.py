@@ -297,8 +297,9 @@ def other_configs(which, steps, with_cpu):
             tier, unc = C.c_int32(), C.c_int64()
             _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
             _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
-            kp = k + max(8, k // 2)
-            row_b = d * 2 + min(1.0, kp / max(cand, 1.0)) * d * 4 if tier.value == 2 else d * 4
+            kp = min(k + max(48, k), 47) if tier.value == 3 else k + max(8, k // 2)   # knn.hip: kp8 / kp16
+            row_b = ((d * (1 if tier.value == 3 else 2) + min(1.0, kp / max(cand, 1.0)) * d * 4)
+                     if tier.value >= 2 else d * 4)
             res = {"workload": "C4 shard: %d x %d f32 two-Gaussian mixture, %d of %d trees (one of %d GPUs), "
                                "minLeaf %d, maxDepth %d, pnz %.4f, k=%d, %d queries" %
                                (n, d, T, Tall, G, min_leaf, maxd, pnz, k, nq),
@@ -314,8 +315,9 @@ def other_configs(which, steps, with_cpu):
                                      MFMA_F32_PEAK_TF, "SURVEY 8d formula at the hyperplanes one launch covers"),
                    "knn_ranking_tier": tier.value, "knn_uncertified": unc.value,
                    "roofline_knn": _roof("knn_fused_wave<float> (one wave per query%s)" %
-                                         (", candidates ranked on the IEEE-half shadow, f32 distances for "
-                                          "the best %d" % kp if tier.value == 2 else ""),
+                                         (", candidates ranked on the %s shadow, f32 distances for "
+                                          "the best %d" % ("int8" if tier.value == 3 else "IEEE-half", kp)
+                                          if tier.value >= 2 else ""),
                                          pq["knn_topk"][0] / max(pq["knn_topk"][1], 1), pq["knn_topk"][1],
                                          nq * cand * row_b, 0.0, 0.0,
                                          "nq x (candidates x d x 2 B + %d x d x 4 B)" % kp
@@ -364,6 +366,11 @@ def other_configs(which, steps, with_cpu):
                          "algorithmic flops 2*N*d*C against the dense bf16 MFMA peak; the kernel ISSUES three "
                          "times that (r = r_hi + r_mid + r_lo keeps 24 bits: the 1e-5 tolerance)")
             roof["mfma_issued_frac"] = 3.0 * roof["mfma_frac"]
+            tier, unc = C.c_int32(), C.c_int64()
+            _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
+            _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+            kp = min(k + max(48, k), 223)                # entries the int8 tier keeps (knn.hip: kp8)
+            row_b = d * 1 + min(1.0, kp / max(cand, 1.0)) * d * 2 if tier.value == 3 else d * 2
             res = {"workload": "C5 shard: %d x %d bf16 unit-norm rows, %d of %d trees (one of %d GPUs), minLeaf %d, "
                                "maxDepth %d, pnz %.4f, k=%d, %d queries" %
                                (n, d, T, Tall, G, min_leaf, maxd, pnz, k, nq),
@@ -374,9 +381,14 @@ def other_configs(which, steps, with_cpu):
                    "build_breakdown_ms": {"projection_total": pb["project"][0] / steps,
                                           "split_total": pb["split"][0] / steps},
                    "roofline": roof,
-                   "roofline_knn": _roof("knn_fused<bf16>", pq["knn_topk"][0] / max(pq["knn_topk"][1], 1),
-                                         pq["knn_topk"][1], nq * cand * d * 2, 0.0, 0.0,
-                                         "nq x candidates x d x 2 B")}
+                   "knn_ranking_tier": tier.value, "knn_uncertified": unc.value,
+                   "roofline_knn": _roof("knn_fused<bf16>%s" %
+                                         (" (candidates ranked on the int8 shadow, f32 distances over the bf16 "
+                                          "rows of the best %d)" % kp if tier.value == 3 else ""),
+                                         pq["knn_topk"][0] / max(pq["knn_topk"][1], 1),
+                                         pq["knn_topk"][1], nq * cand * row_b, 0.0, 0.0,
+                                         "nq x candidates x (d x 1 B int8 rows + k'/candidates x d x 2 B bf16 rows)"
+                                         if tier.value == 3 else "nq x candidates x d x 2 B")}
             if with_cpu:
                 from oracle import oracle as orc
                 Xh = np.empty((n, d), dtype=np.float32)
@@ -613,7 +625,7 @@ def main():
     _lib.check(L_.rpt_knn_last_candidates(ctx._h, C.byref(cand_total)))
     uncertified = C.c_int64()
     _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(uncertified)))
-    knn_tier = C.c_int32()         # 0 all-f64, 1 f32 shadow, 2 IEEE-half shadow (timed batches)
+    knn_tier = C.c_int32()         # 0 all-f64, 1 f32 shadow, 2 IEEE-half shadow, 3 int8 shadow (timed batches)
     _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(knn_tier)))
 
     # ---- recall (untimed) ----
@@ -888,18 +900,19 @@ def main():
         cand_q = cand_total.value / float(max(nq, 1))
         tier = knn_tier.value
         pre32 = tier > 0
-        sb = 2 if tier == 2 else 4                      # bytes per element of the ranking shadow
-        kp = k + max(8, k // 2) if tier == 2 else k + max(6, k // 2)
+        sb = {3: 1, 2: 2}.get(tier, 4)                  # bytes per element of the ranking shadow
+        kp = (min(k + max(48, k), 223) if tier == 3 else       # knn.hip: kp8 / kp16 / prefilter_keep
+              k + max(8, k // 2) if tier == 2 else k + max(6, k // 2))
         topk_ms = prof["knn_topk"][0] / max(prof["knn_topk"][1], 1)
         knn_bytes = nq * (cand_q * d * sb + kp * d * 8) if pre32 else nq * cand_q * d * 8
-        if tier == 2:
+        if tier >= 2:
             knn_traffic = None                          # the committed PMC passes are the f32 tier's
         knn_ach = knn_bytes / (topk_ms * 1e-3) / 1e9 if topk_ms > 0 else 0.0
         roof_knn = {"bound": "hbm", "achieved": knn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": knn_ach / HBM_PEAK_GBS, "traffic": knn_traffic,
                     "traffic_source": traffic_source if knn_traffic else None,
                     "kernel": "knn_fused (%s-shadow ranking + exact f64 distances of the best k')"
-                    % ("half" if tier == 2 else "f32") if pre32 else "knn_fused (all-f64 distances)",
+                    % {3: "int8", 2: "half"}.get(tier, "f32") if pre32 else "knn_fused (all-f64 distances)",
                     "avg_launch_ms": topk_ms,
                     "algorithmic_bytes_per_launch": knn_bytes,
                     "bytes_formula": "nq x (candidates x d x %d B shadow rows + k' x d x 8 B exact "
@@ -944,7 +957,8 @@ def main():
                     "method": "all-f64 distances" if not pre32 else
                     "candidates ranked on %s of X, exact left-fold f64 distances for the best %d, "
                     "cut certified per query (exact fallback); results identical to the all-f64 "
-                    "kernel" % ("an IEEE-half shadow" if tier == 2 else "an f32 shadow", kp),
+                    "kernel" % ({3: "an int8 shadow (one scale, integer ranking values)",
+                                 2: "an IEEE-half shadow"}.get(tier, "an f32 shadow"), kp),
                     "exchange": None if world == 1 else
                     "one ncclAllGather of %d B records per rank on the ctx streams "
                     "(rpt_knn_sharded_dev), merge on every device" % sharded.record_layout(nq, k)[0],

@@ -232,6 +232,8 @@ const OptDesc kOptions[] = {
     {"knn_no_pre32", &rpt_options::knn_no_pre32},
     {"knn_no_pre16", &rpt_options::knn_no_pre16},
     {"knn_kp16", &rpt_options::knn_kp16},
+    {"knn_no_pre8", &rpt_options::knn_no_pre8},
+    {"knn_kp8", &rpt_options::knn_kp8},
     {"knn_csr_pre32", &rpt_options::knn_csr_pre32},
     {"knn_general", &rpt_options::knn_general},
     {"comm_force_exchange", &rpt_options::comm_force_exchange},
@@ -617,6 +619,7 @@ int32_t rpt_dataset_free(rpt_dataset* ds) {
     if (!ds) return RPT_OK;
     if (ds->shadow32) dev_free(ds->shadow32);
     if (ds->shadow16) dev_free(ds->shadow16);
+    if (ds->shadow8) dev_free(ds->shadow8);
     if (ds->shadow_col16) dev_free(ds->shadow_col16);
     if (ds->shadow_ell) dev_free(ds->shadow_ell);
     if (ds->csr_split) dev_free(ds->csr_split);

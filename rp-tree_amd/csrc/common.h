@@ -146,6 +146,8 @@ struct rpt_options {
   int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
   int64_t knn_no_pre16 = 0;     // kNN: the prefilter ranks on the f32 shadow, never on the f16 one
   int64_t knn_kp16 = 0;         // kNN: entries the f16 prefilter keeps (0 = k + max(8, k / 2))
+  int64_t knn_no_pre8 = 0;      // kNN: never rank on the int8 shadow (the half shadow is the first tier)
+  int64_t knn_kp8 = 0;          // kNN: entries the int8 prefilter keeps (0 = k + max(48, k), capped by the kernel variant)
   int64_t knn_csr_pre32 = 0;    // kNN: rank CSR f64 rows on their (u16 column, f32 value) shadow
   int64_t knn_general = 0;      // kNN: unfused general path
   int64_t comm_force_exchange = 0;  // sharded kNN: a one-rank communicator runs record -> all-gather -> merge too
@@ -164,7 +166,7 @@ struct rpt_ctx {
   size_t pin_cap = 0, pin_off = 0;
   int64_t last_uncertified = 0;  // queries of the last kNN call re-run with all-f64 distances
   int64_t last_candidates = 0;
-  int32_t last_tier = 0;  // ranking tier of the last fused kNN call: 0 exact, 1 f32 shadow, 2 half
+  int32_t last_tier = 0;  // ranking tier of the last fused kNN call: 0 exact, 1 f32 shadow, 2 half, 3 int8
   // last build: nodes csub_kernel handed back to the general kernels (pivot codes shared by more
   // points than its pool), and how many of those for a histogram that contradicted the node
   // sizes (a defect: always 0)
@@ -219,6 +221,12 @@ struct rpt_dataset {
   // shadow, a quarter of the f64 bytes; shadow16_state: 0 = not tried, 1 = there, -1 = unusable
   mutable uint16_t* shadow16 = nullptr;
   mutable int shadow16_state = 0;
+  // int8 shadow (round 3): c = rint(x / s8_scale) clamped to [-127, 127], one global scale, rows of
+  // d bytes (d % 16 == 0) — an eighth of the f64 bytes, 1 M x 128 rows fit the 256 MB Infinity
+  // Cache; s8_emax = max over the rows of |x - s c| (what the certificate charges a dropped row)
+  mutable int8_t* shadow8 = nullptr;
+  mutable int shadow8_state = 0;  // as shadow16_state
+  mutable double s8_scale = 0.0, s8_emax = 0.0;
   mutable uint16_t* shadow_col16 = nullptr;  // CSR (d <= 65536): col as u16
   mutable int64_t max_rowlen = 0;            // CSR: the longest row
   // round 3: CSR f64 rows again as a fixed-width table of (u16 column | IEEE-half value << 16)
@@ -245,6 +253,7 @@ struct rpt_forest {
   // equal distances: e.g. the queries are data points, found once per tree): later batches on this
   // forest go straight to the all-f64 kernel
   bool prefilter_off = false;
+  bool pre8_off = false;   // ... and one more: the int8 shadow failed too many cuts here
   bool pre16_off = false;  // ... the same one tier up: the f16 shadow failed too many cuts here
   int64_t nodes = 0;         // 2^L - 1
   rpt::DevBuf<int32_t> perm;  // [T][N] final leaf-ordered permutation

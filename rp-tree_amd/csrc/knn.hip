@@ -662,6 +662,133 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
   }
 }
 
+// ---- int8 ranking tier (round 3) ----------------------------------------------------------
+// The dataset's int8 shadow holds c = rint(x / s) clamped to [-127, 127] with ONE scale s for the
+// whole dataset, stored offset-binary (c + 128), rows of d bytes (d % 16 == 0): an eighth of the f64
+// bytes, a 128-element row is one cache line.  The query is quantised SIXTEEN bits deep on the
+// same grid, g = rint(256 q / s) clamped to the int16 range, kept as two byte planes (g = 256 H +
+// Lo, H + 128 and Lo packed four to a word in LDS), and a candidate is ranked on the INTEGER
+//     I = sum (g_j - 256 c_j)^2 = 65536 sum cu^2 - 131072 sum cu hu - 512 sum cu lo + K(query),
+// cu = c + 128, hu = H + 128 (the sums of cu alone cancel), K = sum g^2 + 2^24 sum hu + 2^16 sum lo
+// - 2^30 d: three v_dot4_u32_u8 per four elements, exact — no rounding anywhere in the ranking
+// value (an 8-bit query doubled the uncertainty of the cut: at C2 17 candidates inside it instead of 9).
+// By the triangle inequality the exact distance of a row x obeys
+//     | |q - x| - (s / 256) sqrt(I) | <= |q - (s / 256) g| + |x - s c| <= eq + emax,
+// eq computed per query in f64 (clipped elements included), emax = the dataset's largest
+// |x - s c| (measured when the shadow is built), so a cut is certified exactly like the other
+// tiers' (knn_fused_kernel), and an uncertified query is answered by the exact kernel.
+struct Sh8 {
+  double s, emax;  // scale, max row error; s == 0: the tier is not in use
+};
+
+// quantised query -> planes[0 .. d/4) = hu words, planes[d/4 .. d/2) = lo words; the caller sums
+// kq (this thread's share of K without the - 2^30 d term) and e2 (its share of eq^2) over its threads
+__device__ inline void quantise_query(const double* qsrc_d, const float* qsrc_f, int d, double s,
+                                      unsigned int* planes, int tid, int nthr, double& kq, double& e2) {
+  kq = 0.0;
+  e2 = 0.0;
+  const double inv = 256.0 / s, g2x = s / 256.0;
+  const int nw = d / 4;
+  for (int w = tid; w < nw; w += nthr) {
+    unsigned int wh = 0, wl = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double v = qsrc_d ? qsrc_d[4 * w + b] : (double)qsrc_f[4 * w + b];
+      double c = rint(v * inv);
+      c = c < -32768.0 ? -32768.0 : (c > 32767.0 ? 32767.0 : c);  // NaN stays NaN: e2 turns NaN, no certificate
+      const int g = c == c ? (int)c : 0;
+      const double e = v - g2x * (double)g;
+      e2 += e * e;
+      const unsigned int hu = (unsigned int)((g >> 8) + 128), lo = (unsigned int)(g & 255);
+      kq += (double)g * (double)g + 16777216.0 * (double)hu + 65536.0 * (double)lo;  // exact: < 2^53
+      wh |= hu << (8 * b);
+      wl |= lo << (8 * b);
+    }
+    planes[w] = wh;
+    planes[nw + w] = wl;
+  }
+}
+
+// integer squared distances (see above) of the candidates [first, fill) -> cdist (exact integers
+// as doubles, in units of (s / 256)^2)
+template <int INFL = 16>
+__device__ __forceinline__ void batch_distances_i8(const uint8_t* __restrict__ X8, int d, const int* cid,
+                                                   double* cdist, const unsigned int* planes, double kq,
+                                                   int first, int fill, int slot, int nslots, int lane) {
+  const int lpr = d / 16;  // lanes one row needs with 16-byte loads
+  const int nw = d / 4;
+  if (lpr <= 32 && (lpr & (lpr - 1)) == 0) {
+    const int rpw = 64 / lpr, sub = lane / lpr, piece = lane % lpr;
+    const uint4 hv = reinterpret_cast<const uint4*>(planes)[piece];
+    const uint4 lv = reinterpret_cast<const uint4*>(planes + nw)[piece];
+    const unsigned int hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
+    for (int i0 = first + slot * INFL * rpw; i0 < fill; i0 += nslots * INFL * rpw) {
+      uint4 x[INFL];
+#pragma unroll
+      for (int u = 0; u < INFL; ++u) {
+        const int i = i0 + u * rpw + sub;
+        x[u] = *reinterpret_cast<const uint4*>(X8 + (int64_t)cid[i < fill ? i : i0] * d + piece * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < INFL; ++u) {
+        const unsigned int xw[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+        unsigned int a = 0, b = 0, cc = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a = __builtin_amdgcn_udot4(xw[w], hw[w], a, false);
+          b = __builtin_amdgcn_udot4(xw[w], lw[w], b, false);
+          cc = __builtin_amdgcn_udot4(xw[w], xw[w], cc, false);
+        }
+        for (int o = lpr >> 1; o > 0; o >>= 1) {
+          a += __shfl_xor(a, o);
+          b += __shfl_xor(b, o);
+          cc += __shfl_xor(cc, o);
+        }
+        const int i = i0 + u * rpw + sub;
+        if (piece == 0 && i < fill)
+          cdist[i] = 65536.0 * (double)cc - 131072.0 * (double)a - 512.0 * (double)b + kq;
+      }
+    }
+    return;
+  }
+  // long rows: one row per load instruction (lanes beyond the row idle), eight rows in flight
+  for (int i0 = first + slot * 8; i0 < fill; i0 += nslots * 8) {
+    unsigned int a[8], b[8], cc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = b[u] = cc[u] = 0;
+    for (int p = lane; p < lpr; p += 64) {
+      const uint4 hv = reinterpret_cast<const uint4*>(planes)[p];
+      const uint4 lv = reinterpret_cast<const uint4*>(planes + nw)[p];
+      const unsigned int hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
+      uint4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        x[u] = *reinterpret_cast<const uint4*>(X8 + (int64_t)cid[i0 + u < fill ? i0 + u : i0] * d + p * 16);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned int xw[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a[u] = __builtin_amdgcn_udot4(xw[w], hw[w], a[u], false);
+          b[u] = __builtin_amdgcn_udot4(xw[w], lw[w], b[u], false);
+          cc[u] = __builtin_amdgcn_udot4(xw[w], xw[w], cc[u], false);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      unsigned int ta = a[u], tb = b[u], tc = cc[u];
+      for (int o = 32; o > 0; o >>= 1) {
+        ta += __shfl_xor(ta, o);
+        tb += __shfl_xor(tb, o);
+        tc += __shfl_xor(tc, o);
+      }
+      if (lane == 0 && i0 + u < fill)
+        cdist[i0 + u] = 65536.0 * (double)tc - 131072.0 * (double)ta - 512.0 * (double)tb + kq;
+    }
+  }
+}
+
 // CSR data for the fused kernel (SVector rows, Internal.hs:92-93): data rows and query rows
 struct CsrPtrs {
   const int64_t* rowptr;
@@ -937,10 +1064,16 @@ constexpr int kFC = 2048;     // candidates per batch
 constexpr int kFR = 512;      // leaf ranges per query in LDS
 constexpr int kFK = 64;       // largest k served by the arg-min selection
 constexpr int kFKx = kFK + kLfMargin;  // capacity of the running best list (see kLfMargin)
+// the workgroup kernel's prefilter tiers may keep more than that: the threshold selection costs
+// the same whatever it keeps, and the int8 tier needs a wide margin at the cut (see Sh8)
+constexpr int kBK = 224;
+constexpr int kBKx = kBK + kLfMargin;
+constexpr int kSelList = 512;  // select_packed's candidate list (in the idle distance slab)
 constexpr int kVoteCap = 16384;  // candidates of one query the voting mode can count (64 KB of LDS)
 
-template <class TD, class TK, bool PRE32, bool CSR = false>
-__global__ __launch_bounds__(256) void knn_fused_kernel(
+template <class TD, class TK, bool PRE32, bool CSR = false, bool I8 = false /* PRE32 on the int8 shadow */>
+// (three workgroups per CU is what the 52 KB slab allows: keep the registers at that occupancy)
+__global__ __launch_bounds__(256, 3) void knn_fused_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
     const double* __restrict__ thr, const double* __restrict__ mglo,
     const double* __restrict__ mghi, int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T,
@@ -951,7 +1084,12 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     const void* __restrict__ Xf /* PRE32: f32 (or, sh16, IEEE half) shadow of X */,
     double xmax /* max row norm */,
     int k1 /* PRE32: entries kept by the shadow pass, the last one = the first excluded */,
-    CsrPtrs csr /* CSR: X / Q are null, rows and queries are SVectors */, int sh16 = 0) {
+    CsrPtrs csr /* CSR: X / Q are null, rows and queries are SVectors */, int sh16 = 0,
+    Sh8 sh8 = Sh8{0.0, 0.0} /* s > 0: Xf is the int8 shadow (see Sh8) */,
+    unsigned long long* dbg = nullptr /* debug_stamps: phase clocks of one workgroup */) {
+  int dbgi = 0;
+#define KSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = clock64(); } while (0)
+  KSTAMP();
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* cdist = reinterpret_cast<double*>(smem);                 // [kFC]
@@ -961,10 +1099,10 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   int* rn = reinterpret_cast<int*>(rpoff + kFR);                   // [kFR]
   int* tcnt = rn + kFR;                                            // [1024] per-tree counts
   int* trng = tcnt + 1024;                                         // [1024]
-  double* bdist = reinterpret_cast<double*>(trng + 1024);          // [kFKx]
-  int* bid = reinterpret_cast<int*>(bdist + kFKx);                 // [kFKx]
-  int* bpos = bid + kFKx;                                          // [kFKx]
-  TA* qs = reinterpret_cast<TA*>(bpos + kFKx);                     // [d]
+  double* bdist = reinterpret_cast<double*>(trng + 1024);          // [kBKx]
+  int* bid = reinterpret_cast<int*>(bdist + kBKx);                 // [kBKx]
+  int* bpos = bid + kBKx;                                          // [kBKx]
+  TA* qs = reinterpret_cast<TA*>(bpos + kBKx);                     // [d]
   float* qs32 = reinterpret_cast<float*>(qs + d);                  // [d] (PRE32)
   // voting mode (dedup_vote >> 8 = v > 0, RPTree.hs:464-478 counts / keepCounts): all candidate
   // ids of the query, sorted, so that the ids found in at least v trees can be picked out
@@ -974,9 +1112,9 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   __shared__ double s_qn;
   __shared__ double s_red_d[8];
   __shared__ int s_red_p[8], s_red_i[8];
-  __shared__ unsigned long long wb_key[4][kFK];  // select_packed: every wave's winners
-  __shared__ int wb_id[4][kFK];
   __shared__ int s_wk[4];
+  __shared__ double s_q8e[4], s_q8k[4];  // int8 tier: the waves' shares of eq^2 and of K (see Sh8)
+  __shared__ unsigned int s_mm[4], s_lcnt;  // select_packed: the waves' thresholds, the list length
   const int vote = PRE32 ? 0 : (dedup_vote >> 8);
   const int dedup = vote > 0 ? 0 : (dedup_vote & 3);  // kept ids are distinct
 
@@ -1006,22 +1144,52 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     }
   } else {
     for (int j = tid; j < d; j += 256) qs[j] = ld<TD>(Q + q * d + j);
-    if (PRE32)
+    if constexpr (I8) {  // int8 tier: the quantised query's byte planes in the f32 copy's place
+      __syncthreads();
+      double kqp, e2p;
+      if constexpr (sizeof(TA) == 8)
+        quantise_query(reinterpret_cast<const double*>(qs), nullptr, d, sh8.s,
+                       reinterpret_cast<unsigned int*>(qs32), tid, 256, kqp, e2p);
+      else
+        quantise_query(nullptr, reinterpret_cast<const float*>(qs), d, sh8.s,
+                       reinterpret_cast<unsigned int*>(qs32), tid, 256, kqp, e2p);
+      for (int o = 32; o > 0; o >>= 1) {
+        kqp += __shfl_xor(kqp, o);  // integer-valued doubles below 2^53: exact in any order
+        e2p += __shfl_xor(e2p, o);
+      }
+      if (lane == 0) {
+        s_q8k[wave] = kqp;
+        s_q8e[wave] = e2p;
+      }
+    } else if (PRE32)
       for (int j = tid; j < d; j += 256) qs32[j] = (float)ld<TD>(Q + q * d + j);
   }
 
-  // ---- traversal 1: counts per tree ----
+  // ---- traversal: ONE pass in the usual case.  Thread = tree; the leaf ranges a tree reaches go
+  // to its S slots (in the batch slab, idle until the first fill) and are counted in any case;
+  // after the scan over the trees they are compacted in tree order.  A tree that outgrows its
+  // slots (or T > kFR) sends the workgroup through the second, emitting traversal.  (Round 3: two
+  // traversals of 13 dependent node loads each were a fifth of a C2 query's life.) ----
+  const int S = T <= kFR ? kFR / T : 0;
+  int64_t* spoff = reinterpret_cast<int64_t*>(cdist);  // [kFR]
+  int* sn = reinterpret_cast<int*>(cdist + kFR);       // [kFR]
+  int slots_short = 0;
   for (int t = tid; t < T; t += 256) {
     int nc = 0, nr = 0;
     traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
-                 nq, L, min_leaf, N, [&](int, int n) {
+                 nq, L, min_leaf, N, [&](int off, int n) {
+                   if (nr < S) {
+                     spoff[t * S + nr] = (int64_t)t * N + off;
+                     sn[t * S + nr] = n;
+                   }
                    nc += n;
                    ++nr;
                  });
     tcnt[t] = nc;
     trng[t] = nr;
+    slots_short |= nr > S;
   }
-  __syncthreads();
+  const int second_pass = __syncthreads_or(slots_short);
   if (tid == 0) {  // exclusive scans over <= 1024 trees
     int c = 0, r = 0;
     for (int t = 0; t < T; ++t) {
@@ -1035,7 +1203,12 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     s_nr = r;
   }
   __syncthreads();
+  KSTAMP();  // 1: query + traversal + scan
   const int nr_tot = s_nr, nc_tot = s_nc;
+  constexpr bool i8 = I8;
+  static_assert(!I8 || (PRE32 && !CSR), "the int8 tier is a dense prefilter");
+  const double q8k = i8 ? s_q8k[0] + s_q8k[1] + s_q8k[2] + s_q8k[3] - 1073741824.0 * (double)d : 0.0;
+  const double q8eq = i8 ? sqrt(s_q8e[0] + s_q8e[1] + s_q8e[2] + s_q8e[3]) : 0.0;
   if (nr_tot > kFR) {  // too many leaf ranges for the slab: general path
     if (tid == 0) {
       ovf_flags[q] = 1u;
@@ -1044,15 +1217,44 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     return;
   }
   if (tid == 0 && !rerun) atomicAdd(cand_total, (unsigned long long)nc_tot);
-  // ---- traversal 2: ranges in tree order ----
-  for (int t = tid; t < T; t += 256) {
-    int r = trng[t];
-    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
-                 nq, L, min_leaf, N, [&](int off, int n) {
-                   rpoff[r] = (int64_t)t * N + off;
-                   rn[r] = n;
-                   ++r;
-                 });
+  // ---- ranges in tree order + rstart[r] = candidates before range r (the batches are filled by
+  // position: a binary search over rstart, every load of a batch in flight at once).  rstart takes
+  // tcnt's place: a thread reads its trees' scan values before anyone overwrites them ----
+  int* rstart = tcnt;  // [nr_tot + 1] <= kFR + 1
+  {
+    int r0[4], r1[4], c0[4];  // T <= 1024: at most four trees per thread
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tid + 256 * u;
+      r0[u] = t < T ? trng[t] : 0;
+      r1[u] = t < T ? (t + 1 < T ? trng[t + 1] : nr_tot) : 0;
+      c0[u] = t < T ? tcnt[t] : 0;
+    }
+    __syncthreads();
+    for (int u = 0; u < 4; ++u) {
+      const int t = tid + 256 * u;
+      if (t >= T) break;
+      int r = r0[u], c = c0[u];
+      if (!second_pass) {
+        for (int i2 = 0; r < r1[u]; ++i2, ++r) {
+          const int n = sn[t * S + i2];
+          rpoff[r] = spoff[t * S + i2];
+          rn[r] = n;
+          rstart[r] = c;
+          c += n;
+        }
+      } else {
+        traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q,
+                     nq, L, min_leaf, N, [&](int off, int n) {
+                       rpoff[r] = (int64_t)t * N + off;
+                       rn[r] = n;
+                       rstart[r] = c;
+                       c += n;
+                       ++r;
+                     });
+      }
+    }
+    if (tid == 0) rstart[nr_tot] = nc_tot;
   }
   __syncthreads();
 
@@ -1104,15 +1306,79 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   // the ksel smallest of its own quarter of the batch, the four lists meet in LDS and the ksel
   // smallest of those 4 x ksel keys — the batch's ksel smallest are among them — are ranked by
   // counting.  Two barriers per batch instead of one per round (C2: 17 rounds per 2048 entries).
-  auto select_packed = [&](int fill, int ksel) -> int {
+  // Round 3 (late): the ksel smallest through a THRESHOLD instead of ksel rounds.  The value half of
+  // a key is the bit pattern of a non-negative float, monotone as an unsigned integer.  An upper
+  // bound tau of the ksel-th smallest value: once a full list exists, the value of its last entry
+  // (the list sits at the front of the batch); before that, every wave takes the ceil(ksel / 4)-th
+  // smallest of its 64 per-thread minima (ranked by counting over lane reads) and tau is the largest
+  // of the four — at least ksel entries lie at or below it.  The entries <= tau (ksel plus a few)
+  // are compacted into a list and ranked by counting on the full keys: three barriers per batch
+  // whatever ksel is (the rounds cost 0.03 ms per kept entry and 10 000 queries at C2).  A list of
+  // more than 256 entries (values tied by the hundred) falls back to the rounds.
+  auto select_packed = [&](int fill, int ksel, int have /* entries of a list from earlier batches */) -> int {
     constexpr int E = kFC / 256;
     unsigned long long key[E];
+    unsigned int vmin = ~0u;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int i = tid + 256 * e;
       key[e] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | (unsigned int)cpos[i]
                         : ~0ULL;
+      const unsigned int v = (unsigned int)(key[e] >> 32);
+      if (i < fill) vmin = v < vmin ? v : vmin;
     }
+    unsigned int tau;
+    if (have == ksel) {
+      tau = __float_as_uint((float)bdist[ksel - 1]);
+    } else {
+      const int r = (ksel + 3) / 4;
+      int cnt = 0;
+      for (int j2 = 0; j2 < 64; ++j2) {
+        const unsigned int o = __shfl(vmin, j2);
+        cnt += (o < vmin || (o == vmin && j2 < lane)) ? 1 : 0;
+      }
+      const unsigned long long hit = __ballot(cnt == r - 1);
+      tau = __shfl(vmin, __ffsll((long long)hit) - 1);  // ~0u when the wave holds fewer than r entries
+      if (lane == 0) s_mm[wave] = tau;
+    }
+    if (tid == 0) s_lcnt = 0u;
+    __syncthreads();  // (every thread has read its cdist entries: the list below reuses that slab)
+    if (have != ksel) {
+      tau = s_mm[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) tau = s_mm[w] > tau ? s_mm[w] : tau;
+    }
+    unsigned long long* lkey = reinterpret_cast<unsigned long long*>(cdist);  // [kSelList]
+    int* lidx = reinterpret_cast<int*>(cdist + kSelList);                      // [kSelList]
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (key[e] != ~0ULL && (unsigned int)(key[e] >> 32) <= tau) {
+        const unsigned int slot = atomicAdd(&s_lcnt, 1u);
+        if (slot < (unsigned int)kSelList) {
+          lkey[slot] = key[e];
+          lidx[slot] = tid + 256 * e;
+        }
+      }
+    __syncthreads();
+    const int n = (int)s_lcnt;
+    if (n <= kSelList) {
+      for (int t2 = tid; t2 < n; t2 += 256) {
+        const unsigned long long mine = lkey[t2];
+        int rank = 0;
+        for (int j2 = 0; j2 < n; ++j2) rank += lkey[j2] < mine;
+        if (rank < ksel) {
+          bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
+          bid[rank] = cid[lidx[t2]];
+          bpos[rank] = (int)(unsigned int)mine;
+        }
+      }
+      __syncthreads();
+      return n < ksel ? n : ksel;
+    }
+    // (the winners' lists of the fallback live in the same idle slab: 4 x kBKx keys, then ids)
+    unsigned long long (*wb_key)[kBKx] = reinterpret_cast<unsigned long long (*)[kBKx]>(cdist);
+    int (*wb_id)[kBKx] = reinterpret_cast<int (*)[kBKx]>(cdist + 4 * kBKx);
+    // ---- fallback: ksel wave-local rounds, the four lists merged by rank counting ----
     for (int r = 0; r < ksel; ++r) {
       unsigned long long m = key[0];
 #pragma unroll
@@ -1135,26 +1401,27 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
         }
     }
     __syncthreads();
-    const int tot = 4 * ksel;  // <= 4 * kFK = 256 threads
-    unsigned long long mine = ~0ULL;
-    int mid = -1;
-    if (tid < tot) {
-      mine = wb_key[tid / ksel][tid % ksel];
-      mid = wb_id[tid / ksel][tid % ksel];
-    }
-    int rank = 0x7fffffff;
-    if (tid < tot && mine != ~0ULL) {
-      rank = 0;
+    const int tot = 4 * ksel;
+    int myvalid = 0;
+    for (int t2 = tid; t2 < tot; t2 += 256) {
+      const unsigned long long mine = wb_key[t2 / ksel][t2 % ksel];
+      if (mine == ~0ULL) continue;
+      ++myvalid;
+      int rank = 0;
       for (int w = 0; w < 4; ++w)
         for (int r = 0; r < ksel; ++r) rank += wb_key[w][r] < mine;
-    }
-    if (rank < ksel) {
-      bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
-      bid[rank] = mid;
-      bpos[rank] = (int)(unsigned int)mine;
+      if (rank < ksel) {
+        bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
+        bid[rank] = wb_id[t2 / ksel][t2 % ksel];
+        bpos[rank] = (int)(unsigned int)mine;
+      }
     }
     // entries in all = the valid keys of the four lists, at most ksel are kept
-    const int nvalid = __syncthreads_count(tid < tot && mine != ~0ULL);
+    for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+    if (lane == 0) s_mm[wave] = (unsigned int)myvalid;
+    __syncthreads();
+    const int nvalid = (int)(s_mm[0] + s_mm[1] + s_mm[2] + s_mm[3]);
+    __syncthreads();  // s_mm is the next batch's threshold exchange
     return nvalid < ksel ? nvalid : ksel;
   };
   auto select = [&](int fill, int ksel, int dedup) -> int {
@@ -1228,10 +1495,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
   };
 
   int best = 0;       // entries of the running best list
-  int r_next = 0;     // next range to consume
-  int r_done = 0;     // candidates of range r_next already consumed
   int pos_base = 0;   // candidate position of the next unconsumed candidate
-  while ((vote > 0 ? vsrc < nc_tot : r_next < nr_tot) || best == 0) {
+  while ((vote > 0 ? vsrc < nc_tot : pos_base < nc_tot) || best == 0) {
     // ---- fill the batch: best list first (keeps its positions), then new candidates ----
     for (int i = tid; i < best; i += 256) {
       cdist[i] = bdist[i];
@@ -1264,27 +1529,43 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       vsrc += 256;
       __syncthreads();  // s_wk is rewritten by the next round
     }
-    // every thread walks the same range list (uniform control flow)
-    int rr = r_next, rd = r_done, pb = pos_base;
-    while (vote == 0 && rr < nr_tot && fill < kFC) {
-      int take = rn[rr] - rd;
+    // the batch's new candidates by position: slot s holds candidate pos_base + s, whose range is
+    // found by a fixed nine-step search over rstart; a thread's (up to) eight perm loads are all
+    // issued before the first is used (walking the ranges one after the other, a dependent global
+    // load per range, was a sixth of a C2 query's life)
+    if (vote == 0) {
+      int take = nc_tot - pos_base;
       if (take > kFC - fill) take = kFC - fill;
-      for (int i = tid; i < take; i += 256) {
-        cid[fill + i] = perm[rpoff[rr] + rd + i];
-        cpos[fill + i] = pb + i;
+      constexpr int EF = kFC / 256;
+      int64_t addr[EF];
+#pragma unroll
+      for (int e = 0; e < EF; ++e) {
+        const int s2 = tid + 256 * e;
+        const int c = pos_base + (s2 < take ? s2 : 0);
+        int lo = 0;
+#pragma unroll
+        for (int step = kFR / 2; step > 0; step >>= 1) {
+          const int m = lo + step;
+          if (m < nr_tot && rstart[m] <= c) lo = m;
+        }
+        addr[e] = rpoff[lo] + (c - rstart[lo]);
+      }
+      int32_t idv[EF];
+#pragma unroll
+      for (int e = 0; e < EF; ++e) idv[e] = tid + 256 * e < take ? perm[addr[e]] : 0;
+#pragma unroll
+      for (int e = 0; e < EF; ++e) {
+        const int s2 = tid + 256 * e;
+        if (s2 < take) {
+          cid[fill + s2] = idv[e];
+          cpos[fill + s2] = pos_base + s2;
+        }
       }
       fill += take;
-      rd += take;
-      pb += take;
-      if (rd == rn[rr]) {
-        ++rr;
-        rd = 0;
-      }
+      pos_base += take;
     }
-    r_next = rr;
-    r_done = rd;
-    pos_base = pb;
     __syncthreads();
+    KSTAMP();  // batch fill
     // ---- distances of the new candidates ----
     if constexpr (CSR && PRE32) {
       if (sh16)
@@ -1298,7 +1579,11 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       batch_distances_csr<TD>(csr.rowptr, csr.col, static_cast<const TD*>(csr.val), csr.nnz, cid,
                               cdist, qsd, s_qn, first_new, fill, wave, lane);
     else if constexpr (PRE32) {
-      if (sh16)  // half rows: a quarter of the f64 bytes (the query stays f32)
+      if constexpr (I8)  // int8 rows: an eighth of the f64 bytes, integer ranking values
+        batch_distances_i8<8>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
+                              reinterpret_cast<const unsigned int*>(qs32), q8k, first_new, fill, wave, 4,
+                              lane);
+      else if (sh16)  // half rows: a quarter of the f64 bytes (the query stays f32)
         batch_distances<_Float16, float, 16, false>(static_cast<const _Float16*>(Xf), d, cid, cdist, qs32,
                                                     first_new, fill, wave, 4, lane);
       else
@@ -1309,11 +1594,13 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     else
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8)>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     __syncthreads();
+    KSTAMP();  // distances
     // dense f64 rows ranked on butterfly sums keep kLfMargin entries more (finalize_leftfold)
     const int ksel = (!CSR && std::is_same<TD, double>::value) ? k + kLfMargin : k;
-    const int nb = PRE32 ? select_packed(fill, k1) : pack32 ? select_packed(fill, k) : select(fill, ksel, dedup);
+    const int nb = PRE32 ? select_packed(fill, k1, best) : pack32 ? select_packed(fill, k, best) : select(fill, ksel, dedup);
     best = nb;
-    if (vote > 0 ? vsrc >= nc_tot : r_next >= nr_tot) break;
+    KSTAMP();  // selection
+    if (vote > 0 ? vsrc >= nc_tot : pos_base >= nc_tot) break;
   }
   if constexpr (PRE32 && CSR) {
     // ---- refine (CSR): exact distances of the kept entries; certify the cut on SQUARED distances.
@@ -1368,7 +1655,11 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
     // f32 pass dropped has an exact distance >= F - err(F), F = the smallest dropped f32
     // distance.  If that is not above the exact k-th distance the query goes to the exact path.
     const bool cut = best == k1;                    // something was dropped
-    const double F = cut ? sqrt(bdist[k1 - 1]) : 0.0;  // the f32 pass keeps squared distances
+    // the f32 pass keeps squared distances; the int8 pass integers, rounded to f32 in the packed
+    // key (2^-24 relative, taken off here): F = s sqrt(I) bounds every dropped row from below
+    const double F = !cut ? 0.0
+                     : i8 ? sh8.s * (1.0 / 256.0) * sqrt(bdist[k1 - 1] * (1.0 - 1.2e-7))
+                          : sqrt(bdist[k1 - 1]);
     const int m = cut ? k1 - 1 : best;
     if (wave == 0) {
       double qn = 0.0;
@@ -1388,6 +1679,7 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       batch_distances<TD, TA>(X, d, cid, cdist, qs, 0, m, wave, 4, lane);
     }
     __syncthreads();
+    KSTAMP();  // refine: exact distances
     {  // the k best of the m <= 63 refined entries by (distance, position): rank by counting
       const bool mine = tid < m;
       const double di = mine ? cdist[tid] : 0.0;
@@ -1417,7 +1709,12 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
       // F must be finite: an overflowed f32 sum (inf) orders nothing among the dropped
       // f32 DATA ranked on their half shadow: what the cut is compared with is the f32 distance the
       // all-f32 kernel ranks on, itself within (d + 2) u dist of the exact one
-      const double err2 = std::is_same<TD, double>::value ? err : err + (double)(d + 2) * u * (F + err) * 1.01;
+      double err2 = std::is_same<TD, double>::value ? err : err + (double)(d + 2) * u * (F + err) * 1.01;
+      if (i8) {  // triangle inequality (Sh8): exact distance of a dropped row >= F - eq - emax
+        const double e8 = (q8eq + sh8.emax) * (1.0 + 1e-12) + 1e-300;
+        err2 = std::is_same<TD, double>::value ? e8 : e8 + (double)(d + 2) * u * F * 1.01;
+        if (!(q8eq == q8eq)) err2 = F + 1.0;  // NaN in the query: never certified
+      }
       if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err2 > bdist[best - 1])) {
         if (tid == 0) {  // flag 2: the host re-runs this query with the all-f64 kernel
           ovf_flags[q] = 2u;
@@ -1443,6 +1740,8 @@ __global__ __launch_bounds__(256) void knn_fused_kernel(
                              : __longlong_as_double(0x7ff0000000000000LL);
   }
   if (tid == 0) out_cnt[q] = best;
+  KSTAMP();  // final ranking, certificate, output
+#undef KSTAMP
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1475,7 +1774,7 @@ __host__ __device__ inline size_t fused_wave_bytes(int d, size_t acc_size) {
   return (b + 15) & ~(size_t)15;
 }
 
-template <class TD, class TK, bool PRE32>
+template <class TD, class TK, bool PRE32, bool I8 = false /* PRE32 on the int8 shadow */>
 __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm,
     const double* __restrict__ thr, const double* __restrict__ mglo,
@@ -1484,7 +1783,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     double* __restrict__ out_dist, int32_t* __restrict__ out_cnt, unsigned int* ovf_flags,
     unsigned int* ovf_count, unsigned long long* cand_total,
     const void* __restrict__ Xf, double xmax, int k1 /* PRE32: see knn_fused_kernel */,
-    unsigned long long* dbg /* debug_stamps: phase clocks of one wave */, int sh16 = 0) {
+    unsigned long long* dbg /* debug_stamps: phase clocks of one wave */, int sh16 = 0,
+    Sh8 sh8 = Sh8{0.0, 0.0} /* s > 0: Xf is the int8 shadow (see Sh8) */) {
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1511,7 +1811,25 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   float* qs32 = reinterpret_cast<float*>(bpos + kFKx);             // [d] (PRE32)
 
   for (int j = lane; j < d; j += 64) qs[j] = ld<TD>(Q + q * d + j);
-  if (PRE32)
+  constexpr bool i8 = I8;
+  static_assert(!I8 || PRE32, "the int8 tier is a prefilter");
+  double q8k = 0.0, q8eq = 0.0;
+  if constexpr (I8) {  // int8 tier: the quantised query's byte planes in the f32 copy's place (see Sh8)
+    wave_sync();
+    if constexpr (sizeof(TA) == 8)
+      quantise_query(reinterpret_cast<const double*>(qs), nullptr, d, sh8.s,
+                     reinterpret_cast<unsigned int*>(qs32), lane, 64, q8k, q8eq);
+    else
+      quantise_query(nullptr, reinterpret_cast<const float*>(qs), d, sh8.s,
+                     reinterpret_cast<unsigned int*>(qs32), lane, 64, q8k, q8eq);
+    for (int o = 32; o > 0; o >>= 1) {
+      q8k += __shfl_xor(q8k, o);
+      q8eq += __shfl_xor(q8eq, o);
+    }
+    q8k -= 1073741824.0 * (double)d;
+    q8eq = sqrt(q8eq);
+    wave_sync();
+  } else if (PRE32)
     for (int j = lane; j < d; j += 64) qs32[j] = (float)ld<TD>(Q + q * d + j);
 
   // ---- traversal: lane = tree; ranges into the tree's S slots, counted in any case ----
@@ -1566,6 +1884,22 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
                  });
   }
   wave_sync();
+  // rstart[r] = candidates before range r (the batches are filled by position, see
+  // knn_fused_kernel), in the slot slab the compaction has just emptied: lane l scans ranges 2l, 2l + 1
+  int* rstart = reinterpret_cast<int*>(spoff);  // [nr_tot + 1] <= kWR + 1 ints in kWR int64
+  {
+    const int a = 2 * lane < nr_tot ? rn[2 * lane] : 0, b = 2 * lane + 1 < nr_tot ? rn[2 * lane + 1] : 0;
+    int incl = a + b;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t2 = __shfl_up(incl, o);
+      if (lane >= o) incl += t2;
+    }
+    const int excl = incl - (a + b);
+    if (2 * lane <= nr_tot) rstart[2 * lane] = excl;
+    if (2 * lane + 1 <= nr_tot) rstart[2 * lane + 1] = excl + a;
+    if (lane == 63) rstart[nr_tot] = incl;  // = nc_tot (the only writer of entry kWR when all slots are in use)
+  }
+  wave_sync();
 
   constexpr int E = kWC / 64;  // batch entries a lane owns: lane, lane + 64, ...
   const double kInf = __longlong_as_double(0x7ff0000000000000LL);
@@ -1575,13 +1909,63 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   // f32 pass: squared f32 distance bits << 32 | position as one key (see knn_fused_kernel)
   auto wselect_packed = [&](int fill, int first_new, int pb0, int ksel) -> int {
     unsigned long long key[E];
+    unsigned int vlo = ~0u;  // the lane's smallest value
 #pragma unroll
     for (int s2 = 0; s2 < E; ++s2) {
       const int i = lane + 64 * s2;
       const unsigned int pos = i < first_new ? (unsigned int)bpos[i < kFKx ? i : 0] : (unsigned int)(pb0 + (i - first_new));
       key[s2] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | pos : ~0ULL;
+      if (i < fill) {
+        const unsigned int v = (unsigned int)(key[s2] >> 32);
+        vlo = v < vlo ? v : vlo;
+      }
     }
-    wave_sync();  // bpos is rewritten below
+    wave_sync();  // bpos is rewritten below, cdist becomes the list slab
+    // a threshold instead of ksel rounds (see knn_fused_kernel's select_packed): the value of the
+    // list's last entry once it is full, else the ksel-th smallest of the 64 per-lane minima
+    unsigned int tau;
+    if (first_new == ksel) {
+      tau = __float_as_uint((float)bdist[ksel - 1]);
+    } else {
+      int cnt = 0;
+      for (int j2 = 0; j2 < 64; ++j2) {
+        const unsigned int o = __shfl(vlo, j2);
+        cnt += (o < vlo || (o == vlo && j2 < lane)) ? 1 : 0;
+      }
+      const unsigned long long hit = __ballot(cnt == ksel - 1);
+      tau = __shfl(vlo, __ffsll((long long)hit) - 1);  // ~0u with fewer than ksel occupied lanes
+    }
+    unsigned long long* lkey = reinterpret_cast<unsigned long long*>(cdist);      // [128]
+    int* lidx = reinterpret_cast<int*>(cdist + 128);                               // [128]
+    unsigned int* lcnt = reinterpret_cast<unsigned int*>(cdist + 192);
+    if (lane == 0) *lcnt = 0u;
+    wave_sync();
+#pragma unroll
+    for (int s2 = 0; s2 < E; ++s2)
+      if (key[s2] != ~0ULL && (unsigned int)(key[s2] >> 32) <= tau) {
+        const unsigned int slot = atomicAdd(lcnt, 1u);
+        if (slot < 128u) {
+          lkey[slot] = key[s2];
+          lidx[slot] = lane + 64 * s2;
+        }
+      }
+    wave_sync();
+    const int n = (int)*lcnt;
+    if (n <= 128) {
+      for (int t = lane; t < n; t += 64) {
+        const unsigned long long mine = lkey[t];
+        int rank = 0;
+        for (int j2 = 0; j2 < n; ++j2) rank += lkey[j2] < mine;
+        if (rank < ksel) {
+          bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
+          bid[rank] = cid[lidx[t]];
+          bpos[rank] = (int)(unsigned int)mine;
+        }
+      }
+      wave_sync();
+      return n < ksel ? n : ksel;
+    }
+    // fallback (values tied by the hundred): ksel rounds of wave-wide arg-min
     int nb = 0;
     while (nb < ksel) {
       unsigned long long m = key[0];
@@ -1661,8 +2045,8 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     return nb;
   };
 
-  int best = 0, r_next = 0, r_done = 0, pos_base = 0;
-  while (r_next < nr_tot || best == 0) {
+  int best = 0, pos_base = 0;
+  while (pos_base < nc_tot || best == 0) {
     // ---- fill the batch: best list first (keeps its positions), then new candidates ----
     for (int i = lane; i < best; i += 64) {
       cdist[i] = bdist[i];
@@ -1670,26 +2054,38 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     }
     int fill = best;
     const int first_new = best, pb0 = pos_base;
-    int rr = r_next, rd = r_done, pb = pos_base;
-    while (rr < nr_tot && fill < kWC) {
-      int take = rn[rr] - rd;
+    {  // by position: a seven-step search over rstart, the lane's perm loads all in flight at once
+      int take = nc_tot - pos_base;
       if (take > kWC - fill) take = kWC - fill;
-      for (int i = lane; i < take; i += 64) cid[fill + i] = perm[rpoff[rr] + rd + i];
-      fill += take;
-      rd += take;
-      pb += take;
-      if (rd == rn[rr]) {
-        ++rr;
-        rd = 0;
+      int64_t addr[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int s2 = lane + 64 * e;
+        const int c = pos_base + (s2 < take ? s2 : 0);
+        int lo = 0;
+#pragma unroll
+        for (int step = kWR / 2; step > 0; step >>= 1) {
+          const int m = lo + step;
+          if (m < nr_tot && rstart[m] <= c) lo = m;
+        }
+        addr[e] = rpoff[lo] + (c - rstart[lo]);
       }
+      int32_t idv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) idv[e] = lane + 64 * e < take ? perm[addr[e]] : 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (lane + 64 * e < take) cid[fill + lane + 64 * e] = idv[e];
+      fill += take;
+      pos_base += take;
     }
-    r_next = rr;
-    r_done = rd;
-    pos_base = pb;
     wave_sync();
     KSTAMP();  // batch filled
     if constexpr (PRE32) {
-      if (sh16)
+      if constexpr (I8)
+        batch_distances_i8<8>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
+                              reinterpret_cast<const unsigned int*>(qs32), q8k, first_new, fill, 0, 1, lane);
+      else if (sh16)
         batch_distances<_Float16, float, 16, false>(static_cast<const _Float16*>(Xf), d, cid, cdist, qs32,
                                                     first_new, fill, 0, 1, lane);
       else
@@ -1707,11 +2103,14 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
                           : wselect(fill, first_new, pb0, ksel, dedup);
     best = nb;
     KSTAMP();  // selection
-    if (r_next >= nr_tot) break;
+    if (pos_base >= nc_tot) break;
   }
   if constexpr (PRE32) {  // exact distances of the kept entries + certified cut (knn_fused_kernel)
     const bool cut = best == k1;
-    const double F = cut ? sqrt(bdist[k1 - 1]) : 0.0;  // the f32 pass keeps squared distances
+    // the f32 pass keeps squared distances, the int8 pass integers (knn_fused_kernel)
+    const double F = !cut ? 0.0
+                     : i8 ? sh8.s * (1.0 / 256.0) * sqrt(bdist[k1 - 1] * (1.0 - 1.2e-7))
+                          : sqrt(bdist[k1 - 1]);
     const int m = cut ? k1 - 1 : best;
     double qn = 0.0;
     for (int j = lane; j < d; j += 64) qn += (double)qs[j] * (double)qs[j];
@@ -1748,7 +2147,12 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
       const double err = sh16 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * sqrt(qn) + (double)(d + 2) * u * F +
                                     sqrt((double)d) * 3.1e-8
                               : 2.1 * u * (xmax + sqrt(qn)) + (double)(d + 2) * u * F + sqrt((double)d) * 4e-23;
-      const double err2 = std::is_same<TD, double>::value ? err : err + (double)(d + 2) * u * (F + err) * 1.01;
+      double err2 = std::is_same<TD, double>::value ? err : err + (double)(d + 2) * u * (F + err) * 1.01;
+      if (i8) {  // triangle inequality (Sh8)
+        const double e8 = (q8eq + sh8.emax) * (1.0 + 1e-12) + 1e-300;
+        err2 = std::is_same<TD, double>::value ? e8 : e8 + (double)(d + 2) * u * F * 1.01;
+        if (!(q8eq == q8eq)) err2 = F + 1.0;  // NaN in the query: never certified
+      }
       if (!(sqrt(qn) < 1e18) || !(F < 1e30) || !(F - err2 > bdist[best - 1])) {
         if (lane == 0) {
           ovf_flags[q] = 2u;
@@ -2278,6 +2682,114 @@ static int32_t ensure_shadow16(rpt_ctx* ctx, const rpt_dataset* data) {
   return RPT_OK;
 }
 
+// int8 shadow (Sh8): pass 1 = the largest |element| (bits in max_bits[0]; NaN / inf -> +inf)
+template <class TIn>
+__global__ __launch_bounds__(256) void maxabs_kernel(const TIn* __restrict__ X, int64_t count,
+                                                     unsigned long long* __restrict__ max_bits) {
+  double mx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const double a = fabs((double)ld<TIn>(X + i));
+    if (!(a <= mx)) mx = a == a ? a : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(mx, o);
+    mx = t > mx ? t : mx;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));
+}
+// pass 2 = the rows (one wave per row) and the largest squared row error |x - s c|^2 (max_bits[1])
+template <class TIn>
+__global__ __launch_bounds__(256) void shadow8_kernel(const TIn* __restrict__ X, int64_t n, int d, double s,
+                                                      int8_t* __restrict__ X8,
+                                                      unsigned long long* __restrict__ max_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const double inv = 1.0 / s;
+  double mx = 0.0;
+  for (int64_t r = row0; r < n; r += (int64_t)gridDim.x * 4) {
+    double e2 = 0.0;
+    for (int j = lane; j < d; j += 64) {
+      const double v = (double)ld<TIn>(X + r * d + j);
+      double c = rint(v * inv);
+      c = c < -127.0 ? -127.0 : (c > 127.0 ? 127.0 : c);
+      X8[r * d + j] = (int8_t)(uint8_t)((int)c + 128);  // offset binary
+      const double e = v - s * c;
+      e2 += e * e;
+    }
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+    if (!(e2 <= mx)) mx = e2 == e2 ? e2 : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  if (lane == 0) atomicMax(max_bits + 1, (unsigned long long)__double_as_longlong(mx));
+}
+
+// The int8 shadow, once per dataset; allowed to fail like the others (no memory, rows that are not a
+// multiple of 16 elements, non-finite or all-zero data): the half tier then ranks.
+static int32_t ensure_shadow8(rpt_ctx* ctx, const rpt_dataset* data) {
+  if (data->shadow8_state != 0) return RPT_OK;
+  data->shadow8_state = -1;
+  void* p = nullptr;
+  DevBuf<unsigned long long> mb;
+  unsigned long long bits[2] = {0, 0};
+  auto give_up = [&](const char* why = "") {
+    if (ctx->opt.debug_host) fprintf(stderr, "int8 shadow: not built (%s)\n", why);
+    if (p) dev_free(p);
+    (void)hipGetLastError();
+    return RPT_OK;
+  };
+  if (data->csr || data->n == 0 || (data->d % 16) != 0 || data->d > 16384)
+    return give_up("CSR rows, or rows that are not a multiple of 16 elements");
+  if (dev_alloc(&p, (size_t)data->n * data->d + 16) != hipSuccess) {
+    p = nullptr;
+    return give_up("no memory");
+  }
+  if (mb.alloc(2) != RPT_OK) return give_up();
+  if (hipMemsetAsync(mb.p, 0, 16, ctx->stream) != hipSuccess) return give_up();
+  const int64_t count = data->n * data->d;
+  int64_t b1 = (count + 255) / 256;
+  if (b1 > (int64_t)ctx->n_cu * 16) b1 = (int64_t)ctx->n_cu * 16;
+  if (data->dtype == RPT_F64)
+    hipLaunchKernelGGL(maxabs_kernel<double>, dim3((unsigned)b1), dim3(256), 0, ctx->stream,
+                       (const double*)data->X, count, mb.p);
+  else if (data->dtype == RPT_F32)
+    hipLaunchKernelGGL(maxabs_kernel<float>, dim3((unsigned)b1), dim3(256), 0, ctx->stream,
+                       (const float*)data->X, count, mb.p);
+  else
+    hipLaunchKernelGGL(maxabs_kernel<__hip_bfloat16>, dim3((unsigned)b1), dim3(256), 0, ctx->stream,
+                       (const __hip_bfloat16*)data->X, count, mb.p);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (hipMemcpyAsync(bits, mb.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
+  double mabs;
+  std::memcpy(&mabs, &bits[0], 8);
+  if (!(mabs > 0.0) || !(mabs < 1e150)) return give_up("max |x| is zero, huge or not finite");  // all zeros, NaN / inf, or no range left
+  const double s = mabs / 127.0;
+  if (!(s > 0.0) || !(1.0 / s < 1e300)) return give_up();
+  int64_t blocks = (data->n + 3) / 4;
+  if (blocks > (int64_t)ctx->n_cu * 16) blocks = (int64_t)ctx->n_cu * 16;
+  if (data->dtype == RPT_F64)
+    hipLaunchKernelGGL(shadow8_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const double*)data->X, data->n, data->d, s, (int8_t*)p, mb.p);
+  else if (data->dtype == RPT_F32)
+    hipLaunchKernelGGL(shadow8_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const float*)data->X, data->n, data->d, s, (int8_t*)p, mb.p);
+  else
+    hipLaunchKernelGGL(shadow8_kernel<__hip_bfloat16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const __hip_bfloat16*)data->X, data->n, data->d, s, (int8_t*)p, mb.p);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  if (hipMemcpyAsync(bits, mb.p, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return give_up();
+  if (stream_sync(ctx->stream) != hipSuccess) return give_up();
+  double e2;
+  std::memcpy(&e2, &bits[1], 8);
+  if (!(e2 < 1e300)) return give_up("row error not finite");
+  data->s8_scale = s;
+  data->s8_emax = std::sqrt(e2) * (1.0 + 1e-9);  // (the butterfly sum of squares: a few ulp)
+  data->shadow8 = (int8_t*)p;
+  data->shadow8_state = 1;
+  if (ctx->opt.debug_host)
+    fprintf(stderr, "int8 shadow: scale %.6g (max |x| %.6g), max row error %.6g\n", s, mabs, data->s8_emax);
+  return RPT_OK;
+}
+
 // (u16 column, f32 value) shadow of a CSR f64 dataset, its largest squared row norm and longest row
 __global__ __launch_bounds__(256) void shadow_csr_kernel(const int64_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col,
@@ -2466,7 +2978,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // debug_stamps: phase clocks of one wave of the wave kernel, printed after the launch
   DevBuf<unsigned long long> dbgdev;
   unsigned long long* dbg = nullptr;
-  if (ctx->opt.debug_stamps && wave && dbgdev.alloc(64) == RPT_OK) {
+  if (ctx->opt.debug_stamps && dbgdev.alloc(64) == RPT_OK) {
     (void)hipMemsetAsync(dbgdev.p, 0, 64 * 8, ctx->stream);
     dbg = dbgdev.p;
   }
@@ -2507,22 +3019,40 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                    !ctx->opt.knn_no_pre16 && !f->pre16_off && !f->prefilter_off && kp16 + 1 <= kFK &&
                    dedup == 0 && !rerun && !ctx->opt.knn_no_pre32;
   if (sh16 || ell) kp = kp16;
-  if (tier) *tier = (sh16 || ell) ? 2 : pre32 ? 1 : 0;
-  const void* shadow = sh16 ? (const void*)data->shadow16 : (const void*)data->shadow32;
+  // ... or, before that, on the INT8 shadow (an eighth of the f64 bytes; integer ranking values, the
+  // cut certified through the triangle inequality, see Sh8): coarser again, k + max(48, k) kept
+  const int kp8_env = (int)ctx->opt.knn_kp8;
+  // (the one-wave kernel takes its threshold from the 64 per-lane minima: beyond the 48th of them
+  // the candidate list outgrows its 128 slots)
+  const int kcap8 = wave ? 48 : kBK;
+  int kp8 = kp8_env > k && kp8_env < kcap8 ? kp8_env : k + (k > 48 ? k : 48);
+  if (kp8 > kcap8 - 1) kp8 = kcap8 - 1;
+  const bool sh8 = !data->csr && data->shadow8 && !ctx->opt.knn_no_pre8 && !f->pre8_off &&
+                   kp8 >= k + 8 && dedup == 0 && !rerun && !ctx->opt.knn_no_pre32 &&
+                   !ctx->opt.knn_no_pre16 && !f->pre16_off && !f->prefilter_off &&
+                   ((std::is_same<TD, double>::value && data->shadow32) || std::is_same<TD, float>::value ||
+                    (std::is_same<TD, __hip_bfloat16>::value && !wave));  // (bf16: the workgroup kernel only)
+  if (sh8) kp = kp8;
+  const Sh8 s8 = sh8 ? Sh8{data->s8_scale, data->s8_emax} : Sh8{0.0, 0.0};
+  if (tier) *tier = sh8 ? 3 : (sh16 || ell) ? 2 : pre32 ? 1 : 0;
+  const void* shadow = sh8    ? (const void*)data->shadow8
+                       : sh16 ? (const void*)data->shadow16
+                              : (const void*)data->shadow32;
   if (wave) {
     dbgprint.p = dbg;
     const size_t smem = 4 * wbytes;
     if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
-      if (pre32 || sh16) {
+      if (pre32 || sh16 || sh8) {
+        auto kern = sh8 ? knn_fused_wave_kernel<TD, TK, true, true> : knn_fused_wave_kernel<TD, TK, true, false>;
         if (smem > 64 * 1024)
-          RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_wave_kernel<TD, TK, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((knn_fused_wave_kernel<TD, TK, true>), dim3((unsigned)((q->n + 3) / 4)),
+          RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)smem));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((q->n + 3) / 4)),
                            dim3(256), smem, ctx->stream, (const TD*)data->X, data->d,
                            (const TD*)q->X, f->perm.p, f->thr.p, f->mglo.p, f->mghi.p, f->nodes,
                            (const TK*)Pq, q->n, f->T, f->L, f->min_leaf, f->n, k, dedup, ids, dist,
                            cnt, ovf + 1, ovf, cand_total, shadow, data->max_norm, kp + 1, dbg,
-                           sh16 ? 1 : 0);
+                           sh16 ? 1 : 0, s8);
         RPT_HIP(hipGetLastError());
         return RPT_OK;
       }
@@ -2538,19 +3068,20 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
     RPT_HIP(hipGetLastError());
     return RPT_OK;
   }
-  const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kFKx * 16 +
+  const size_t smem = (size_t)kFC * 16 + (size_t)kFR * 12 + 2048 * 4 + (size_t)kBKx * 16 +
                       (size_t)data->d * (sizeof(TA) + 4) + 64 +
                       (vote > 0 ? (size_t)kVoteCap * 4 + 16 : 0);
-  if constexpr (std::is_same<TD, float>::value) {
-    if (sh16) {  // f32 rows ranked on their half shadow
+  if constexpr (!std::is_same<TD, double>::value) {
+    if (sh16 || sh8) {  // f32 rows ranked on their half / int8 shadow, bf16 rows on their int8 shadow
+      auto kern = sh8 ? knn_fused_kernel<TD, TK, true, false, true> : knn_fused_kernel<TD, TK, true, false, false>;
       if (smem > 64 * 1024)
-        RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL((knn_fused_kernel<TD, TK, true>), dim3((unsigned)q->n), dim3(256), smem,
+        RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+      hipLaunchKernelGGL(kern, dim3((unsigned)q->n), dim3(256), smem,
                          ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                          f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                          f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                         shadow, data->max_norm, kp + 1, CsrPtrs{}, 1);
+                         shadow, data->max_norm, kp + 1, CsrPtrs{}, 1, s8, (unsigned long long*)nullptr);
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -2571,15 +3102,17 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
-    if (pre32) {
+    if (pre32 || sh8) {
+      auto kern = sh8 ? knn_fused_kernel<TD, TK, true, false, true> : knn_fused_kernel<TD, TK, true, false, false>;
       if (smem > 64 * 1024)
-        RPT_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel<TD, TK, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL((knn_fused_kernel<TD, TK, true>), dim3((unsigned)q->n), dim3(256), smem,
+        RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+      hipLaunchKernelGGL(kern, dim3((unsigned)q->n), dim3(256), smem,
                          ctx->stream, (const TD*)data->X, data->d, (const TD*)q->X, f->perm.p,
                          f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, q->n, f->T, f->L,
                          f->min_leaf, f->n, k, dedup, ids, dist, cnt, ovf + 1, ovf, cand_total,
-                         shadow, data->max_norm, kp + 1, CsrPtrs{}, sh16 ? 1 : 0);
+                         shadow, data->max_norm, kp + 1, CsrPtrs{}, sh16 ? 1 : 0, s8, dbg);
+      dbgprint.p = dbg;
       RPT_HIP(hipGetLastError());
       return RPT_OK;
     }
@@ -2693,6 +3226,8 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     if (!data->csr) {
       RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
       if (data->shadow32 && !ctx->opt.knn_no_pre16 && !f->pre16_off) RPT_TRY(ensure_shadow16(ctx, data));
+      if (data->shadow32 && !ctx->opt.knn_no_pre16 && !f->pre16_off && !ctx->opt.knn_no_pre8 && !f->pre8_off)
+        RPT_TRY(ensure_shadow8(ctx, data));
     }
     // CSR rows: the (u16, f32) shadow halves the bytes of the ranking pass but NOT its time — at C3
     // the exact kernel already gathers rows at 6.4 TB/s and the f32 pass, with its 17 selection
@@ -2705,8 +3240,17 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   }
   int tier = 0;
   if (data->dtype == RPT_F32 && !data->csr && dedup == 0 && !ctx->opt.knn_no_pre16 &&
-      !ctx->opt.knn_no_pre32 && !f->pre16_off)
+      !ctx->opt.knn_no_pre32 && !f->pre16_off) {
     RPT_TRY(ensure_shadow16(ctx, data));
+    if (!ctx->opt.knn_no_pre8 && !f->pre8_off) RPT_TRY(ensure_shadow8(ctx, data));
+  }
+  // bf16 rows: the int8 tier exists (identical answers, tested) but is OPT-IN (knn_kp8 > 0): at C5
+  // (10 M x 768, k = 50) the cut needs 200 kept rows to certify 99 % of the queries and the pass is
+  // then no faster than the plain bf16 kernel (82 against 68 ms per 100 000 queries) — its 768-byte
+  // rows keep half the bytes in flight per wave — while the shadow costs 7.7 GB
+  if (data->dtype == RPT_BF16 && !data->csr && dedup == 0 && ctx->opt.knn_kp8 > 0 && !ctx->opt.knn_no_pre16 &&
+      !ctx->opt.knn_no_pre32 && !ctx->opt.knn_no_pre8 && !f->pre16_off && !f->pre8_off && !f->prefilter_off)
+    RPT_TRY(ensure_shadow8(ctx, data));
   auto launch = [&](bool rerun) -> int32_t {
     if (f->pdtype == RPT_F64)
       return launch_fused<double, double>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
@@ -2715,7 +3259,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
       return launch_fused<float, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
                                         count_dev, ovf_p, ctot_p, rerun, rerun ? nullptr : &tier);
     return launch_fused<__hip_bfloat16, float>(ctx, f, data, q, Pq.p, k, dedup, ids_dev, dist_dev,
-                                               count_dev, ovf_p, ctot_p, rerun);
+                                               count_dev, ovf_p, ctot_p, rerun, rerun ? nullptr : &tier);
   };
   RPT_TRY(launch(false));
   unsigned int hctl[6] = {0, 0, 0, 0, 0, 0};
@@ -2734,7 +3278,8 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   // too many uncertified cuts: one tier down for the later batches on this forest (half -> f32
   // shadow -> all-f64)
   if (tot[1] * 4 > (unsigned long long)nq) {
-    if (tier == 2) f->pre16_off = true;
+    if (tier == 3) f->pre8_off = true;
+    else if (tier == 2) f->pre16_off = true;
     else f->prefilter_off = true;
   }
   ctx->last_tier = tier;

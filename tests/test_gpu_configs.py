@@ -368,3 +368,41 @@ def test_bf16_forest_and_knn_small_all_paths(rp, oracle, torch):
     sel = np.nonzero(same)[0]
     pos, tot, whole = knn_agreement(ids[sel], dist[sel], cnt[sel], wi[sel], wd[sel], wc[sel], k, 1e-5)
     assert pos >= 0.8 * tot and whole >= 40, (pos, tot, whole)
+
+
+@pytest.mark.parametrize("shape", [(20_000, 64, 12, 100, 10), (8_000, 768, 12, 100, 50)])
+def test_bf16_int8_ranking_tier_changes_nothing(rp, torch, shape):
+    """bf16 rows can be ranked on the int8 shadow first (opt-in: half of the bf16 bytes; the kept rows
+    get the f32 distance the all-bf16 kernel ranks on, the cut certified per query): ids, distances
+    and counts equal the all-bf16 kernel's bit for bit, rows of 4 and of 48 sixteen-byte pieces."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, min_leaf, k = shape
+    rng = np.random.default_rng(13)
+    Xb = rp.to_bf16((rng.standard_normal((n, d)) * 0.5 + rng.integers(0, 2, (n, 1)) * 2.0).astype(np.float32))
+    Xh = rp.from_bf16(Xb)
+    ctx = rp.default_context()
+    ds = rp.Dataset.dense(ctx, Xb, dtype=rp.RPT_BF16)
+    cfg = rp.rpTreeCfg(min_leaf, n, d)
+    _, R = rp.gen.forest_hyperplanes(5, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
+    f = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)
+    Q = Xh[:64] * 1.01
+    kp8 = ctx.set_option("knn_kp8", 200 if k == 50 else 58)   # (opt-in for bf16 rows)
+    try:
+        got = rp.knnBatch(k, f, Q)
+    finally:
+        ctx.set_option("knn_kp8", kp8)
+    tier, unc = C.c_int32(-1), C.c_int64(-1)
+    _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+    _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+    assert tier.value == 3
+    old = ctx.set_option("knn_no_pre8", 1)
+    try:
+        ref = rp.knnBatch(k, f, Q)
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        assert tier.value == 0
+    finally:
+        ctx.set_option("knn_no_pre8", old)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    print("bf16 int8 tier: %d of %d queries uncertified" % (unc.value, len(Q)))

@@ -562,16 +562,23 @@ def test_knn_f32_prefilter_is_exact(rp, ctx, oracle, option, kind, k):
     unc = C.c_int64(-1)
     _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
     if kind == "cont" and k == 24:
-        assert unc.value == 0                   # every cut certified
+        assert unc.value <= len(Q) // 8         # (the int8 tier: coarse for 16-element rows)
     # (k = 1: a query is a data point + 0.003, its source is found once per tree, and a cut inside
     # that group of equal distances cannot be certified: those queries are re-run in f64)
     with option("knn_no_pre32", 1):
         ref = rp.knnBatch(k, f, Q)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
-    with option("knn_no_pre16", 1):          # the f32 shadow alone (the default ranks on the half one)
+    with option("knn_no_pre16", 1):          # the f32 shadow alone
         g32 = rp.knnBatch(k, f, Q)
     for a, b in zip(g32, ref):
+        assert np.array_equal(a, b)
+    with option("knn_no_pre8", 1):           # the half shadow first (the default ranks on the int8 one)
+        g16 = rp.knnBatch(k, f, Q)
+        _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+    if kind == "cont" and k == 24:
+        assert unc.value == 0                   # every cut certified
+    for a, b in zip(g16, ref):
         assert np.array_equal(a, b)
     fo = oracle.forest_build_dense(X, R, ml)
     ids, dist, cnt = got
@@ -680,6 +687,78 @@ def test_knn_f32_prefilter_switches_itself_off_on_self_queries(rp, ctx, oracle):
             assert np.array_equal(dist[i, :cnt[i]], wd)
     assert tiers == [2, 1, 0], tiers
     assert seen[0] > len(Q) // 4 and seen[1] > len(Q) // 4 and seen[2] == 0
+
+
+@pytest.mark.parametrize("shape", [(20000, 128, 12, 100), (20000, 128, 6, 100), (6000, 208, 12, 100),
+                                   (3000, 1040, 6, 100)])
+@pytest.mark.parametrize("kind", ["cont", "ties", "clip"])
+def test_knn_int8_tier_is_exact(rp, ctx, oracle, option, shape, kind):
+    """First ranking tier of dense f64 data with rows of 16 n elements: an int8 shadow under ONE
+    scale, the query quantised alike, candidates ranked on the exact integer sum (qc - c)^2; the
+    cut is certified through the triangle inequality (|q - s qc| + max row error) and uncertified
+    queries are answered by the exact kernel.  Answers equal the all-f64 kernel's and the oracle's
+    bit for bit: workgroup and wave kernel, rows of 8 / 13 / 65 sixteen-byte pieces, continuous and
+    rounded data, and queries far outside the data's range (their elements clip at +-127)."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, ml = shape
+    X = oracle.data_normal_dense2(31, n, d)
+    if kind == "ties":
+        X = np.round(X * 2) / 2
+    rng = np.random.default_rng(11)
+    Q = X[rng.integers(0, n, 40)] + 0.003
+    if kind == "clip":
+        Q[::3] *= 40.0                           # far beyond max |x|: clipped, eq is large, not certified
+    cfg = rp.rpTreeCfg(ml, n, d)
+    L, pnz = min(cfg.fpMaxTreeDepth, 8), cfg.fpProjNzDensity
+    R, _ = oracle.forest_hyperplanes(5, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    fo = oracle.forest_build_dense(X, R, ml)
+    for k in (1, 10, 24):
+        got = rp.knnBatch(k, f, Q)
+        tier, unc = C.c_int32(-1), C.c_int64(-1)
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+        if tier.value != 3:                      # (a batch that failed too many cuts demotes the forest:
+            assert kind == "clip" or d > 128, (tier.value, kind, k)   # clipped queries; long mixture rows)
+        if kind == "cont" and d == 128:
+            assert unc.value <= len(Q) // 4, unc.value
+        with option("knn_no_pre32", 1):
+            ref = rp.knnBatch(k, f, Q)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (k, kind)
+        ids, dist, cnt = got
+        for i in range(0, len(Q), 5):
+            wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+            assert np.array_equal(dist[i, :cnt[i]], wd)
+
+
+def test_knn_tiers_demote_one_at_a_time(rp, ctx, oracle, option):
+    """Rows of 16 elements have all four tiers; self queries (24 copies of the nearest point across
+    every cut; the int8 tier told to keep 12 instead of its 52) fail each in turn: int8 -> half ->
+    f32 -> exact, the answers the oracle's throughout."""
+    import ctypes as C
+    from rptree_amd import _lib
+    n, d, T, ml, k = 8000, 16, 24, 100, 4
+    X = oracle.data_normal_dense2(17, n, d)
+    Q = X[:24].copy()
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(6, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    fo = oracle.forest_build_dense(X, R, ml)
+    tiers = []
+    for rnd in range(4):
+        with option("knn_kp8", 12):
+            ids, dist, cnt = rp.knnBatch(k, f, Q)
+        tier = C.c_int32(-1)
+        _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+        tiers.append(tier.value)
+        for i in range(len(Q)):
+            wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+            assert np.array_equal(dist[i, :cnt[i]], wd)
+    assert tiers == [3, 2, 1, 0], tiers
 
 
 def test_knn_f32_prefilter_out_of_range_data(rp, ctx, oracle):
@@ -836,7 +915,8 @@ def test_knn_f32_data(rp, ctx, oracle):
     assert (bi[:, 0] == np.arange(50)).all()
 
 
-@pytest.mark.parametrize("shape", [(20000, 16, 12, 100), (20000, 16, 6, 100), (12000, 200, 8, 200)])
+@pytest.mark.parametrize("shape", [(20000, 16, 12, 100), (20000, 16, 6, 100), (12000, 200, 8, 200),
+                                   (6000, 208, 4, 200), (4000, 1040, 8, 200)])
 @pytest.mark.parametrize("kind", ["cont", "ties", "self"])
 def test_knn_f32_data_half_shadow_tier_changes_nothing(rp, ctx, option, oracle, shape, kind):
     """f32 data are ranked on an IEEE-half shadow first; the kept rows get the f32 distance the
@@ -861,15 +941,19 @@ def test_knn_f32_data_half_shadow_tier_changes_nothing(rp, ctx, option, oracle, 
         tier, unc = C.c_int32(-1), C.c_int64(-1)
         _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
         _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
-        if k == 1:
-            assert tier.value == 2                       # the half tier ran
-        if kind == "cont" and k == 24:
+        if k == 1:                                           # (later k: a demotion may have happened)
+            assert tier.value == (3 if d % 16 == 0 else 2)   # the int8 (rows of 16 n bytes) / half tier ran
+        if kind == "cont" and k == 24 and tier.value == 2:    # (the int8 tier's cut is wider: it may demote)
             assert unc.value <= len(Q) // 8
         with option("knn_no_pre16", 1):
             ref = rp.knnBatch(k, f, Q)
             _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
             assert tier.value == 0
         for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (k, kind)
+        with option("knn_no_pre8", 1):
+            g16 = rp.knnBatch(k, f, Q)
+        for a, b in zip(g16, ref):
             assert np.array_equal(a, b), (k, kind)
 
 

@@ -1,5 +1,5 @@
-"""kNN ranking tiers at C2 (32 trees and a 4-tree shard): f32 shadow vs the half shadow with several
-numbers of kept entries: ms per 10 000 queries, uncertified queries, identity of the answers.
+"""kNN ranking tiers at C2 (32 trees and a 4-tree shard): f32 shadow vs the half and int8 shadows with
+several numbers of kept entries: ms per 10 000 queries, uncertified queries, identity of the answers.
 usage: python tools/knn_tiers.py"""
 import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/rp-tree_amd/python')
@@ -24,9 +24,11 @@ torch.cuda.synchronize()
 for T in (32, 4):
     _, R = rp.gen.forest_hyperplanes(1235137, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
     ref = None
-    for name, opts in [("f32 shadow", {"knn_no_pre16": 1}), ("half, keep 18", {"knn_kp16": 18}),
-                       ("half, keep 26", {"knn_kp16": 26}), ("half, keep 34", {"knn_kp16": 34}),
-                       ("half, keep 42", {"knn_kp16": 42})]:
+    for name, opts in [("f32 shadow", {"knn_no_pre16": 1}), ("half, keep 18", {"knn_no_pre8": 1, "knn_kp16": 18}),
+                       ("half, keep 26", {"knn_no_pre8": 1, "knn_kp16": 26}),
+                       ("int8, keep 14", {"knn_kp8": 14}), ("int8, keep 18", {"knn_kp8": 18}),
+                       ("int8, keep 22", {"knn_kp8": 22}), ("int8, keep 26", {"knn_kp8": 26}),
+                       ("int8, keep 34", {"knn_kp8": 34}), ("int8, keep 42", {"knn_kp8": 42})]:
         f = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_MFMA)   # fresh tier state
         for o, v in opts.items():
             ctx.set_option(o, v)
