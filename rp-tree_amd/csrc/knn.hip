@@ -425,7 +425,26 @@ __device__ inline TA wave_sum(TA v) {
 // library carry the reference's bits and their order is the order of those values.
 __device__ inline double leftfold_distance(const double* __restrict__ x, const double* qs, int d) {
   double acc = 0.0;
-  for (int j = 0; j < d; ++j) {
+  int j = 0;
+  // one thread walks one row: the row's loads go out thirty-two elements at a time (sixteen 16-byte
+  // loads in flight) so that the walk waits for HBM d / 32 times, not d / 4; the sum itself is the
+  // reference's left fold whatever the grouping of the loads
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    typedef double d2 __attribute__((ext_vector_type(2), aligned(16)));
+    for (; j + 32 <= d; j += 32) {
+      d2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const d2*>(x + j + 2 * u);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const double t0 = v[u][0] - qs[j + 2 * u];
+        acc = acc + t0 * t0;
+        const double t1 = v[u][1] - qs[j + 2 * u + 1];
+        acc = acc + t1 * t1;
+      }
+    }
+  }
+  for (; j < d; ++j) {
     const double t = x[j] - qs[j];
     acc = acc + t * t;
   }
@@ -707,6 +726,38 @@ __device__ inline void quantise_query(const double* qsrc_d, const float* qsrc_f,
     planes[w] = wh;
     planes[nw + w] = wl;
   }
+}
+
+// number of keys of an LDS list below `mine`: the loads go out eight at a time (one load, one
+// compare per turn left every iteration waiting out an LDS round trip: 14 k cycles for 150 keys)
+__device__ __forceinline__ int count_below(const unsigned long long* lkey, int n, unsigned long long mine) {
+  int rank = 0, j = 0;
+  for (; j + 8 <= n; j += 8) {
+    unsigned long long a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = lkey[j + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rank += a[u] < mine;
+  }
+  for (; j < n; ++j) rank += lkey[j] < mine;
+  return rank;
+}
+// ... and of (distance, position) pairs below (di, pi)
+__device__ __forceinline__ int count_below2(const double* dd, const int* pp, int m, double di, int pi) {
+  int rank = 0, j = 0;
+  for (; j + 8 <= m; j += 8) {
+    double a[8];
+    int b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = dd[j + u];
+      b[u] = pp[j + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rank += a[u] < di || (a[u] == di && b[u] < pi);
+  }
+  for (; j < m; ++j) rank += dd[j] < di || (dd[j] == di && pp[j] < pi);
+  return rank;
 }
 
 // integer squared distances (see above) of the candidates [first, fill) -> cdist (exact integers
@@ -1333,8 +1384,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
     } else {
       const int r = (ksel + 3) / 4;
       int cnt = 0;
-      for (int j2 = 0; j2 < 64; ++j2) {
-        const unsigned int o = __shfl(vmin, j2);
+#pragma unroll
+      for (int j2 = 0; j2 < 64; ++j2) {  // (constant lane: v_readlane, not an LDS permute)
+        const unsigned int o = (unsigned int)__builtin_amdgcn_readlane((int)vmin, j2);
         cnt += (o < vmin || (o == vmin && j2 < lane)) ? 1 : 0;
       }
       const unsigned long long hit = __ballot(cnt == r - 1);
@@ -1342,7 +1394,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
       if (lane == 0) s_mm[wave] = tau;
     }
     if (tid == 0) s_lcnt = 0u;
+    KSTAMP();  // sel: keys + threshold
     __syncthreads();  // (every thread has read its cdist entries: the list below reuses that slab)
+    KSTAMP();  // sel: barrier
     if (have != ksel) {
       tau = s_mm[0];
 #pragma unroll
@@ -1359,13 +1413,14 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
           lidx[slot] = tid + 256 * e;
         }
       }
+    KSTAMP();  // sel: compaction
     __syncthreads();
+    KSTAMP();  // sel: barrier
     const int n = (int)s_lcnt;
     if (n <= kSelList) {
       for (int t2 = tid; t2 < n; t2 += 256) {
         const unsigned long long mine = lkey[t2];
-        int rank = 0;
-        for (int j2 = 0; j2 < n; ++j2) rank += lkey[j2] < mine;
+        const int rank = count_below(lkey, n, mine);
         if (rank < ksel) {
           bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
           bid[rank] = cid[lidx[t2]];
@@ -1494,6 +1549,12 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
     return nb;
   };
 
+  // A dense prefilter cut that cannot be certified is tried ONCE more, by the same workgroup, with
+  // three times the kept entries (the other workgroups keep the chip busy meanwhile); only then is
+  // the query left to the host's second launch of the exact kernel (two such queries of C2's 10 000
+  // cost that launch 0.4 ms: they run alone on an empty chip)
+  const int k1_retry = (PRE32 && !CSR) ? (3 * k1 < kBK ? 3 * k1 : kBK) : k1;
+retry_wider:
   int best = 0;       // entries of the running best list
   int pos_base = 0;   // candidate position of the next unconsumed candidate
   while ((vote > 0 ? vsrc < nc_tot : pos_base < nc_tot) || best == 0) {
@@ -1580,7 +1641,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
                               cdist, qsd, s_qn, first_new, fill, wave, lane);
     else if constexpr (PRE32) {
       if constexpr (I8)  // int8 rows: an eighth of the f64 bytes, integer ranking values
-        batch_distances_i8<8>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
+        batch_distances_i8<16>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
                               reinterpret_cast<const unsigned int*>(qs32), q8k, first_new, fill, wave, 4,
                               lane);
       else if (sh16)  // half rows: a quarter of the f64 bytes (the query stays f32)
@@ -1686,7 +1747,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
       const int pi = mine ? cpos[tid] : 0, ii = mine ? cid[tid] : -1;
       int rank = 0;
       if (mine)
-        for (int j = 0; j < m; ++j) rank += cdist[j] < di || (cdist[j] == di && cpos[j] < pi);
+        rank = count_below2(cdist, cpos, m, di, pi);
       if (mine && rank < k) {
         bdist[rank] = di;
         bid[rank] = ii;
@@ -1716,6 +1777,11 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
         if (!(q8eq == q8eq)) err2 = F + 1.0;  // NaN in the query: never certified
       }
       if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err2 > bdist[best - 1])) {
+        if (k1 < k1_retry) {  // (uniform: shared values decide)
+          k1 = k1_retry;
+          __syncthreads();
+          goto retry_wider;
+        }
         if (tid == 0) {  // flag 2: the host re-runs this query with the all-f64 kernel
           ovf_flags[q] = 2u;
           atomicAdd(cand_total + 1, 1ULL);
@@ -1928,8 +1994,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
       tau = __float_as_uint((float)bdist[ksel - 1]);
     } else {
       int cnt = 0;
-      for (int j2 = 0; j2 < 64; ++j2) {
-        const unsigned int o = __shfl(vlo, j2);
+#pragma unroll
+      for (int j2 = 0; j2 < 64; ++j2) {  // (constant lane: v_readlane, not an LDS permute)
+        const unsigned int o = (unsigned int)__builtin_amdgcn_readlane((int)vlo, j2);
         cnt += (o < vlo || (o == vlo && j2 < lane)) ? 1 : 0;
       }
       const unsigned long long hit = __ballot(cnt == ksel - 1);
@@ -1954,8 +2021,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     if (n <= 128) {
       for (int t = lane; t < n; t += 64) {
         const unsigned long long mine = lkey[t];
-        int rank = 0;
-        for (int j2 = 0; j2 < n; ++j2) rank += lkey[j2] < mine;
+        const int rank = count_below(lkey, n, mine);
         if (rank < ksel) {
           bdist[rank] = (double)__uint_as_float((unsigned int)(mine >> 32));
           bid[rank] = cid[lidx[t]];
@@ -2083,7 +2149,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     KSTAMP();  // batch filled
     if constexpr (PRE32) {
       if constexpr (I8)
-        batch_distances_i8<8>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
+        batch_distances_i8<16>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
                               reinterpret_cast<const unsigned int*>(qs32), q8k, first_new, fill, 0, 1, lane);
       else if (sh16)
         batch_distances<_Float16, float, 16, false>(static_cast<const _Float16*>(Xf), d, cid, cdist, qs32,
@@ -2131,7 +2197,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
       const double di = mine ? cdist[lane] : kInf;
       const int pi = mine ? bpos[lane] : 0x7fffffff, ii = mine ? bid[lane] : -1;
       int rank = 0;
-      for (int j = 0; j < m; ++j) rank += cdist[j] < di || (cdist[j] == di && bpos[j] < pi);
+      rank = count_below2(cdist, bpos, m, di, pi);
       wave_sync();
       if (mine && rank < k) {
         bdist[rank] = di;

@@ -666,7 +666,8 @@ def test_knn_f32_prefilter_switches_itself_off_on_self_queries(rp, ctx, oracle):
     tries), and the answers stay the oracle's."""
     import ctypes as C
     from rptree_amd import _lib
-    n, d, T, ml, k = 8000, 8, 24, 100, 4      # 24 copies of the query's own point: more than either tier keeps
+    n, d, T, ml, k = 8000, 8, 64, 100, 4      # 64 copies of the query's own point: more than either tier
+                                              # keeps, also on its second, three times wider attempt
     X = oracle.data_normal_dense2(17, n, d)
     Q = X[:24].copy()
     L, _, pnz = oracle.tree_cfg(ml, n, d)
@@ -735,12 +736,12 @@ def test_knn_int8_tier_is_exact(rp, ctx, oracle, option, shape, kind):
 
 
 def test_knn_tiers_demote_one_at_a_time(rp, ctx, oracle, option):
-    """Rows of 16 elements have all four tiers; self queries (24 copies of the nearest point across
-    every cut; the int8 tier told to keep 12 instead of its 52) fail each in turn: int8 -> half ->
+    """Rows of 16 elements have all four tiers; self queries (64 copies of the nearest point across
+    every cut; the int8 tier told to keep 12 instead of its 68) fail each in turn: int8 -> half ->
     f32 -> exact, the answers the oracle's throughout."""
     import ctypes as C
     from rptree_amd import _lib
-    n, d, T, ml, k = 8000, 16, 24, 100, 4
+    n, d, T, ml, k = 8000, 16, 64, 100, 4     # (64 copies: beyond the second, three times wider attempt too)
     X = oracle.data_normal_dense2(17, n, d)
     Q = X[:24].copy()
     L, _, pnz = oracle.tree_cfg(ml, n, d)
