@@ -906,8 +906,8 @@ def main():
         # per BATCH (the re-run of the few uncertified queries is a second launch inside a batch)
         topk_ms = prof["knn_topk"][0] / max(args.steps, 1)
         knn_bytes = nq * (cand_q * d * sb + kp * d * 8) if pre32 else nq * cand_q * d * 8
-        if tier >= 2:
-            knn_traffic = None                          # the committed PMC passes are the f32 tier's
+        if tier != 3:
+            knn_traffic = None                          # the committed PMC passes (r03) are the int8 tier's
         knn_ach = knn_bytes / (topk_ms * 1e-3) / 1e9 if topk_ms > 0 else 0.0
         roof_knn = {"bound": "hbm", "achieved": knn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": knn_ach / HBM_PEAK_GBS, "traffic": knn_traffic,

@@ -105,11 +105,12 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  * documented tolerances of the MFMA projections).  rpt_ctx_create seeds them ONCE from the
  * environment (RPT_<NAME>, upper case); no entry point reads the environment afterwards.
  *   no_stream, stream_maxnodes, stream_minper, no_wmid, no_midselect, stream_big_node, no_wsub,
- *   no_wsort, no_wpack, no_codes, no_pcodes
+ *   no_wsort, no_wpack, no_csub, no_codes, no_pcodes
  *       median split: which regime handles which level
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
- *   knn_wave (-1 auto, 0, 1), knn_kp, knn_kp16, knn_no_pre32, knn_no_pre16, knn_csr_pre32, knn_general
- *       query kernels
+ *   knn_wave (-1 auto, 0, 1), knn_kp, knn_kp16, knn_kp8, knn_no_pre32, knn_no_pre16, knn_no_pre8,
+ *   knn_csr_pre32, knn_general
+ *       query kernels; knn_kp8 > 0 also opts bf16 datasets into the int8 ranking tier
  *   comm_force_exchange            sharded kNN on a ONE-rank communicator still runs record ->
  *                                  ncclAllGather -> merge (set on the communicator's first ctx)
  *   comm_inject_failure            test hook: the device's shard reports a failure (see "Failures"
@@ -264,10 +265,14 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
  * number of valid entries (< k when fewer candidates).  Unused slots: id -1, dist +inf. */
 /* Memory note: the first rpt_knn_* call with duplicates kept (flags 0) and k <= 42 on a dense
  * f64 dataset builds an f32 copy of it on the device (+50 % of the dataset's size, freed with the
- * dataset), and an IEEE-half copy (+25 %) when its elements fit the half range: candidates are
- * ranked on the half copy (k + max(8, k/2) kept) or the f32 copy (k + max(6, k/2) kept), exact f64
- * distances are computed for the kept ones, and a per-query error bound certifies the cut
- * (uncertifiable queries take the all-f64 path).
+ * dataset), an IEEE-half copy (+25 %) when its elements fit the half range, and an int8 copy
+ * (+12.5 %; one scale for the whole dataset, rows of a multiple of 16 elements; f32 datasets get the
+ * half and int8 copies): candidates are ranked on the int8 copy (k + max(48, k) kept; the ranking
+ * value is an exact integer, the cut is certified through the triangle inequality with the
+ * quantisation errors of the query and of the worst row), the half copy (k + max(8, k/2) kept) or
+ * the f32 copy (k + max(6, k/2) kept), exact f64 distances are computed for the kept ones, and a
+ * per-query error bound certifies the cut (a query that fails it is tried once more with three
+ * times the kept entries, then takes the all-f64 path).
  * Results are identical either way.  A dataset borrowed with rpt_dataset_dense_dev must not be
  * modified while the library holds it. */
 int32_t rpt_knn_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
@@ -283,8 +288,9 @@ int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total);
 int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total);
 /* ... and the shadow its candidates were ranked on: 0 = none (all-f64 distances), 1 = the f32 copy
  * of the dataset, 2 = its IEEE-half copy (round 3: a quarter of the f64 bytes; keeps k + max(8, k / 2)
- * entries for the exact pass, same certificate with the half rounding in the error bound; a forest
- * on which more than a quarter of a batch cannot be certified drops one tier for later batches) */
+ * entries for the exact pass, same certificate with the half rounding in the error bound), 3 = its
+ * int8 copy (an eighth of the f64 bytes).  A forest on which more than a quarter of a batch cannot
+ * be certified drops one tier for its later batches (int8 -> half -> f32 -> none). */
 int32_t rpt_knn_last_tier(rpt_ctx* ctx, int32_t* tier);
 /* diagnostics of the last rpt_forest_build on this context: split nodes of 1025 .. 8192 points that
  * the packed-code kernel handed back to the general kernels (heavy ties: more than 1024 points of a

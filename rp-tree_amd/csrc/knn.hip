@@ -1827,7 +1827,11 @@ constexpr int kWC = 512;  // candidates per batch of one wave
 constexpr int kWR = 128;  // leaf ranges per query
 constexpr int kWT = 64;   // trees (lane = tree)
 // the variant is chosen when trees x minLeaf (~ candidates per query) is at most this
-constexpr int64_t kWaveCandidates = 1024;
+// (round 3: trees x the leaf size the topology gives, at most 700 — it was trees x minLeaf <= 1024.
+// With the threshold selection, the single traversal and the in-kernel retry the workgroup kernel
+// answers an 8-tree shard of C2 (8 x 122 candidates) in 0.67 ms, this one in 0.96; the 8 x 76 of a
+// C4 shard stay here: 3.2 against 5.9 ms per 100 000 queries)
+constexpr int64_t kWaveCandidates = 700;
 
 __device__ inline void wave_sync() {  // LDS writes of the wave visible to all its lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -3037,8 +3041,10 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const int64_t force = ctx->opt.knn_wave;  // -1 auto
   const size_t wbytes = fused_wave_bytes(data->d, sizeof(TA));
   const int vote = dedup >> 8;  // voting mode: the workgroup kernel, all-exact distances
+  int64_t leaf = f->n;  // the size splitting stops at: the first level's node size <= minLeaf, or depth L
+  for (int l = 0; l < f->L && leaf > (int64_t)f->min_leaf; ++l) leaf -= leaf / 2;
   bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 &&
-              (int64_t)f->T * f->min_leaf <= kWaveCandidates;
+              (int64_t)f->T * (leaf > 0 ? leaf : 1) <= kWaveCandidates;
   if (force >= 0) wave = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
   if (vote > 0 || data->csr) wave = false;
   // debug_stamps: phase clocks of one wave of the wave kernel, printed after the launch

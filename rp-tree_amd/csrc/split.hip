@@ -3689,7 +3689,21 @@ __global__ __launch_bounds__(256) void sample_range_kernel(const TIn* __restrict
       rl[k * CG + c] = c0 + c < C ? R[(int64_t)(c0 + c) * d + k0 + k] : 0.0;
     }
     __syncthreads();
-    for (int k = 0; k < kn; ++k) {
+    // a thread walks its own sample row: sixteen elements of it in flight at a time (one load per
+    // multiply-add round left the walk waiting for HBM d times: 81 us of a 4.6 ms C2 build)
+    int k = 0;
+    for (; k + 16 <= kn; k += 16) {
+      TIn xv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xv[u] = xr[k0 + k + u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const double x = sample_value(xv[u]);
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[c] = __builtin_fma(x, rl[(k + u) * CG + c], acc[c]);
+      }
+    }
+    for (; k < kn; ++k) {
       const double x = sample_value(xr[k0 + k]);
 #pragma unroll
       for (int c = 0; c < CG; ++c) acc[c] = __builtin_fma(x, rl[k * CG + c], acc[c]);

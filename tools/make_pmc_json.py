@@ -68,9 +68,11 @@ if ex:
     out["proj_exact_lds"] = dict(rw(e), cols=32)
 kn = full("knn_fused_kernel")
 for name, e in kn.items():
-    key = "f32_prefilter" if ",true,false>" in name else "all_f64"
+    # template arguments: <TD, TK, PRE32, CSR, I8>
+    key = ("int8_prefilter" if name.endswith(",true,false,true>") else
+           "prefilter" if ",true,false" in name else "all_f64")
     out.setdefault("knn_fused_kernel", {})["%s (%s)" % (key, name)] = rw(e)
-    if key == "f32_prefilter":
+    if key in ("int8_prefilter", "prefilter") and ("knn_fused" not in out or key == "int8_prefilter"):
         out["knn_fused"] = {"hbm_bytes_per_launch": rw(e)["hbm_bytes_per_launch"], "kernel": name}
 out["split"] = {}
 for pre in ("wsub_kernel", "wsort_kernel", "wpack_kernel", "stream_assign", "stream_hist", "stream_to_perm", "stream_mid"):
