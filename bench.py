@@ -881,9 +881,13 @@ def main():
                          "measured_stream_peak": MFMA_F64_STREAM_TF,
                          "frac_of_measured_stream": mfma_achieved / MFMA_F64_STREAM_TF
                          if args.mode == "mfma" else 0.0,
-                         "measured_stream_source": "profiles/r03_mfma_f64_peak.txt: independent "
-                                                   "v_mfma_f64_16x16x4_f64 on every SIMD sustain "
-                                                   "44-47 TFLOP/s (108-115 cycles per MFMA)",
+                         "measured_stream_source": "profiles/r03_mfma_f64_peak.txt: a naive loop of "
+                                                   "independent v_mfma_f64_16x16x4_f64 on every SIMD "
+                                                   "sustains 44-47 TFLOP/s at a measured 2.29 GHz (104 "
+                                                   "elapsed cycles per MFMA; this kernel: 88 at the "
+                                                   "2.11 GHz it runs at) - reported, NOT a roof",
+                         "shader_clock_ghz_under_this_kernel": 2.11,
+                         "clock_source": "GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r03_pmc.csv",
                          # rocprofv3 --pmc MfmaUtil of the same launches (profiles/), not live
                          "mfma_busy_pmc_pct": mfma_busy},
             # the reference formulation projects one tree level (32 hyperplanes) per read of X:
