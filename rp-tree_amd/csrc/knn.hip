@@ -52,32 +52,52 @@ __device__ inline void traverse(const double* __restrict__ thr, const double* __
                                 int64_t pq_stride, int L, int min_leaf, int64_t N, Emit emit) {
   unsigned int pending = 0, heap = 0;
   int level = 0, off = 0, n = (int)N;
+  // Two levels per memory round trip (round 3): the walk is a chain of dependent node loads — 13 at
+  // C2, a fifth of a query's life in the fused kernels — so a node's record is fetched together
+  // with the records of BOTH its children (adjacent heap slots), and the child the decision picks
+  // is decided on at once.  `last` clamps the children of the deepest Bin level into the arrays
+  // (their records are never used: the level test comes first).
+  const unsigned int last = L > 0 ? (1u << L) - 2u : 0u;
+  auto step = [&](double th, double lo, double hi, double proj) {  // RPTree.hs:303-314
+    const double dl = fabs(lo - proj);  // :306
+    const double dr = fabs(hi - proj);  // :307
+    const int nh = n / 2;
+    const bool both = (proj < th && dl > dr) || (proj > th && dl < dr);  // :309-313
+    if (both) {  // the right child waits, continue left
+      pending |= 1u << level;
+      heap = 2 * heap + 1;
+      n = nh;
+    } else if (proj < th) {  // :311
+      heap = 2 * heap + 1;
+      n = nh;
+    } else {  // :314 (includes proj == thr)
+      heap = 2 * heap + 2;
+      off += nh;
+      n = n - nh;
+    }
+    ++level;
+  };
   for (;;) {
     for (;;) {
       if (level >= L || n <= min_leaf) {  // Tip (RPTree.hs:299)
         emit(off, n);
         break;
       }
-      const double proj = (double)pq[(int64_t)level * pq_stride];  // RPTree.hs:303-304
-      const double th = thr[heap];
-      const double dl = fabs(mglo[heap] - proj);  // :306
-      const double dr = fabs(mghi[heap] - proj);  // :307
-      const int nh = n / 2;
-      const bool both = (proj < th && dl > dr) || (proj > th && dl < dr);  // :309-313
-      const bool left = proj < th;
-      if (both) {  // the right child waits, continue left
-        pending |= 1u << level;
-        heap = 2 * heap + 1;
-        n = nh;
-      } else if (left) {  // :311
-        heap = 2 * heap + 1;
-        n = nh;
-      } else {  // :314 (includes proj == thr)
-        heap = 2 * heap + 2;
-        off += nh;
-        n = n - nh;
+      const unsigned int c0 = 2 * heap + 1 < last ? 2 * heap + 1 : last;
+      const unsigned int c1 = 2 * heap + 2 < last ? 2 * heap + 2 : last;
+      const int l1 = level + 1 < L ? level + 1 : level;
+      const double proj = (double)pq[(int64_t)level * pq_stride];
+      const double proj1 = (double)pq[(int64_t)l1 * pq_stride];
+      const double th = thr[heap], lo = mglo[heap], hi = mghi[heap];
+      const double th0 = thr[c0], lo0 = mglo[c0], hi0 = mghi[c0];
+      const double th1 = thr[c1], lo1 = mglo[c1], hi1 = mghi[c1];
+      step(th, lo, hi, proj);
+      if (level >= L || n <= min_leaf) {
+        emit(off, n);
+        break;
       }
-      ++level;
+      const bool right = (heap & 1u) == 0u;  // heap = 2 h + 2
+      step(right ? th1 : th0, right ? lo1 : lo0, right ? hi1 : hi0, proj1);
     }
     if (!pending) break;
     const int l = 31 - __clz((int)pending);
