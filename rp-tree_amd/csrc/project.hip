@@ -599,20 +599,20 @@ __global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, 
 }
 
 template <class TIn, class TC, int D, int CBT, bool CODES = false>
-__global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
-                                                         const TC* __restrict__ Apad, int c0,
-                                                         int ncol, TC* __restrict__ P,
-                                                         int64_t ldp, int64_t ntiles,
-                                                         int64_t ldx /* row stride of X */,
-                                                         int accumulate /* P += instead of = */,
-                                                         int kvalid /* elements of the K chunk that
-                                                                       exist (the rest reads as 0) */,
-                                                         uint16_t* __restrict__ Cd /* codes.h; null
-                                                            unless this pass completes the sums */,
-                                                         int64_t ldc,
-                                                         const unsigned long long* __restrict__ cmm,
-                                                         int cL, int cLc /* codes for the columns
-                                                            whose level (column % cL) is < cLc */) {
+__device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_t n,
+                                               const TC* __restrict__ Apad, int c0,
+                                               int ncol, TC* __restrict__ P,
+                                               int64_t ldp, int64_t ntiles,
+                                               int64_t ldx /* row stride of X */,
+                                               int accumulate /* P += instead of = */,
+                                               int kvalid /* elements of the K chunk that
+                                                             exist (the rest reads as 0) */,
+                                               uint16_t* __restrict__ Cd /* codes.h; null
+                                                  unless this pass completes the sums */,
+                                               int64_t ldc,
+                                               const unsigned long long* __restrict__ cmm,
+                                               int cL, int cLc /* codes for the columns
+                                                  whose level (column % cL) is < cLc */) {
   constexpr int STEPS = D / 4;
   constexpr int PIECE = 16 / (int)sizeof(TIn);            // elements per 16-B piece
   constexpr int PIECES_PER_ROW = D / PIECE;
@@ -695,6 +695,34 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
     tile_store<TC, CBT, CODES>(acc, P, ldp, c0, ncol, t * 16, n, lane, &cctl, cmask);
     t = tn;
   }
+}
+
+template <class TIn, class TC, int D, int CBT, bool CODES = false>
+__global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
+                                                         const TC* __restrict__ Apad, int c0, int ncol,
+                                                         TC* __restrict__ P, int64_t ldp, int64_t ntiles,
+                                                         int64_t ldx, int accumulate, int kvalid,
+                                                         uint16_t* __restrict__ Cd, int64_t ldc,
+                                                         const unsigned long long* __restrict__ cmm,
+                                                         int cL, int cLc) {
+  proj_fast_body<TIn, TC, D, CBT, CODES>(X, n, Apad, c0, ncol, P, ldp, ntiles, ldx, accumulate, kvalid, Cd,
+                                         ldc, cmm, cL, cLc);
+}
+
+// Few rows, many hyperplanes (a query batch against every (tree, level) of a forest): ALL column
+// groups of 32 in ONE launch, blockIdx.y = group (fragments Apad[group][2][D/4][64]); the rows are
+// read once per group — nothing next to the launches this saves (C2: ten 96/128-column launches and
+// fragment copies of 10 000 rows took 0.15 ms of a 1.5 ms query batch).  Same MFMA sequence per
+// (row, hyperplane) as the other kernels: same bits.
+template <class TIn, class TC, int D>
+__global__ __launch_bounds__(256, 2) void proj_mfma_fast_groups(const TIn* __restrict__ X, int64_t n,
+                                                                const TC* __restrict__ Apad, int C,
+                                                                TC* __restrict__ P, int64_t ldp,
+                                                                int64_t ntiles, int64_t ldx, int kvalid) {
+  const int c0 = (int)blockIdx.y * 32;
+  const int ncol = C - c0 < 32 ? C - c0 : 32;
+  proj_fast_body<TIn, TC, D, 2, false>(X, n, Apad + (size_t)blockIdx.y * 2 * (D / 4) * 64, c0, ncol, P, ldp,
+                                       ntiles, ldx, 0, kvalid, nullptr, 0, nullptr, 1, 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1412,6 +1440,23 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
     // continue the sums in P; a last chunk shorter than 128 reads as zero past the row's end
     // (and the wide kernel skips its empty K slices).
     const int nkc = (ds->d + D - 1) / D;
+    if (nkc == 1 && C > 32 && !co && n <= 65536 && !ctx->opt.proj_narrow) {  // see proj_mfma_fast_groups
+      const int ngrp = (C + 31) / 32;
+      const size_t frag1 = (size_t)(D / 4) * 64;
+      DevBuf<TC> Ag;
+      RPT_TRY(Ag.alloc((size_t)ngrp * 2 * frag1));
+      hipLaunchKernelGGL(pad_A_kernel<TC>, dim3(64), dim3(256), 0, ctx->stream, R_dev, C, ds->d, D, ngrp, 2,
+                         0, 0, Ag.p);
+      int64_t bx = (ntiles + 3) / 4;
+      const int64_t capx = ((int64_t)ctx->n_cu * 8 + ngrp - 1) / ngrp;
+      if (bx > capx) bx = capx;
+      if (bx < 1) bx = 1;
+      ProfScope pn(ctx, RPT_PROF_PROJECT);
+      hipLaunchKernelGGL((proj_mfma_fast_groups<TIn, TC, D>), dim3((unsigned)bx, (unsigned)ngrp), dim3(256), 0,
+                         ctx->stream, (const TIn*)ds->X, n, Ag.p, C, P, n, ntiles, (int64_t)ds->d, ds->d);
+      RPT_HIP(hipGetLastError());
+      return RPT_OK;  // Ag returns to the stream-ordered allocator
+    }
     // Column passes.  Full passes take 96 hyperplanes per read of X (6 column tiles: the point
     // where the f64 matrix pipe and HBM take about as long).  What is left goes to the smallest
     // shape that holds it (the matrix pipe pays for padded columns too): <= 32 columns the
