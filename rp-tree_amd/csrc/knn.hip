@@ -822,7 +822,47 @@ __device__ __forceinline__ void batch_distances_i8(const uint8_t* __restrict__ X
     }
     return;
   }
-  // long rows: one row per load instruction (lanes beyond the row idle), eight rows in flight
+  if (lpr <= 64) {
+    // rows of up to 1024 bytes: one row per load instruction (lanes beyond the row idle), SIXTEEN rows
+    // in flight — with eight a 768-byte row kept half the bytes of the bf16 kernel's rows in flight
+    // and the pass was no faster than reading the bf16 rows themselves (C5: 82 against 68 ms)
+    constexpr int RF = 16;
+    const bool on = lane < lpr;
+    uint4 hv = uint4{0u, 0u, 0u, 0u}, lv = hv;
+    if (on) {
+      hv = reinterpret_cast<const uint4*>(planes)[lane];
+      lv = reinterpret_cast<const uint4*>(planes + nw)[lane];
+    }
+    const unsigned int hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
+    for (int i0 = first + slot * RF; i0 < fill; i0 += nslots * RF) {
+      uint4 x[RF];
+#pragma unroll
+      for (int u = 0; u < RF; ++u) {
+        x[u] = uint4{0u, 0u, 0u, 0u};
+        if (on) x[u] = *reinterpret_cast<const uint4*>(X8 + (int64_t)cid[i0 + u < fill ? i0 + u : i0] * d + lane * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < RF; ++u) {
+        const unsigned int xw[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+        unsigned int a = 0, b = 0, cc = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a = __builtin_amdgcn_udot4(xw[w], hw[w], a, false);
+          b = __builtin_amdgcn_udot4(xw[w], lw[w], b, false);
+          cc = __builtin_amdgcn_udot4(xw[w], xw[w], cc, false);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          a += __shfl_xor(a, o);
+          b += __shfl_xor(b, o);
+          cc += __shfl_xor(cc, o);
+        }
+        if (lane == 0 && i0 + u < fill)
+          cdist[i0 + u] = 65536.0 * (double)cc - 131072.0 * (double)a - 512.0 * (double)b + kq;
+      }
+    }
+    return;
+  }
+  // longer rows: one row per load instruction and 1024-byte piece, eight rows in flight
   for (int i0 = first + slot * 8; i0 < fill; i0 += nslots * 8) {
     unsigned int a[8], b[8], cc[8];
 #pragma unroll
@@ -3117,7 +3157,10 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   // (the one-wave kernel takes its threshold from the 64 per-lane minima: beyond the 48th of them
   // the candidate list outgrows its 128 slots)
   const int kcap8 = wave ? 48 : kBK;
-  int kp8 = kp8_env > k && kp8_env < kcap8 ? kp8_env : k + (k > 48 ? k : 48);
+  // (the width of the band at the cut grows with the square root of the row length: sqrt(d / 128)
+  // times the margin that certifies C2's 128-element rows)
+  const int margin8 = (int)((k > 48 ? k : 48) * (data->d > 128 ? std::sqrt((double)data->d / 128.0) : 1.0));
+  int kp8 = kp8_env > k && kp8_env < kcap8 ? kp8_env : k + margin8;
   if (kp8 > kcap8 - 1) kp8 = kcap8 - 1;
   const bool sh8 = !data->csr && data->shadow8 && !ctx->opt.knn_no_pre8 && !f->pre8_off &&
                    kp8 >= k + 8 && dedup == 0 && !rerun && !ctx->opt.knn_no_pre32 &&
