@@ -82,3 +82,37 @@ def test_argument_errors_do_not_abort(rp):
     assert L.rpt_topology(10, 40, 1, None, 0, C.byref(cnt)) == -1      # RPT_E_ARG
     assert b"topology" in L.rpt_last_error()
     assert L.rpt_ctx_sync(None) == -1
+
+
+def test_int8_ranking_value_identity():
+    """The integer the int8 kNN tier ranks on (csrc/knn.hip, Sh8): with cu = c + 128 (the stored
+    byte), g = 256 H + lo the 16-bit query grid value, hu = H + 128,
+        sum (g - 256 c)^2 = 65536 sum cu^2 - 131072 sum cu hu - 512 sum cu lo + K,
+        K = sum g^2 + 2^24 sum hu + 2^16 sum lo - 2^30 d
+    (the sums of cu alone cancel) — checked in exact integer arithmetic over the whole value range,
+    and the triangle inequality the certificate uses: | |q - x| - (s/256) sqrt(I) | <= eq + ex."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    for d in (16, 128, 768):
+        c = rng.integers(-127, 128, d).astype(object)
+        g = rng.integers(-32768, 32768, d).astype(object)
+        c[:2], g[:2] = [-127, 127], [-32768, 32767]
+        cu = c + 128
+        H = np.array([int(v) >> 8 for v in g], dtype=object)
+        lo = np.array([int(v) & 255 for v in g], dtype=object)
+        assert all(256 * int(h) + int(l) == int(v) for h, l, v in zip(H, lo, g))
+        hu = H + 128
+        assert all(0 <= int(v) <= 255 for v in list(cu) + list(hu) + list(lo))
+        K = int((g * g).sum()) + (1 << 24) * int(hu.sum()) + (1 << 16) * int(lo.sum()) - (1 << 30) * d
+        I = 65536 * int((cu * cu).sum()) - 131072 * int((cu * hu).sum()) - 512 * int((cu * lo).sum()) + K
+        assert I == int(((g - 256 * c) ** 2).sum()) and I >= 0
+        assert I < 2 ** 53                       # exact in the kernel's doubles
+    # the certificate's inequality on real vectors
+    d = 128
+    x, q = rng.standard_normal(d) * 0.5 + 2.0, rng.standard_normal(d) * 0.5
+    s = 4.77 / 127.0
+    cq = np.clip(np.rint(x / s), -127, 127)
+    gq = np.clip(np.rint(256.0 * q / s), -32768, 32767)
+    ex, eq = np.linalg.norm(x - s * cq), np.linalg.norm(q - (s / 256.0) * gq)
+    approx = (s / 256.0) * np.sqrt(((gq - 256.0 * cq) ** 2).sum())
+    assert abs(np.linalg.norm(q - x) - approx) <= (eq + ex) * (1 + 1e-12)
