@@ -626,9 +626,10 @@ __global__ __launch_bounds__(256) void topk_dense_kernel(
 // reduced by the same fixed butterfly whichever wave handles it, so the value does not depend
 // on the kernel variant.  Each wave keeps EIGHT load instructions in flight.
 template <class TD, class TA, int INFL = 8 /* load instructions in flight per wave */,
-          bool SQRT = true /* false: leave the squared distance (a TA value) in cdist */>
+          bool SQRT = true /* false: leave the squared distance (a TA value) in cdist */,
+          class TO = double /* element type of the batch values */>
 __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d, const int* cid,
-                                       double* cdist, const TA* qs, int first, int fill, int slot,
+                                       TO* cdist, const TA* qs, int first, int fill, int slot,
                                        int nslots, int lane) {
   constexpr int VV = 16 / (int)sizeof(TD);
   const int lpr = (d % VV) == 0 ? d / VV : 0;  // lanes one row needs with 16-byte loads
@@ -654,7 +655,7 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
         }
         for (int o = lpr >> 1; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);  // fixed butterfly
         const int i = i0 + u * rpw + sub;
-        if (jl == 0 && i < fill) cdist[i] = SQRT ? (double)sqrt((double)s[u]) : (double)s[u];
+        if (jl == 0 && i < fill) cdist[i] = SQRT ? (TO)sqrt((double)s[u]) : (TO)s[u];
       }
     }
   } else
@@ -696,7 +697,7 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const TA tot = wave_sum(s[u]);
-      if (lane == 0 && i0 + u < fill) cdist[i0 + u] = SQRT ? (double)sqrt((double)tot) : (double)tot;
+      if (lane == 0 && i0 + u < fill) cdist[i0 + u] = SQRT ? (TO)sqrt((double)tot) : (TO)tot;
     }
   }
 }
@@ -782,9 +783,9 @@ __device__ __forceinline__ int count_below2(const double* dd, const int* pp, int
 
 // integer squared distances (see above) of the candidates [first, fill) -> cdist (exact integers
 // as doubles, in units of (s / 256)^2)
-template <int INFL = 16>
+template <int INFL = 16, class TO = double>
 __device__ __forceinline__ void batch_distances_i8(const uint8_t* __restrict__ X8, int d, const int* cid,
-                                                   double* cdist, const unsigned int* planes, double kq,
+                                                   TO* cdist, const unsigned int* planes, double kq,
                                                    int first, int fill, int slot, int nslots, int lane) {
   const int lpr = d / 16;  // lanes one row needs with 16-byte loads
   const int nw = d / 4;
@@ -817,7 +818,7 @@ __device__ __forceinline__ void batch_distances_i8(const uint8_t* __restrict__ X
         }
         const int i = i0 + u * rpw + sub;
         if (piece == 0 && i < fill)
-          cdist[i] = 65536.0 * (double)cc - 131072.0 * (double)a - 512.0 * (double)b + kq;
+          cdist[i] = (TO)(65536.0 * (double)cc - 131072.0 * (double)a - 512.0 * (double)b + kq);
       }
     }
     return;
@@ -857,7 +858,7 @@ __device__ __forceinline__ void batch_distances_i8(const uint8_t* __restrict__ X
           cc += __shfl_xor(cc, o);
         }
         if (lane == 0 && i0 + u < fill)
-          cdist[i0 + u] = 65536.0 * (double)cc - 131072.0 * (double)a - 512.0 * (double)b + kq;
+          cdist[i0 + u] = (TO)(65536.0 * (double)cc - 131072.0 * (double)a - 512.0 * (double)b + kq);
       }
     }
     return;
@@ -895,7 +896,7 @@ __device__ __forceinline__ void batch_distances_i8(const uint8_t* __restrict__ X
         tc += __shfl_xor(tc, o);
       }
       if (lane == 0 && i0 + u < fill)
-        cdist[i0 + u] = 65536.0 * (double)tc - 131072.0 * (double)ta - 512.0 * (double)tb + kq;
+        cdist[i0 + u] = (TO)(65536.0 * (double)tc - 131072.0 * (double)ta - 512.0 * (double)tb + kq);
     }
   }
 }
@@ -1203,10 +1204,19 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
   KSTAMP();
   typedef typename AccOf<TD>::type TA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* cdist = reinterpret_cast<double*>(smem);                 // [kFC]
-  int* cid = reinterpret_cast<int*>(cdist + kFC);                  // [kFC]
-  int* cpos = cid + kFC;                                           // [kFC]
-  int64_t* rpoff = reinterpret_cast<int64_t*>(cpos + kFC);         // [kFR]
+  // Dense prefilter instantiations (round 3): the batch values are f32 (what their packed keys hold
+  // anyway) and a candidate's position is computed, not stored, so the same 32 KB hold TWICE the
+  // candidates — C2's 3922 per query in ONE batch: one fill, one selection.
+  constexpr bool WIDE = PRE32 && !CSR;
+  constexpr int FC = WIDE ? 2 * kFC : kFC;   // candidates per batch
+  typedef typename std::conditional<WIDE, float, double>::type TB;
+  TB* cval = reinterpret_cast<TB*>(smem);                          // [FC] batch values
+  double* cdist = reinterpret_cast<double*>(smem);                 // the same slab as doubles: [kFC]
+                                                                   // (exact paths, refine, slots, lists)
+  int* cid = reinterpret_cast<int*>(cdist + kFC);                  // [FC] (WIDE) / [kFC]
+  int* cpos = WIDE ? cid + 1024 : cid + kFC;                       // [kFC]; WIDE: only the refine
+                                                                   // stage's <= kBKx positions
+  int64_t* rpoff = reinterpret_cast<int64_t*>(cid + 2 * kFC);      // [kFR]
   int* rn = reinterpret_cast<int*>(rpoff + kFR);                   // [kFR]
   int* tcnt = rn + kFR;                                            // [1024] per-tree counts
   int* trng = tcnt + 1024;                                         // [1024]
@@ -1426,15 +1436,18 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
   // are compacted into a list and ranked by counting on the full keys: three barriers per batch
   // whatever ksel is (the rounds cost 0.03 ms per kept entry and 10 000 queries at C2).  A list of
   // more than 256 entries (values tied by the hundred) falls back to the rounds.
-  auto select_packed = [&](int fill, int ksel, int have /* entries of a list from earlier batches */) -> int {
-    constexpr int E = kFC / 256;
+  auto select_packed = [&](int fill, int ksel, int have /* entries of a list from earlier batches */,
+                           int pb0 /* WIDE: position of the batch's first NEW candidate */) -> int {
+    constexpr int E = FC / 256;
     unsigned long long key[E];
     unsigned int vmin = ~0u;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int i = tid + 256 * e;
-      key[e] = i < fill ? ((unsigned long long)__float_as_uint((float)cdist[i]) << 32) | (unsigned int)cpos[i]
-                        : ~0ULL;
+      unsigned int pos;
+      if constexpr (WIDE) pos = (unsigned int)(i < have ? bpos[i < kBKx ? i : 0] : pb0 + (i - have));
+      else pos = (unsigned int)cpos[i < kFC ? i : 0];
+      key[e] = i < fill ? ((unsigned long long)__float_as_uint((float)cval[i]) << 32) | pos : ~0ULL;
       const unsigned int v = (unsigned int)(key[e] >> 32);
       if (i < fill) vmin = v < vmin ? v : vmin;
     }
@@ -1620,15 +1633,16 @@ retry_wider:
   while ((vote > 0 ? vsrc < nc_tot : pos_base < nc_tot) || best == 0) {
     // ---- fill the batch: best list first (keeps its positions), then new candidates ----
     for (int i = tid; i < best; i += 256) {
-      cdist[i] = bdist[i];
+      cval[i] = (TB)bdist[i];
       cid[i] = bid[i];
-      cpos[i] = bpos[i];
+      if constexpr (!WIDE) cpos[i] = bpos[i];
     }
     int fill = best;
     const int first_new = fill;
+    const int pb0 = pos_base;
     // voting mode: the heads of the runs of at least `vote` equal ids, 256 entries of vid per
     // round, compacted into the batch with their index in vid as position (ascending id order)
-    while (vote > 0 && vsrc < nc_tot && fill + 256 <= kFC) {
+    while (!WIDE && vote > 0 && vsrc < nc_tot && fill + 256 <= kFC) {
       const int i = vsrc + tid;
       int keep = 0;
       if (i < nc_tot && (i == 0 || vid[i] != vid[i - 1])) {
@@ -1656,30 +1670,46 @@ retry_wider:
     // load per range, was a sixth of a C2 query's life)
     if (vote == 0) {
       int take = nc_tot - pos_base;
-      if (take > kFC - fill) take = kFC - fill;
-      constexpr int EF = kFC / 256;
+      if (take > FC - fill) take = FC - fill;
+      constexpr int EF = FC / 256;
+      // a thread takes EF CONSECUTIVE slots: one search for the first, then a walk along rstart (a
+      // leaf range holds ~100 candidates: a boundary or two per thread) — sixteen independent
+      // nine-step searches per thread were 13 % of a C2 query's life
       int64_t addr[EF];
-#pragma unroll
-      for (int e = 0; e < EF; ++e) {
-        const int s2 = tid + 256 * e;
-        const int c = pos_base + (s2 < take ? s2 : 0);
+      {
+        const int s0 = tid * EF;
+        const int c0 = pos_base + (s0 < take ? s0 : 0);
         int lo = 0;
 #pragma unroll
         for (int step = kFR / 2; step > 0; step >>= 1) {
           const int m = lo + step;
-          if (m < nr_tot && rstart[m] <= c) lo = m;
+          if (m < nr_tot && rstart[m] <= c0) lo = m;
         }
-        addr[e] = rpoff[lo] + (c - rstart[lo]);
+        int rs = rstart[lo], re = rstart[lo + 1];
+        int64_t rbase = rpoff[lo];
+#pragma unroll
+        for (int e = 0; e < EF; ++e) {
+          const int c = c0 + e;
+          if (s0 + e < take) {
+            while (c >= re) {  // (c < nc_tot = rstart[nr_tot]: ends; empty ranges are stepped over)
+              ++lo;
+              rs = re;
+              re = rstart[lo + 1];
+              rbase = rpoff[lo];
+            }
+          }
+          addr[e] = rbase + (c - rs);
+        }
       }
       int32_t idv[EF];
 #pragma unroll
-      for (int e = 0; e < EF; ++e) idv[e] = tid + 256 * e < take ? perm[addr[e]] : 0;
+      for (int e = 0; e < EF; ++e) idv[e] = tid * EF + e < take ? perm[addr[e]] : 0;
 #pragma unroll
       for (int e = 0; e < EF; ++e) {
-        const int s2 = tid + 256 * e;
+        const int s2 = tid * EF + e;
         if (s2 < take) {
           cid[fill + s2] = idv[e];
-          cpos[fill + s2] = pos_base + s2;
+          if constexpr (!WIDE) cpos[fill + s2] = pos_base + s2;
         }
       }
       fill += take;
@@ -1701,15 +1731,15 @@ retry_wider:
                               cdist, qsd, s_qn, first_new, fill, wave, lane);
     else if constexpr (PRE32) {
       if constexpr (I8)  // int8 rows: an eighth of the f64 bytes, integer ranking values
-        batch_distances_i8<16>(static_cast<const uint8_t*>(Xf), d, cid, cdist,
-                              reinterpret_cast<const unsigned int*>(qs32), q8k, first_new, fill, wave, 4,
-                              lane);
+        batch_distances_i8<16, TB>(static_cast<const uint8_t*>(Xf), d, cid, cval,
+                                   reinterpret_cast<const unsigned int*>(qs32), q8k, first_new, fill, wave, 4,
+                                   lane);
       else if (sh16)  // half rows: a quarter of the f64 bytes (the query stays f32)
-        batch_distances<_Float16, float, 16, false>(static_cast<const _Float16*>(Xf), d, cid, cdist, qs32,
-                                                    first_new, fill, wave, 4, lane);
+        batch_distances<_Float16, float, 16, false, TB>(static_cast<const _Float16*>(Xf), d, cid, cval, qs32,
+                                                        first_new, fill, wave, 4, lane);
       else
-        batch_distances<float, float, 16, false>(static_cast<const float*>(Xf), d, cid, cdist, qs32,
-                                                 first_new, fill, wave, 4, lane);
+        batch_distances<float, float, 16, false, TB>(static_cast<const float*>(Xf), d, cid, cval, qs32,
+                                                     first_new, fill, wave, 4, lane);
     } else if (pack32)
       batch_distances<TD, TA, (sizeof(TD) < 8 ? 16 : 8), false>(X, d, cid, cdist, qs, first_new, fill, wave, 4, lane);
     else
@@ -1718,7 +1748,8 @@ retry_wider:
     KSTAMP();  // distances
     // dense f64 rows ranked on butterfly sums keep kLfMargin entries more (finalize_leftfold)
     const int ksel = (!CSR && std::is_same<TD, double>::value) ? k + kLfMargin : k;
-    const int nb = PRE32 ? select_packed(fill, k1, best) : pack32 ? select_packed(fill, k, best) : select(fill, ksel, dedup);
+    const int nb = PRE32 ? select_packed(fill, k1, best, pb0) : pack32 ? select_packed(fill, k, best, pb0)
+                                                                    : select(fill, ksel, dedup);
     best = nb;
     KSTAMP();  // selection
     if (vote > 0 ? vsrc >= nc_tot : pos_base >= nc_tot) break;
