@@ -26,6 +26,10 @@ for it in range(3):
     f = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_MFMA)
     _lib.check(L_.rpt_knn_dev(ctx._h, f._h, ds._h, qs._h, k, 0, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr()))
 ctx.sync()
+import os
+if os.environ.get("SHARD4_PROF"):          # the HIP-event spans bench.py records (rpt_prof_enable): their cost
+    _lib.check(L_.rpt_prof_reset(ctx._h))
+    _lib.check(L_.rpt_prof_enable(ctx._h, 1))
 t0 = time.perf_counter()
 for it in range(reps):
     rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_MFMA).close()
