@@ -264,10 +264,12 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
  * candidate order (tree ascending, then leaf order).  ids/dist are [nq][k]; count[nq] is the
  * number of valid entries (< k when fewer candidates).  Unused slots: id -1, dist +inf. */
 /* Memory note: the first rpt_knn_* call with duplicates kept (flags 0) and k <= 42 on a dense
- * f64 dataset builds an f32 copy of it on the device (+50 % of the dataset's size, freed with the
- * dataset), an IEEE-half copy (+25 %) when its elements fit the half range, and an int8 copy
- * (+12.5 %; one scale for the whole dataset, rows of a multiple of 16 elements; f32 datasets get the
- * half and int8 copies): candidates are ranked on the int8 copy (k + max(48, k) kept; the ranking
+ * f64 dataset builds an int8 copy of it on the device (+12.5 % of the dataset's size, freed with the
+ * dataset; one scale for the whole dataset, rows of a multiple of 16 elements).  Only when that copy
+ * cannot rank the call (other row lengths, k >= 40 on small tree shards, no memory, or a forest that
+ * has dropped the tier) an f32 copy (+50 %) and an IEEE-half copy (+25 %, elements within the half
+ * range) are built as well; f32 datasets likewise get the int8 copy first, the half copy when
+ * needed: candidates are ranked on the int8 copy (k + max(48, k) kept; the ranking
  * value is an exact integer, the cut is certified through the triangle inequality with the
  * quantisation errors of the query and of the worst row), the half copy (k + max(8, k/2) kept) or
  * the f32 copy (k + max(6, k/2) kept), exact f64 distances are computed for the kept ones, and a

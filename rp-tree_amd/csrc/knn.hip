@@ -3196,7 +3196,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const bool sh8 = !data->csr && data->shadow8 && !ctx->opt.knn_no_pre8 && !f->pre8_off &&
                    kp8 >= k + 8 && dedup == 0 && !rerun && !ctx->opt.knn_no_pre32 &&
                    !ctx->opt.knn_no_pre16 && !f->pre16_off && !f->prefilter_off &&
-                   ((std::is_same<TD, double>::value && data->shadow32) || std::is_same<TD, float>::value ||
+                   (std::is_same<TD, double>::value || std::is_same<TD, float>::value ||
                     (std::is_same<TD, __hip_bfloat16>::value && !wave));  // (bf16: the workgroup kernel only)
   if (sh8) kp = kp8;
   const Sh8 s8 = sh8 ? Sh8{data->s8_scale, data->s8_emax} : Sh8{0.0, 0.0};
@@ -3390,10 +3390,15 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   if (f->pdtype == RPT_F64 && dedup == 0 && prefilter_keep(k) < kFK && !ctx->opt.knn_no_pre32 &&
       !f->prefilter_off) {  // (dedup carries the vote threshold too: no prefilter when voting)
     if (!data->csr) {
-      RPT_TRY(ensure_shadow(ctx, data));  // once per dataset
-      if (data->shadow32 && !ctx->opt.knn_no_pre16 && !f->pre16_off) RPT_TRY(ensure_shadow16(ctx, data));
-      if (data->shadow32 && !ctx->opt.knn_no_pre16 && !f->pre16_off && !ctx->opt.knn_no_pre8 && !f->pre8_off)
-        RPT_TRY(ensure_shadow8(ctx, data));
+      // the int8 shadow first; the f32 and half ones (+75 % of the dataset) only when it cannot rank
+      // this call: rows that are not a multiple of 16 elements, k beyond what the tier keeps in the
+      // one-wave kernel, no memory, or a forest that has dropped the tier (once per dataset each)
+      const bool want8 = !ctx->opt.knn_no_pre16 && !f->pre16_off && !ctx->opt.knn_no_pre8 && !f->pre8_off;
+      if (want8) RPT_TRY(ensure_shadow8(ctx, data));
+      if (!(want8 && data->shadow8 && k + 8 <= 47)) {
+        RPT_TRY(ensure_shadow(ctx, data));
+        if (data->shadow32 && !ctx->opt.knn_no_pre16 && !f->pre16_off) RPT_TRY(ensure_shadow16(ctx, data));
+      }
     }
     // CSR rows: the (u16, f32) shadow halves the bytes of the ranking pass but NOT its time — at C3
     // the exact kernel already gathers rows at 6.4 TB/s and the f32 pass, with its 17 selection
@@ -3407,8 +3412,9 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   int tier = 0;
   if (data->dtype == RPT_F32 && !data->csr && dedup == 0 && !ctx->opt.knn_no_pre16 &&
       !ctx->opt.knn_no_pre32 && !f->pre16_off) {
-    RPT_TRY(ensure_shadow16(ctx, data));
-    if (!ctx->opt.knn_no_pre8 && !f->pre8_off) RPT_TRY(ensure_shadow8(ctx, data));
+    const bool want8 = !ctx->opt.knn_no_pre8 && !f->pre8_off;
+    if (want8) RPT_TRY(ensure_shadow8(ctx, data));
+    if (!(want8 && data->shadow8 && k + 8 <= 47)) RPT_TRY(ensure_shadow16(ctx, data));
   }
   // bf16 rows: the int8 tier exists (identical answers, tested) but is OPT-IN (knn_kp8 > 0): at C5
   // (10 M x 768, k = 50) the cut needs 200 kept rows to certify 99 % of the queries and the pass is
