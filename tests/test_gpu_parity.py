@@ -1088,3 +1088,27 @@ def test_mid_size_nodes_on_packed_codes(rp, ctx, oracle, option, dtype, mode, n,
     if mode == "exact":
         fo = oracle.forest_build_dense(X.astype(np.float64), R, min_leaf)
         assert_forest_equal(f, fo)
+
+
+@pytest.mark.parametrize("T", [200, 600, 1000])
+def test_knn_many_trees_slots_and_second_traversal(rp, ctx, oracle, option, T):
+    """The workgroup query kernel keeps kFR / T range slots per tree for its one-pass traversal
+    (2 at T = 200, none above 512 trees: the emitting second traversal); thread = tree covers up to
+    four trees per thread.  Answers equal the unfused general path's and the oracle's."""
+    n, d, ml, k = 4000, 16, 40, 5
+    X = oracle.data_normal_dense2(23, n, d)
+    rng = np.random.default_rng(2)
+    Q = X[rng.integers(0, n, 12)] + 0.01
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(3, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    got = rp.knnBatch(k, f, Q)
+    with option("knn_general", 1):
+        ref = rp.knnBatch(k, f, Q)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    fo = oracle.forest_build_dense(X, R, ml)
+    for i in range(0, len(Q), 4):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+        assert got[2][i] == len(wi) and np.array_equal(got[0][i, :got[2][i]], wi)
+        assert np.array_equal(got[1][i, :got[2][i]], wd)
