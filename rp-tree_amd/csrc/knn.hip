@@ -1676,7 +1676,20 @@ retry_wider:
       // leaf range holds ~100 candidates: a boundary or two per thread) — sixteen independent
       // nine-step searches per thread were 13 % of a C2 query's life
       int64_t addr[EF];
-      {
+      if constexpr (!WIDE) {
+#pragma unroll
+        for (int e = 0; e < EF; ++e) {
+          const int s2 = tid + 256 * e;
+          const int c = pos_base + (s2 < take ? s2 : 0);
+          int lo = 0;
+#pragma unroll
+          for (int step = kFR / 2; step > 0; step >>= 1) {
+            const int m = lo + step;
+            if (m < nr_tot && rstart[m] <= c) lo = m;
+          }
+          addr[e] = rpoff[lo] + (c - rstart[lo]);
+        }
+      } else {
         const int s0 = tid * EF;
         const int c0 = pos_base + (s0 < take ? s0 : 0);
         int lo = 0;
@@ -1703,10 +1716,10 @@ retry_wider:
       }
       int32_t idv[EF];
 #pragma unroll
-      for (int e = 0; e < EF; ++e) idv[e] = tid * EF + e < take ? perm[addr[e]] : 0;
+      for (int e = 0; e < EF; ++e) idv[e] = (WIDE ? tid * EF + e : tid + 256 * e) < take ? perm[addr[e]] : 0;
 #pragma unroll
       for (int e = 0; e < EF; ++e) {
-        const int s2 = tid * EF + e;
+        const int s2 = WIDE ? tid * EF + e : tid + 256 * e;
         if (s2 < take) {
           cid[fill + s2] = idv[e];
           if constexpr (!WIDE) cpos[fill + s2] = pos_base + s2;
