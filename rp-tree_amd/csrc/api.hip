@@ -346,6 +346,8 @@ int32_t rpt_ctx_destroy(rpt_ctx* ctx) {
     if (ctx->stream) {
       (void)stream_sync(ctx->stream);
       prof_resolve(ctx);
+      for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+      ctx->prof_events.clear();
       (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
@@ -418,8 +420,14 @@ static void prof_resolve(rpt_ctx* ctx) {
         ctx->prof_n[RPT_PROF_PROJECT] += 1;
       }
     }
-    (void)hipEventDestroy(sp.a);
-    (void)hipEventDestroy(sp.b);
+    if (hipEventQuery(sp.b) == hipSuccess) {  // both have completed: free for the next span
+      ctx->prof_events.push_back(sp.a);
+      ctx->prof_events.push_back(sp.b);
+    } else {
+      (void)hipGetLastError();
+      (void)hipEventDestroy(sp.a);
+      (void)hipEventDestroy(sp.b);
+    }
   }
   ctx->spans.clear();
 }
