@@ -245,10 +245,16 @@ def other_configs(which, steps, with_cpu):
                 t1 = time.perf_counter() - t0
                 nt_all = min(T, ncores)
                 t0 = time.perf_counter()
-                orc.forest_build_csr(hr, hc, hv, d, R[:nt_all], min_leaf, threads=ncores)
+                fo_all = orc.forest_build_csr(hr, hc, hv, d, R[:nt_all], min_leaf, threads=ncores)
                 tall = time.perf_counter() - t0
                 same = bool(np.array_equal(fo1.perm[0], f.perm[0]) and
                             np.array_equal(fo1.thr[0], f.thr[0], equal_nan=True))
+                fperm, fthr, fmglo, fmghi = f.perm, f.thr, f.mglo, f.mghi
+                same_all = sum(int(np.array_equal(fo_all.perm[t], fperm[t]) and
+                                   np.array_equal(fo_all.thr[t], fthr[t], equal_nan=True) and
+                                   np.array_equal(fo_all.mglo[t], fmglo[t], equal_nan=True) and
+                                   np.array_equal(fo_all.mghi[t], fmghi[t], equal_nan=True))
+                               for t in range(nt_all))
                 ff = orc.Forest(n, d, R, maxd, min_leaf, f.perm, f.thr, f.mglo, f.mghi)
                 hqr, hqc, hqv = qr.cpu().numpy(), qc.cpu().numpy(), qv.cpu().numpy()
                 nqs = 20
@@ -263,7 +269,8 @@ def other_configs(which, steps, with_cpu):
                     "knn_queries_per_s": nqs / tq, "cores_all": ncores,
                     "value_all_cores": n / (tall / nt_all * T),
                     "sample_all_cores": "%d trees on %d threads (%.1f s), scaled to %d" % (nt_all, ncores, tall, T),
-                    "tree0_identical_to_gpu": same}
+                    "tree0_identical_to_gpu": same,
+                    "trees_identical_to_gpu": "%d/%d" % (same_all, nt_all)}
             out["c3"] = res
             f.close()
             ds.close()
@@ -408,6 +415,123 @@ def other_configs(which, steps, with_cpu):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# shard_sweep: what ONE GPU of an N-GPU run does, measured on one GPU.  The trees of a forest are
+# independent (Internal.hs:234-240) and knn concatenates per-tree candidates (RPTree.hs:174-176), so
+# GPU r of G builds and queries trees [r*T/G, (r+1)*T/G) of the SAME point set: a run at G GPUs is as
+# fast as its slowest shard plus the exchange.  For C2 (T = 32) and C4 (T = 64) this leg times the
+# shard sizes T/8, T/4, T/2 and T: build ms, kNN ms per batch of 10 000 and of 100 000 queries, both
+# through rpt_knn_sharded_dev on a one-rank communicator WITH the exchange forced (record ->
+# ncclAllGather -> merge -> status scan: the code path of every rank; what one GPU cannot show is
+# the transfer over xGMI and G records from G devices).  `projected_speedup_8gpu` = time of the
+# whole forest on one GPU / time of the T/8 shard incl. the forced exchange — a PROJECTION from
+# one-GPU measurements, never a measured scaling number (the driver's SCALE run is that).
+# ---------------------------------------------------------------------------------------------
+def shard_sweep(which, steps):
+    import ctypes as C
+    import torch
+    import rptree_amd as rp
+    from rptree_amd import _lib, gen, sharded
+    L_ = _lib.lib()
+    comm = sharded.Comm.local(1)
+    ctx = comm.contexts[0]
+    dev = torch.device("cuda", ctx.device)
+    out = {"note": "one GPU, tree shards of the whole point set (what 1 of G GPUs holds); kNN through "
+                   "rpt_knn_sharded_dev with comm_force_exchange = 1 (one-rank ncclAllGather + merge); "
+                   "projected_speedup_8gpu = whole forest on one GPU / the T/8 shard, a projection",
+           "steps": steps}
+
+    def leg(name, Xd, Qs, T_all, min_leaf, k, mode, dt):
+        n, d = Xd.shape
+        cfg = rp.rpTreeCfg(min_leaf, n, d)
+        maxd, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+        ds = rp.Dataset.from_torch(ctx, Xd)
+        _, R = gen.forest_hyperplanes(1235137, T_all, maxd, pnz, d)
+        rows = []
+        for T in (T_all // 8, T_all // 4, T_all // 2, T_all):
+            row = {"trees": T}
+            try:
+                sharded.ShardedForest(comm, [ds], R[:T], maxd, min_leaf, mode).close()      # warm
+                comm.sync()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    sf = sharded.ShardedForest(comm, [ds], R[:T], maxd, min_leaf, mode)
+                    if _ < steps - 1:
+                        sf.close()
+                comm.sync()
+                row["build_ms"] = (time.perf_counter() - t0) / steps * 1e3
+                for nq, Qd in Qs:
+                    qs = rp.Dataset.from_torch(ctx, Qd)
+                    oi = torch.empty((nq, k), dtype=torch.int32, device=dev)
+                    od = torch.empty((nq, k), dtype=torch.float64, device=dev)
+                    oc = torch.empty((nq,), dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize(dev)
+                    for force in (0, 1):
+                        ctx.set_option("comm_force_exchange", force)
+                        for _ in range(2):
+                            sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+                            comm.sync()
+                        t0 = time.perf_counter()
+                        for _ in range(max(steps, 5)):
+                            sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+                            comm.sync()
+                        row["knn_ms_nq%d%s" % (nq, "_forced_exchange" if force else "")] = \
+                            (time.perf_counter() - t0) / max(steps, 5) * 1e3
+                    ctx.set_option("comm_force_exchange", 0)
+                    tier = C.c_int32()
+                    _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
+                    row["knn_ranking_tier"] = tier.value
+                    qs.close()
+                    del oi, od, oc
+                sf.close()
+            except Exception as e:          # noqa: BLE001
+                row["error"] = "%s: %s" % (type(e).__name__, e)
+                ctx.set_option("comm_force_exchange", 0)
+            rows.append(row)
+        res = {"workload": "%s: %d x %d %s, %d trees in all, minLeaf %d, maxDepth %d, k=%d" %
+                           (name, n, d, dt, T_all, min_leaf, maxd, k), "shards": rows}
+        try:
+            whole, eighth = rows[-1], rows[0]
+            proj = {"build": whole["build_ms"] / eighth["build_ms"]}
+            for nq, _ in Qs:
+                proj["knn_nq%d" % nq] = whole["knn_ms_nq%d" % nq] / eighth["knn_ms_nq%d_forced_exchange" % nq]
+            res["projected_speedup_8gpu"] = proj
+        except Exception:                   # noqa: BLE001
+            res["projected_speedup_8gpu"] = None
+        ds.close()
+        return res
+
+    if "c2" in which:
+        try:
+            X = gen.normal_dense2_torch(1234, 1_000_000, 128, dev)
+            Qb = gen.normal_dense2_torch(4321, 100_000, 128, dev)
+            torch.cuda.synchronize(dev)
+            out["c2"] = leg("C2", X, [(10_000, Qb[:10_000].contiguous()), (100_000, Qb)], 32, 128, 10,
+                            rp.RPT_PROJ_MFMA, "f64")
+            del X, Qb
+        except Exception as e:              # noqa: BLE001
+            out["c2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    if "c4" in which:
+        try:
+            n, d = 10_000_000, 128
+            g = torch.Generator(device=dev).manual_seed(1234)
+            coin = (torch.rand(n, 1, device=dev, generator=g) < 0.5).float() * 2.0
+            Xd = torch.randn(n, d, device=dev, dtype=torch.float32, generator=g) * 0.5 + coin
+            del coin
+            qi = torch.randint(0, n, (100_000,), device=dev, generator=g)
+            Qd = (Xd[qi] * 1.001 + 0.003).contiguous()
+            torch.cuda.synchronize(dev)
+            out["c4"] = leg("C4", Xd, [(10_000, Qd[:10_000].contiguous()), (100_000, Qd)], 64, 128, 10,
+                            rp.RPT_PROJ_AUTO, "f32")
+            del Xd, Qd
+        except Exception as e:              # noqa: BLE001
+            out["c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    comm.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -427,8 +551,20 @@ def main():
     ap.add_argument("--other-configs", default="c3,c4,c5",
                     help="comma list of the other BASELINE configurations to time after C2 at N = 1 "
                          "(c3, c4, c5; 'none' to skip): build / kNN / roofline / cpu_baseline each")
+    ap.add_argument("--shard-sweep", default="c2,c4",
+                    help="comma list of the configurations whose tree shards (T/8 .. T trees on one GPU) are "
+                         "timed after C2 at N = 1 (c2, c4; 'none' to skip): build / kNN at 10 000 and 100 000 "
+                         "queries incl. the forced one-rank exchange, projected_speedup_8gpu")
     ap.add_argument("--_other-child", dest="other_child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--_sweep-child", dest="sweep_child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sweep_child:       # child process of the shard_sweep leg: ONE JSON line on stdout
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        res = shard_sweep([w for w in args.shard_sweep.split(",") if w], max(1, min(args.steps, 3)))
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+        return
     if args.other_child:       # child process of the other_configs leg: ONE JSON line on stdout
         sys.stdout.flush()
         json_fd = os.dup(1)
@@ -611,9 +747,51 @@ def main():
     leaf_flip_rate = flips / float(nt_cmp * N)
     # exact-order build of the first trees, kept for the full-size comparison with the oracle
     ex_loc = a_loc if alt_name == "exact" else f_loc
-    ex_perm = np.array(ex_loc.perm[:3])
-    ex_thr = np.array(ex_loc.thr[:3])
+    ex_perm = np.array(ex_loc.perm)            # every tree of this rank (C2: 32 x 4 MB)
+    ex_thr, ex_mglo, ex_mghi = np.array(ex_loc.thr), np.array(ex_loc.mglo), np.array(ex_loc.mghi)
     alt.close()
+
+    # ---- the survey's own projection batch (ONE level x 32 trees = 32 hyperplanes per
+    # read of X, 1.280 GB at C2): the same K builds with 32 hyperplanes per pass (proj_narrow:
+    # 13 x proj_mfma_fast at C2).  The timed headline reads X once per 96-128 hyperplanes, which is
+    # faster overall; this leg is the unit north_star quotes its ">= 60 % of HBM" on ----
+    per_level = None
+    if args.mode == "mfma" and world == 1:
+        per_level = {}
+        for tag, opts in (("with_codes", {"proj_narrow": 1}), ("no_codes", {"proj_narrow": 1, "no_codes": 1})):
+            olds = {o: ctx.set_option(o, v) for o, v in opts.items()}
+            try:
+                build(rp.RPT_PROJ_MFMA).close()
+                _lib.check(L_.rpt_prof_reset(ctx._h))
+                _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    build(rp.RPT_PROJ_MFMA).close()
+                barrier()
+                t_nar = (time.perf_counter() - t0) / args.steps
+                pn = read_prof()
+                _lib.check(L_.rpt_prof_enable(ctx._h, 0))
+                n_ms, n_n = pn["project"]
+                lb = N * d * 8 + d * 32 * 8 + N * 32 * 8
+                avg = n_ms / max(n_n, 1)
+                per_level[tag] = {
+                    "kernel": "proj_mfma_fast (MFMA f64 16x16x4, 32 hyperplanes per pass over X%s)" %
+                              ("; the pass also writes the split's 16-bit codes" if tag == "with_codes" else ""),
+                    "launches_per_build": n_n / args.steps, "avg_launch_ms": avg,
+                    "algorithmic_bytes_per_launch": lb,
+                    "achieved": lb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": lb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0,
+                    "bound": "hbm", "build_ms": t_nar * 1e3,
+                    "projection_ms_per_build": n_ms / args.steps, "split_ms_per_build": pn["split"][0] / args.steps}
+            except Exception as e:      # noqa: BLE001
+                per_level[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                for o, v in olds.items():
+                    ctx.set_option(o, v)
+        per_level["note"] = ("SURVEY 8d's per-level projection batch (N*d*8 + d*32*8 + N*32*8 = 1.280 GB, "
+                             "8.19 GFLOP); HIP events around every launch; profiles/r04_narrow_* hold the "
+                             "rocprofv3 kernel trace and FETCH/WRITE of the same launches")
 
     if launcher:
         tt = torch.tensor([t_build, t_knn], dtype=torch.float64)
@@ -708,10 +886,13 @@ def main():
         t_all = time.perf_counter() - t0
         cpu_build_all = N / (t_all / nt_all * T)
         assert np.array_equal(f_all.perm[:nt], f_cpu.perm)
-        # full-size parity: the oracle's trees against the exact-order device build, bit for bit
-        ncmp = min(nt, len(ex_perm))
-        same_trees = sum(int(np.array_equal(f_cpu.perm[t], ex_perm[t]) and
-                             np.array_equal(f_cpu.thr[t], ex_thr[t], equal_nan=True))
+        # full-size parity: EVERY tree the all-core leg built against the exact-order device build,
+        # bit for bit (leaf assignment, thresholds, margins: Internal.hs:484-505 at every node)
+        ncmp = min(nt_all, len(ex_perm))
+        same_trees = sum(int(np.array_equal(f_all.perm[t], ex_perm[t]) and
+                             np.array_equal(f_all.thr[t], ex_thr[t], equal_nan=True) and
+                             np.array_equal(f_all.mglo[t], ex_mglo[t], equal_nan=True) and
+                             np.array_equal(f_all.mghi[t], ex_mghi[t], equal_nan=True))
                          for t in range(ncmp))
         # queries: the oracle's knn over the FULL forest (the device-built flat arrays; they
         # are identical to the oracle's in exact mode) for a sample of queries
@@ -802,6 +983,20 @@ def main():
             other = {"error": "other_configs child exceeded 420 s"}
         except Exception as e:      # noqa: BLE001
             other = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    sweep = None
+    if rank == 0 and world == 1 and args.shard_sweep not in ("", "none"):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--_sweep-child", "--shard-sweep", args.shard_sweep,
+               "--steps", str(args.steps)]
+        try:
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            line = pr.stdout.decode().strip().splitlines()[-1] if pr.stdout.strip() else ""
+            sweep = json.loads(line) if line else {"error": "child exited with %d, no output" % pr.returncode}
+        except subprocess.TimeoutExpired:
+            sweep = {"error": "shard_sweep child exceeded 300 s"}
+        except Exception as e:      # noqa: BLE001
+            sweep = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         p_ms, p_n = prof["project"]
@@ -986,6 +1181,8 @@ def main():
                         "flips are points whose projection is within rounding of a median"},
             "forest_stats": f_loc.stats(),
             "other_configs": other,
+            "shard_sweep": sweep,
+            "roofline_per_level": per_level,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -236,8 +236,11 @@ const OptDesc kOptions[] = {
     {"knn_kp8", &rpt_options::knn_kp8},
     {"knn_csr_pre32", &rpt_options::knn_csr_pre32},
     {"knn_general", &rpt_options::knn_general},
+    {"knn_shard_old", &rpt_options::knn_shard_old},
     {"comm_force_exchange", &rpt_options::comm_force_exchange},
     {"comm_inject_failure", &rpt_options::comm_inject_failure},
+    {"comm_timeout_ms", &rpt_options::comm_timeout_ms},
+    {"comm_stall_test", &rpt_options::comm_stall_test},
     {"tune0", &rpt_options::tune0},
     {"tune1", &rpt_options::tune1},
     {"tune2", &rpt_options::tune2},

@@ -25,11 +25,22 @@
 // kernels fail STILL enqueues the all-gather, with its status word poisoned, and returns its
 // error; after the merge every rank scans the gathered status words: if one is set, every count of
 // the answer becomes -1 and the next rpt_comm_sync (rpt_knn_sharded calls it) fails with
-// RPT_E_INTERNAL naming the rank.  A rank that cannot even hold its record (allocation failure)
-// or whose collective cannot be enqueued aborts its communicator (ncclCommAbort): the peers'
-// collective then fails instead of hanging, and the communicator is dead on every rank.
+// RPT_E_INTERNAL naming the rank.  The failed word accumulates (atomicMax) over all the exchanges
+// since the last rpt_comm_sync, which reads and resets it: a peer's failure in ANY batch enqueued
+// before the sync is reported.
+// A rank that cannot even hold its record (allocation failure), whose collective cannot be
+// enqueued, or that returns before the collective for any other reason aborts its OWN communicator
+// (ncclCommAbort).  That alone does not release the peers: an RCCL collective whose remote rank has
+// gone keeps spinning.  So rpt_comm_sync never blocks in hipStreamSynchronize while a collective
+// may be in flight: it POLLS hipStreamQuery together with ncclCommGetAsyncError on every local
+// communicator, under a deadline (ctx option comm_timeout_ms, default 120 000; RCCL_/NCCL_ timeouts
+// are not relied on); an asynchronous RCCL error or the deadline aborts the local communicator too,
+// marks it dead and returns RPT_E_INTERNAL — every rank gets out, the communicator is dead
+// everywhere.  This path has run with ONE rank only (comm_force_exchange + comm_inject_failure /
+// comm_stall_test on the one-GPU box); a two-process test is what is still missing.
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -199,7 +210,10 @@ int32_t ensure_exchange(rpt_comm* c, int g, int64_t nq, int32_t k) {
   e.off_status = e.off_count + nq * 4;  // the int32 behind the counts
   RPT_TRY(e.record.alloc((size_t)e.bytes));
   RPT_TRY(e.gathered.alloc((size_t)e.bytes * c->nranks));
-  if (!e.failed.p) RPT_TRY(e.failed.alloc(1));
+  if (!e.failed.p) {
+    RPT_TRY(e.failed.alloc(1));
+    RPT_HIP(hipMemsetAsync(e.failed.p, 0, 4, c->ctx[g]->stream));
+  }
   if (!e.failed_host) {
     RPT_HIP(hipHostMalloc((void**)&e.failed_host, 64, hipHostMallocDefault));
     *e.failed_host = 0;
@@ -213,7 +227,7 @@ int32_t ensure_exchange(rpt_comm* c, int g, int64_t nq, int32_t k) {
 }
 
 // after the merge: any status word set among the G gathered records -> every count of the answer
-// becomes -1 and *failed = 1 + that rank
+// becomes -1 and *failed = max(*failed, 1 + that rank)
 __global__ void exchange_status_kernel(const char* __restrict__ gathered, int64_t record_bytes,
                                        int64_t off_status, int G, int64_t nq,
                                        int32_t* __restrict__ out_count,
@@ -222,7 +236,7 @@ __global__ void exchange_status_kernel(const char* __restrict__ gathered, int64_
   for (int g = G - 1; g >= 0; --g)
     if (*reinterpret_cast<const int32_t*>(gathered + g * record_bytes + off_status) != 0) bad = g + 1;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *failed = bad;
+  if (i == 0 && bad) atomicMax(failed, bad);  // accumulates until rpt_comm_sync resets it
   if (bad && i < nq) out_count[i] = -1;
 }
 
@@ -376,17 +390,76 @@ int32_t rpt_comm_ctx(rpt_comm* comm, int32_t local_index, rpt_ctx** ctx) {
 int32_t rpt_comm_sync(rpt_comm* comm) {
   return guarded([&]() -> int32_t {
     RPT_ARG(comm, "comm is NULL");
-    for (rpt_ctx* x : comm->ctx) RPT_TRY(rpt_ctx_sync(x));
+    // an exchange may be in flight: poll instead of blocking (failure protocol, top of this file)
+    bool pending = false;
+    for (auto& e : comm->ex) pending = pending || (e && e->check);
+    if (pending && !comm->dead) {
+      int64_t limit_ms = comm->ctx[0]->opt.comm_timeout_ms;
+      if (limit_ms <= 0) limit_ms = 120000;
+      if (comm->ctx[0]->opt.comm_stall_test) {  // test hook: the deadline has passed, whatever the streams say
+        abort_comm(comm);
+        return fail(RPT_E_INTERNAL, "rpt_comm_sync: the exchange did not complete within its deadline "
+                                    "(comm_stall_test); communicator aborted");
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      std::vector<char> drained(comm->ctx.size(), 0);
+      size_t left = comm->ctx.size();
+      int spins = 0;
+      while (left) {
+        for (size_t g = 0; g < comm->ctx.size(); ++g) {
+          if (drained[g]) continue;
+          (void)hipSetDevice(comm->ctx[g]->device);
+          const hipError_t q = hipStreamQuery(comm->ctx[g]->stream);
+          if (q == hipSuccess) {
+            drained[g] = 1;
+            --left;
+          } else if (q != hipErrorNotReady) {
+            abort_comm(comm);
+            return fail(RPT_E_HIP, std::string("rpt_comm_sync: ") + hipGetErrorString(q) +
+                                       " (communicator aborted)");
+          }
+          if (g < comm->comm.size() && comm->comm[g]) {
+            ncclResult_t ae = ncclSuccess;
+            const ncclResult_t r = ncclCommGetAsyncError(comm->comm[g], &ae);
+            if (r != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) {
+              abort_comm(comm);
+              return fail(RPT_E_INTERNAL, std::string("rpt_comm_sync: RCCL reports ") +
+                                              ncclGetErrorString(r != ncclSuccess ? r : ae) +
+                                              " on the exchange (a peer has gone?); communicator aborted");
+            }
+          }
+        }
+        if (!left) break;
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(
+                            std::chrono::steady_clock::now() - t0).count();
+        if (ms > limit_ms) {
+          abort_comm(comm);
+          return fail(RPT_E_INTERNAL, "rpt_comm_sync: the exchange did not complete within " +
+                                          std::to_string(limit_ms) + " ms (a peer that never joined "
+                                          "the all-gather?); communicator aborted");
+        }
+        // the first few thousand turns spin (a batch is a fraction of a millisecond), then back off
+        if (++spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+    }
+    for (rpt_ctx* x : comm->ctx) RPT_TRY(rpt_ctx_sync(x));  // (returns at once after the poll; recycles the allocator's blocks)
     // the status words of the exchanges since the last sync (failure protocol, top of this file)
     int32_t bad = 0;
-    for (auto& e : comm->ex)
+    for (size_t g = 0; g < comm->ex.size(); ++g) {
+      Exchange* e = comm->ex[g].get();
       if (e && e->check) {
         e->check = false;
-        if (e->failed_host && *e->failed_host && !bad) bad = *e->failed_host;
+        if (e->failed_host && *e->failed_host) {
+          if (!bad) bad = *e->failed_host;
+          *e->failed_host = 0;
+          (void)hipSetDevice(comm->ctx[g]->device);
+          RPT_HIP(hipMemsetAsync(e->failed.p, 0, 4, comm->ctx[g]->stream));
+        }
       }
+    }
     if (bad)
       return fail(RPT_E_INTERNAL, "sharded kNN: rank " + std::to_string(bad - 1) +
-                                      " failed to answer the batch (its own call returned the "
+                                      " failed to answer a batch (its own call returned the "
                                       "error); the merged answer is invalid, every count is -1");
     return RPT_OK;
   });

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,12 +77,21 @@ hipError_t stream_sync(hipStream_t s);       // hipStreamSynchronize + release b
 // device's copy of the code object, and one process may drive several devices from several host
 // threads (rpt_comm_init).  first(dev) is true exactly once per device (devices 0..63).
 struct DeviceOnce {
-  std::atomic<unsigned long long> mask{0};
-  bool first(int dev) {
+  std::mutex mu;
+  std::atomic<unsigned long long> done{0};
+  // runs f() (an int32_t status) once per device; the device's bit is set only after f succeeded,
+  // under the mutex, so a failed attempt is retried by the next call and a second host thread on
+  // the same device cannot pass before the first one's call has returned
+  template <class F>
+  int32_t run(int dev, F&& f) {
     const unsigned long long bit = 1ULL << (dev & 63);
-    return (mask.fetch_or(bit) & bit) == 0;
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return 0;
+    const int32_t s = f();
+    if (s == 0) done.fetch_or(bit, std::memory_order_release);
+    return s;
   }
-  void undo(int dev) { mask.fetch_and(~(1ULL << (dev & 63))); }
 };
 
 // simple owned device buffer
@@ -150,8 +160,12 @@ struct rpt_options {
   int64_t knn_kp8 = 0;          // kNN: entries the int8 prefilter keeps (0 = k + max(48, k), capped by the kernel variant)
   int64_t knn_csr_pre32 = 0;    // kNN: rank CSR f64 rows on their (u16 column, f32 value) shadow
   int64_t knn_general = 0;      // kNN: unfused general path
+  int64_t knn_shard_old = 0;    // kNN: small shards keep the round-3 one-wave kernel (in-kernel traversal, fixed k')
   int64_t comm_force_exchange = 0;  // sharded kNN: a one-rank communicator runs record -> all-gather -> merge too
   int64_t comm_inject_failure = 0;  // sharded kNN (test hook): this device's shard reports a failure
+  int64_t comm_timeout_ms = 0;      // sharded kNN: rpt_comm_sync's deadline for an exchange in flight (0 = 120 000)
+  int64_t comm_stall_test = 0;      // sharded kNN (test hook): rpt_comm_sync treats a pending exchange as timed out
+                                    // (the abort path on a one-GPU box)
   int64_t tune0 = 0, tune1 = 0, tune2 = 0, tune3 = 0;  // experiment hooks (0 = the built-in choice)
   int64_t debug_host = 0;       // stderr: host-side phase times of a build
   int64_t debug_stamps = 0;     // device time stamps of the wave kernel

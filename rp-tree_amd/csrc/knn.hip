@@ -497,7 +497,12 @@ __device__ inline void finalize_leftfold(const double* __restrict__ X, int d, co
     const double di = lf[i];
     const int pi = bpos[i];
     int rank = 0;
-    for (int j = 0; j < m; ++j) rank += lf[j] < di || (lf[j] == di && bpos[j] < pi);
+    // a total order whatever the values are: NaN (a NaN query or row, inf - inf) ranks behind every
+    // number, NaNs among themselves by position — the ranks are a permutation of 0 .. m - 1
+    if (di == di)
+      for (int j = 0; j < m; ++j) rank += lf[j] < di || (lf[j] == di && bpos[j] < pi);
+    else
+      for (int j = 0; j < m; ++j) rank += lf[j] == lf[j] || bpos[j] < pi;
     order[rank] = i;
   }
   sync();
@@ -766,6 +771,10 @@ __device__ __forceinline__ int count_below(const unsigned long long* lkey, int n
 // ... and of (distance, position) pairs below (di, pi)
 __device__ __forceinline__ int count_below2(const double* dd, const int* pp, int m, double di, int pi) {
   int rank = 0, j = 0;
+  if (di != di) {  // NaN ranks behind every number, NaNs by position (a total order: no two equal ranks)
+    for (; j < m; ++j) rank += dd[j] == dd[j] || pp[j] < pi;
+    return rank;
+  }
   for (; j + 8 <= m; j += 8) {
     double a[8];
     int b[8];
@@ -1560,6 +1569,9 @@ __global__ __launch_bounds__(256, 3) void knn_fused_kernel(
     for (int e = 0; e < E; ++e) {
       const int i = tid + 256 * e;
       dd[e] = i < fill ? cdist[i] : __longlong_as_double(0x7ff0000000000000LL);
+      // NaN (a NaN query or row, inf - inf) ranks with +inf, by position: a total order, every entry
+      // can be selected (a NaN would lose every comparison and end the rounds with nothing chosen)
+      if (dd[e] != dd[e]) dd[e] = __longlong_as_double(0x7ff0000000000000LL);
       pp[e] = i < fill ? cpos[i] : -1;
     }
     int nb = 0, par = 0;
@@ -1936,6 +1948,7 @@ constexpr int kWT = 64;   // trees (lane = tree)
 // answers an 8-tree shard of C2 (8 x 122 candidates) in 0.67 ms, this one in 0.96; the 8 x 76 of a
 // C4 shard stay here: 3.2 against 5.9 ms per 100 000 queries)
 constexpr int64_t kWaveCandidates = 700;
+constexpr int64_t kShardCandidates = 1100;  // ... and the round-4 shard kernels (see launch_fused)
 
 __device__ inline void wave_sync() {  // LDS writes of the wave visible to all its lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1965,7 +1978,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
   const int64_t q = (int64_t)blockIdx.x * 4 + wave;
   if (q >= nq) return;  // no workgroup barrier below
   int dbgi = 0;
-#define KSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) dbg[dbgi++] = clock64(); } while (0)
+#define KSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = clock64(); } while (0)
   KSTAMP();
   const bool rerun = !PRE32 && k1 == -1;  // second pass: only the queries the prefilter gave up on
   if (rerun && ovf_flags[q] != 2u) return;
@@ -2171,6 +2184,7 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     for (int s = 0; s < E; ++s) {
       const int i = lane + 64 * s;
       dd[s] = i < fill ? cdist[i] : kInf;
+      if (dd[s] != dd[s]) dd[s] = kInf;  // NaN ranks with +inf, by position (see knn_fused_kernel's select)
       pp[s] = i < fill ? (i < first_new ? bpos[i] : pb0 + (i - first_new)) : -1;
     }
     wave_sync();  // bpos is rewritten below
@@ -2349,6 +2363,463 @@ __global__ __launch_bounds__(256, 3) void knn_fused_wave_kernel(
     out_dist[q * k + i] = ok ? (pack32 ? (double)sqrt(bdist[i]) : bdist[i]) : kInf;
   }
   if (lane == 0) out_cnt[q] = best;
+  KSTAMP();
+#undef KSTAMP
+}
+
+// ---------------------------------------------------------------------------------------
+// Small tree shards, round 4 (what one of G GPUs holds: a few trees, a few hundred candidates per
+// query).  Two changes against knn_fused_wave_kernel's prefiltered instantiations, same answers:
+//
+// (1) The traversal is its own launch.  In the fused kernel it was 28 % of a query's life (47 k of
+//     165 k cycles at a 4-tree C2 shard) with 4 of 64 lanes at work on a chain of dependent loads,
+//     inside a wave that holds 168 registers and 12 KB of LDS for the phases that follow.
+//     shard_ranges_kernel walks with lane = (query, tree) — 64 / T queries per wave, every lane
+//     busy, a dozen registers — and leaves each query's leaf ranges compacted in tree order
+//     (RPTree.hs:289-314 per tree, :176 the concatenation).
+//
+// (2) The rows that get an exact distance are chosen by VALUE, not by count.  The ranking tiers
+//     bound a candidate's exact distance D by its ranking value: lower(Dh) <= D <= upper(Dh), Dh the
+//     tier's distance estimate (the int8 tier: triangle inequality, Sh8; f32 / half: the rounding
+//     analysis in knn_fused_kernel).  So
+//       * the k-th smallest exact distance d_k is at most upper(Dh_(k)), Dh_(k) the k-th smallest
+//         estimate seen so far: a candidate with lower(Dh) > upper(Dh_(k)) can be dropped at once and
+//         for good (the bound only tightens as batches arrive) — the carried list;
+//       * once the first entries of the list have their exact distances, U = the k-th smallest of
+//         those is an upper bound of d_k too, and only list entries with lower(Dh) <= U need an exact
+//         distance at all.
+//     Every candidate without an exact distance is strictly farther than d_k, so the k best by
+//     (exact distance, position) of the refined ones are the reference's answer (RPTree.hs:174-176) —
+//     certified by construction: no fixed k' (the one-wave kernel kept k + 37 rows for every query to
+//     certify the worst of ten thousand: 48 KB of f64 rows per query against 63 KB of int8 rows; the
+//     band at the cut holds ~ 9), no uncertified re-runs except a list that outgrows its 128 slots.
+constexpr int kSKmax = 48;  // largest k the shard kernel serves (the carried list must hold k and its band)
+
+template <class TK>
+__global__ __launch_bounds__(256) void shard_ranges_kernel(
+    const double* __restrict__ thr, const double* __restrict__ mglo, const double* __restrict__ mghi,
+    int64_t nodes, const TK* __restrict__ Pq, int64_t nq, int T, int L, int min_leaf, int64_t N,
+    int2* __restrict__ hdr /* [nq] (leaf ranges, candidates) */, int64_t* __restrict__ rng_off /* [nq][kWR] */,
+    int* __restrict__ rng_n /* [nq][kWR] */, unsigned int* ovf_flags, unsigned int* ovf_count,
+    unsigned long long* cand_total) {
+  const int lane = threadIdx.x & 63;
+  const int qpw = 64 / T;  // queries per wave (T <= 64)
+  const int64_t wave_g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ql = lane / T, t = lane - ql * T;
+  const int64_t q = wave_g * qpw + ql;
+  const bool on = ql < qpw && q < nq;
+  int nr = 0, nc = 0, o0 = 0, n0 = 0, o1 = 0, n1 = 0;
+  if (on)
+    traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q, nq, L,
+                 min_leaf, N, [&](int off, int n) {
+                   if (nr == 0) {
+                     o0 = off;
+                     n0 = n;
+                   } else if (nr == 1) {
+                     o1 = off;
+                     n1 = n;
+                   }
+                   nc += n;
+                   ++nr;
+                 });
+  int ir = nr, ic = nc;  // inclusive scans over the wave, made segment-relative below
+  for (int o = 1; o < 64; o <<= 1) {
+    const int a = __shfl_up(ir, o), b = __shfl_up(ic, o);
+    if (lane >= o) {
+      ir += a;
+      ic += b;
+    }
+  }
+  const int seg0 = ql * T, seg1 = seg0 + T - 1 < 63 ? seg0 + T - 1 : 63;
+  const int pr = __shfl(ir, seg0 > 0 ? seg0 - 1 : 0), pc = __shfl(ic, seg0 > 0 ? seg0 - 1 : 0);
+  const int er = __shfl(ir, seg1), ec = __shfl(ic, seg1);
+  const int before_r = seg0 > 0 ? pr : 0, before_c = seg0 > 0 ? pc : 0;
+  const int nr_tot = er - before_r, nc_tot = ec - before_c;
+  const int base = ir - nr - before_r;  // this tree's first slot in the query's compact list
+  unsigned long long visited = 0;
+  if (on) {
+    if (t == 0) hdr[q] = make_int2(nr_tot, nc_tot);
+    if (nr_tot > kWR) {  // too many leaf ranges for the consumer's slab: general path
+      if (t == 0) {
+        ovf_flags[q] = 1u;
+        atomicAdd(ovf_count, 1u);
+      }
+    } else {
+      if (t == 0) visited = (unsigned long long)nc_tot;
+      int64_t* ro = rng_off + q * kWR + base;
+      int* rn = rng_n + q * kWR + base;
+      if (nr >= 1) {
+        ro[0] = (int64_t)t * N + o0;
+        rn[0] = n0;
+      }
+      if (nr >= 2) {
+        ro[1] = (int64_t)t * N + o1;
+        rn[1] = n1;
+      }
+      if (nr > 2) {  // rare (both children at two nodes of one tree): walk again for the rest
+        int i = 0;
+        traverse<TK>(thr + t * nodes, mglo + t * nodes, mghi + t * nodes, Pq + (int64_t)t * L * nq + q, nq,
+                     L, min_leaf, N, [&](int off, int n) {
+                       if (i >= 2) {
+                         ro[i] = (int64_t)t * N + off;
+                         rn[i] = n;
+                       }
+                       ++i;
+                     });
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
+  if (lane == 0 && visited) atomicAdd(cand_total, visited);
+}
+
+__host__ __device__ inline size_t shard_wave_bytes(int d, size_t acc_size, int kSL) {
+  const size_t b = (size_t)kWC * 8 + (size_t)kWR * 8 + (size_t)(kWR + 4) * 4 + (size_t)kSL * 20 + 16 +
+                   (((size_t)d * acc_size + 15) & ~(size_t)15) + (size_t)d * 4;
+  return (b + 15) & ~(size_t)15;
+}
+
+// TIER: 1 = f32 shadow, 2 = IEEE-half shadow, 3 = int8 shadow (Sh8)
+// kSL: slots of the carried list (a multiple of 64); MINB: workgroups per CU the register budget allows.
+// Two shapes are instantiated: (128, 4) for shards whose candidates are one batch, (256, 3) beyond
+// (the first batch's threshold comes from per-lane minima and lets more of a 980-candidate query
+// through than 128 slots hold: 1.6 % of the queries of an 8-tree C2 shard)
+template <class TD, int TIER, int kSL, int MINB>
+__global__ __launch_bounds__(256, MINB) void knn_shard_wave_kernel(
+    const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm, int64_t nq,
+    int k, const int2* __restrict__ hdr, const int64_t* __restrict__ rng_off, const int* __restrict__ rng_n,
+    int32_t* __restrict__ out_ids, double* __restrict__ out_dist, int32_t* __restrict__ out_cnt,
+    unsigned int* ovf_flags, unsigned long long* cand_total, const void* __restrict__ Xf, double xmax, Sh8 sh8,
+    int r1_pct /* first refinement round: estimates up to Dh_(k) + r1_pct % of the error bound */,
+    unsigned long long* dbg) {
+  typedef typename AccOf<TD>::type TA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  if (q >= nq) return;  // no workgroup barrier below
+  int dbgi = 0;
+#define KSTAMP() do { if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && dbgi < 60) dbg[dbgi++] = clock64(); } while (0)
+  KSTAMP();
+  const int2 h = hdr[q];
+  const int nr_tot = h.x, nc_tot = h.y;
+  if (nr_tot > kWR) return;  // flagged by shard_ranges_kernel: the general path answers it
+  constexpr int kSLpl = kSL / 64;  // list entries per lane
+  unsigned char* base = smem + (size_t)wave * shard_wave_bytes(d, sizeof(TA), kSL);
+  unsigned long long* lkey = reinterpret_cast<unsigned long long*>(base);           // [kSL] (value bits << 32 | position)
+  double* rdist = reinterpret_cast<double*>(lkey + kSL);                              // [kSL] exact distances
+  int64_t* rpoff = reinterpret_cast<int64_t*>(rdist + kSL);                           // [kWR]
+  TA* qs = reinterpret_cast<TA*>(rpoff + kWR);                                        // [d]
+  float* cval = reinterpret_cast<float*>(base + (size_t)kSL * 16 + (size_t)kWR * 8 +
+                                         (((size_t)d * sizeof(TA) + 15) & ~(size_t)15));  // [kWC] ranking values
+  int* cid = reinterpret_cast<int*>(cval + kWC);                                      // [kWC]
+  int* rstart = cid + kWC;                                                            // [kWR + 1]
+  int* lid = rstart + kWR + 4;                                                        // [kSL]
+  unsigned int* lcnt = reinterpret_cast<unsigned int*>(lid + kSL);                    // [4]
+  float* qs32 = reinterpret_cast<float*>(lcnt + 4);                                   // [d] f32 copy / byte planes
+
+  // ---- the query's leaf ranges (tree order) and rstart[r] = candidates before range r ----
+  for (int r = lane; r < nr_tot; r += 64) rpoff[r] = rng_off[q * kWR + r];
+  {
+    const int a = 2 * lane < nr_tot ? rng_n[q * kWR + 2 * lane] : 0;
+    const int b = 2 * lane + 1 < nr_tot ? rng_n[q * kWR + 2 * lane + 1] : 0;
+    int incl = a + b;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t2 = __shfl_up(incl, o);
+      if (lane >= o) incl += t2;
+    }
+    const int excl = incl - (a + b);
+    if (2 * lane <= nr_tot) rstart[2 * lane] = excl;
+    if (2 * lane + 1 <= nr_tot) rstart[2 * lane + 1] = excl + a;
+  }
+  // ---- the query: exact copy, ranking copy, norm ----
+  double qn = 0.0;
+  for (int j = lane; j < d; j += 64) {
+    const TA v = ld<TD>(Q + q * d + j);
+    qs[j] = v;
+    qn += (double)v * (double)v;
+    if constexpr (TIER != 3) qs32[j] = (float)v;
+  }
+  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  const double qnorm = sqrt(qn);
+  double q8k = 0.0, q8eq = 0.0;
+  if constexpr (TIER == 3) {
+    wave_sync();
+    if constexpr (sizeof(TA) == 8)
+      quantise_query(reinterpret_cast<const double*>(qs), nullptr, d, sh8.s, reinterpret_cast<unsigned int*>(qs32),
+                     lane, 64, q8k, q8eq);
+    else
+      quantise_query(nullptr, reinterpret_cast<const float*>(qs), d, sh8.s, reinterpret_cast<unsigned int*>(qs32),
+                     lane, 64, q8k, q8eq);
+    for (int o = 32; o > 0; o >>= 1) {
+      q8k += __shfl_xor(q8k, o);
+      q8eq += __shfl_xor(q8eq, o);
+    }
+    q8k -= 1073741824.0 * (double)d;
+    q8eq = sqrt(q8eq);
+  }
+  wave_sync();
+  KSTAMP();  // 1: ranges + query
+
+  // ---- the tier's bounds: lower(Dh) <= D <= upper(Dh) for the exact distance D of a row whose
+  // estimate is Dh;  lower(Dh) = (Dh - A - Bt Dh)(1 - Bf),  upper(Dh) = (Dh + A + Bt Dh)(1 + Bf)
+  //   f32 shadow : A = 2.1 u (xmax + |q|) + sqrt(d) 4e-23,  Bt = (d + 2) u       (knn_fused_kernel)
+  //   half shadow: A = 1.05 2^-11 xmax + 2.1 u |q| + sqrt(d) 3.1e-8,  Bt = (d + 2) u
+  //   int8 shadow: A = eq + emax,  Bt = 0;  Dh = (s / 256) sqrt(I), the stored value is I rounded to f32
+  //   f32 DATA   : "exact" is the f32 distance the all-f32 kernel ranks on, within Bf = (d + 2) u of D
+  const double u = 5.9604644775390625e-08;
+  const double A = TIER == 3   ? (q8eq + sh8.emax) * (1.0 + 1e-12) + 1e-300
+                   : TIER == 2 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * qnorm + sqrt((double)d) * 3.1e-8
+                               : 2.1 * u * (xmax + qnorm) + sqrt((double)d) * 4e-23;
+  const double Bt = TIER == 3 ? 0.0 : (double)(d + 2) * u;
+  const double Bf = std::is_same<TD, double>::value ? 0.0 : (double)(d + 2) * u * 1.01;
+  const double g = TIER == 3 ? sh8.s * (1.0 / 256.0) : 1.0;       // estimate = g sqrt(value)
+  const double rnd = TIER == 3 ? 1.2e-7 : 0.0;                    // the stored value against the integer
+  // squares outside the f32 range, NaN: no bound holds — the exact kernel answers (as before)
+  if (!(qnorm < 1e18) || !(A == A)) {
+    if (lane == 0) {
+      ovf_flags[q] = 2u;
+      atomicAdd(cand_total + 1, 1ULL);
+    }
+    return;
+  }
+  auto dh_up = [&](unsigned int vb) -> double {  // the estimate of a stored value, rounded up
+    return g * sqrt((double)__uint_as_float(vb) * (1.0 + rnd)) * (1.0 + 1e-15);
+  };
+  // keep-threshold in stored-value bits: a candidate may be dropped iff lower(Dh) > Ulim, i.e. iff
+  // Dh > (Ulim / (1 - Bf) + A) / (1 - Bt); everything at or below the returned bits is KEPT
+  auto keep_bits = [&](double Ulim) -> unsigned int {
+    const double dstar = (Ulim / (1.0 - Bf) + A) / (1.0 - Bt) * (1.0 + 1e-15);
+    const double t = (dstar / g) * (dstar / g) / (1.0 - rnd) * (1.0 + 1e-15);
+    if (!(t < 3.0e38)) return 0x7fc00000u;  // inf / NaN: keep everything that is a number
+    float tf = (float)t;
+    if ((double)tf < t) tf = __uint_as_float(__float_as_uint(tf) + 1u);  // round up (t >= 0)
+    return __float_as_uint(tf);
+  };
+  auto upper = [&](double dh) -> double { return (dh + A + Bt * dh) * (1.0 + Bf) * (1.0 + 1e-15); };
+
+  constexpr int E = kWC / 64;
+  int n_list = 0, pos_base = 0;
+  while (pos_base < nc_tot) {
+    // ---- fill: candidate s of the batch by position (a search over rstart, the perm loads in flight together)
+    const int take = nc_tot - pos_base < kWC ? nc_tot - pos_base : kWC;
+    {
+      int64_t addr[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int s2 = lane + 64 * e;
+        const int c = pos_base + (s2 < take ? s2 : 0);
+        int lo = 0;
+#pragma unroll
+        for (int step = kWR / 2; step > 0; step >>= 1) {
+          const int m = lo + step;
+          if (m < nr_tot && rstart[m] <= c) lo = m;
+        }
+        addr[e] = rpoff[lo] + (c - rstart[lo]);
+      }
+      int32_t idv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) idv[e] = lane + 64 * e < take ? perm[addr[e]] : 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (lane + 64 * e < take) cid[lane + 64 * e] = idv[e];
+    }
+    wave_sync();
+    KSTAMP();  // batch filled
+    if constexpr (TIER == 3)
+      batch_distances_i8<16, float>(static_cast<const uint8_t*>(Xf), d, cid, cval,
+                                    reinterpret_cast<const unsigned int*>(qs32), q8k, 0, take, 0, 1, lane);
+    else if constexpr (TIER == 2)
+      batch_distances<_Float16, float, 16, false, float>(static_cast<const _Float16*>(Xf), d, cid, cval, qs32, 0,
+                                                         take, 0, 1, lane);
+    else
+      batch_distances<float, float, 16, false, float>(static_cast<const float*>(Xf), d, cid, cval, qs32, 0, take,
+                                                      0, 1, lane);
+    wave_sync();
+    KSTAMP();  // ranking values
+    // ---- the batch against the carried list ----
+    unsigned long long key[E];
+    unsigned int vlo = ~0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = lane + 64 * e;
+      key[e] = i < take ? ((unsigned long long)__float_as_uint(cval[i]) << 32) | (unsigned int)(pos_base + i) : ~0ULL;
+      const unsigned int v = (unsigned int)(key[e] >> 32);
+      vlo = v < vlo ? v : vlo;
+    }
+    // an upper bound of the k-th smallest value seen: the list's k-th entry, or (first batch) the
+    // k-th smallest of the 64 per-lane minima
+    unsigned int tau;
+    if (n_list >= k) {
+      tau = (unsigned int)(lkey[k - 1] >> 32);
+    } else {
+      int cnt = 0;
+#pragma unroll
+      for (int j2 = 0; j2 < 64; ++j2) {
+        const unsigned int o = (unsigned int)__builtin_amdgcn_readlane((int)vlo, j2);
+        cnt += (o < vlo || (o == vlo && j2 < lane)) ? 1 : 0;
+      }
+      const unsigned long long hit = __ballot(cnt == k - 1);
+      tau = __shfl(vlo, __ffsll((long long)hit) - 1);  // ~0u with fewer than k occupied lanes
+    }
+    const unsigned int thr0 = tau >= 0x7f800000u ? 0x7fc00000u : keep_bits(upper(dh_up(tau)));
+    if (lane == 0) *lcnt = (unsigned int)n_list;
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (key[e] != ~0ULL && (unsigned int)(key[e] >> 32) <= thr0) {
+        const unsigned int slot = atomicAdd(lcnt, 1u);
+        if (slot < (unsigned int)kSL) {
+          lkey[slot] = key[e];
+          lid[slot] = cid[lane + 64 * e];
+        }
+      }
+    wave_sync();
+    const int n = (int)*lcnt;
+    if (n > kSL) {  // more candidates inside the band than the list holds (values tied by the hundred)
+      if (lane == 0) {
+        ovf_flags[q] = 2u;
+        atomicAdd(cand_total + 1, 1ULL);
+      }
+      return;
+    }
+    {  // order the list by (value, position): rank by counting, kSLpl entries per lane
+      unsigned long long mk[kSLpl];
+      int mi[kSLpl], mr[kSLpl];
+#pragma unroll
+      for (int w = 0; w < kSLpl; ++w) {
+        const int i = lane + 64 * w;
+        mk[w] = i < n ? lkey[i] : ~0ULL;
+        mi[w] = i < n ? lid[i] : 0;
+      }
+#pragma unroll
+      for (int w = 0; w < kSLpl; ++w) mr[w] = lane + 64 * w < n ? count_below(lkey, n, mk[w]) : 0;
+      wave_sync();
+#pragma unroll
+      for (int w = 0; w < kSLpl; ++w)
+        if (lane + 64 * w < n) {
+          lkey[mr[w]] = mk[w];
+          lid[mr[w]] = mi[w];
+        }
+      wave_sync();
+    }
+    n_list = n;
+    if (n > k) {  // trim to the band of the (now exact) k-th smallest value: a prefix of the ordered list
+      const unsigned int vk = (unsigned int)(lkey[k - 1] >> 32);
+      const unsigned int thr1 = vk >= 0x7f800000u ? 0x7fc00000u : keep_bits(upper(dh_up(vk)));
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < kSLpl; ++w)
+        c += __popcll(__ballot(lane + 64 * w < n && (unsigned int)(lkey[lane + 64 * w] >> 32) <= thr1));
+      n_list = c;
+    }
+    pos_base += take;
+    KSTAMP();  // list updated
+  }
+
+  // ---- exact distances, first round: the entries whose estimate is within r1_pct % of the error bound
+  // above the k-th estimate (the k-th exact distance is about the k-th estimate: what lies beyond
+  // that is what the second round would have to add)
+  auto exact = [&](int from, int to) {
+    if constexpr (std::is_same<TD, double>::value) {
+      for (int i = from + lane; i < to; i += 64)  // the reference's own arithmetic (leftfold_distance)
+        rdist[i] = leftfold_distance(reinterpret_cast<const double*>(X) + (int64_t)lid[i] * d,
+                                     reinterpret_cast<const double*>(qs), d);
+    } else {
+      batch_distances<TD, TA>(X, d, lid, rdist, qs, from, to, 0, 1, lane);
+    }
+  };
+  auto prefix_le = [&](unsigned int tb) -> int {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < kSLpl; ++w)
+      c += __popcll(__ballot(lane + 64 * w < n_list && (unsigned int)(lkey[lane + 64 * w] >> 32) <= tb));
+    return c;
+  };
+  // rank of entry (di, pi) among the refined entries [0, m) by (exact distance, position); NaN behind
+  // every number, NaNs by position
+  auto rank_of = [&](int m, double di, unsigned int pi) -> int {
+    int rank = 0;
+    if (di != di) {
+      for (int j = 0; j < m; ++j) rank += rdist[j] == rdist[j] || (unsigned int)lkey[j] < pi;
+      return rank;
+    }
+    int j = 0;
+    for (; j + 8 <= m; j += 8) {
+      double a[8];
+      unsigned int b[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        a[w] = rdist[j + w];
+        b[w] = (unsigned int)lkey[j + w];
+      }
+#pragma unroll
+      for (int w = 0; w < 8; ++w) rank += a[w] < di || (a[w] == di && b[w] < pi);
+    }
+    for (; j < m; ++j) rank += rdist[j] < di || (rdist[j] == di && (unsigned int)lkey[j] < pi);
+    return rank;
+  };
+  int m = n_list;
+  if (n_list > k) {
+    const double dk = dh_up((unsigned int)(lkey[k - 1] >> 32));
+    int r1 = prefix_le(keep_bits((dk + (A + Bt * dk) * (0.01 * (double)r1_pct) - A) * (1.0 - Bf)));
+    // (keep_bits(U) keeps Dh <= (U / (1 - Bf) + A) / (1 - Bt): with the U above that is about
+    // Dh <= dk + r1_pct % of the bound)
+    r1 = r1 < k ? k : r1;
+    exact(0, r1);
+    wave_sync();
+    KSTAMP();  // first round
+    m = r1;
+    if (r1 < n_list) {
+      // U = the k-th smallest exact distance so far; entries beyond r1 with lower(Dh) <= U follow
+      double U = 0.0;
+      {
+        double dv[kSLpl];
+        unsigned long long hit[kSLpl];
+#pragma unroll
+        for (int w = 0; w < kSLpl; ++w) {
+          const int i = lane + 64 * w;
+          dv[w] = i < r1 ? rdist[i] : 0.0;
+          const int rk = i < r1 ? rank_of(r1, dv[w], (unsigned int)lkey[i]) : -1;
+          hit[w] = __ballot(rk == k - 1);
+        }
+#pragma unroll
+        for (int w = 0; w < kSLpl; ++w)
+          if (hit[w]) U = __shfl(dv[w], __ffsll((long long)hit[w]) - 1);  // (uniform: exactly one hit)
+      }
+      const int r2 = U == U ? prefix_le(keep_bits(U)) : n_list;
+      if (r2 > r1) {
+        exact(r1, r2);
+        wave_sync();
+        m = r2;
+      }
+      KSTAMP();  // second round
+    }
+  } else {
+    exact(0, n_list);
+    wave_sync();
+    KSTAMP();
+  }
+  // ---- the k best of the m refined entries by (exact distance, position) ----
+  {
+#pragma unroll
+    for (int w = 0; w < kSLpl; ++w) {
+      const int i = lane + 64 * w;
+      if (i < m) {
+        const double di = rdist[i];
+        const int rk = rank_of(m, di, (unsigned int)lkey[i]);
+        if (rk < k) {
+          out_ids[q * k + rk] = lid[i];
+          out_dist[q * k + rk] = di;
+        }
+      }
+    }
+    const int best = m < k ? m : k;
+    for (int i = best + lane; i < k; i += 64) {
+      out_ids[q * k + i] = -1;
+      out_dist[q * k + i] = __longlong_as_double(0x7ff0000000000000LL);
+    }
+    if (lane == 0) out_cnt[q] = best;
+  }
   KSTAMP();
 #undef KSTAMP
 }
@@ -3147,10 +3618,13 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const int vote = dedup >> 8;  // voting mode: the workgroup kernel, all-exact distances
   int64_t leaf = f->n;  // the size splitting stops at: the first level's node size <= minLeaf, or depth L
   for (int l = 0; l < f->L && leaf > (int64_t)f->min_leaf; ++l) leaf -= leaf / 2;
-  bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 &&
-              (int64_t)f->T * (leaf > 0 ? leaf : 1) <= kWaveCandidates;
-  if (force >= 0) wave = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
-  if (vote > 0 || data->csr) wave = false;
+  const int64_t est_cand = (int64_t)f->T * (leaf > 0 ? leaf : 1);
+  bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 && est_cand <= kWaveCandidates;
+  // the round-4 shard kernels (traversal as its own launch, adaptive certified set) stay ahead of the
+  // workgroup kernel for longer: an 8-tree C2 shard (980 candidates) 0.42 against 0.65 ms per 10 000 queries
+  bool wave_shard = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 && est_cand <= kShardCandidates;
+  if (force >= 0) wave = wave_shard = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
+  if (vote > 0 || data->csr) wave = wave_shard = false;
   // debug_stamps: phase clocks of one wave of the wave kernel, printed after the launch
   DevBuf<unsigned long long> dbgdev;
   unsigned long long* dbg = nullptr;
@@ -3217,10 +3691,45 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const void* shadow = sh8    ? (const void*)data->shadow8
                        : sh16 ? (const void*)data->shadow16
                               : (const void*)data->shadow32;
-  if (wave) {
+  if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
+    if (wave_shard && !wave && !((pre32 || sh16 || sh8) && k <= kSKmax && !ctx->opt.knn_shard_old))
+      wave_shard = false;  // (only the prefiltered instantiations have the shard kernels)
+  } else {
+    wave_shard = false;
+  }
+  if (wave || wave_shard) {
     dbgprint.p = dbg;
     const size_t smem = 4 * wbytes;
     if constexpr (!std::is_same<TD, __hip_bfloat16>::value) {
+      // round 4: traversal as its own launch, exact distances for an adaptive certified set
+      // (shard_ranges_kernel / knn_shard_wave_kernel); knn_shard_old = 1 keeps the round-3 kernel
+      if (wave_shard && (pre32 || sh16 || sh8) && k <= kSKmax && !ctx->opt.knn_shard_old) {
+        const int64_t nq = q->n;
+        DevBuf<int2> hdr;
+        DevBuf<int64_t> roff;
+        DevBuf<int> rlen;
+        RPT_TRY(hdr.alloc((size_t)nq));
+        RPT_TRY(roff.alloc((size_t)nq * kWR));
+        RPT_TRY(rlen.alloc((size_t)nq * kWR));
+        const int qpw = 64 / f->T;
+        hipLaunchKernelGGL(shard_ranges_kernel<TK>, dim3((unsigned)((nq + 4 * qpw - 1) / (4 * qpw))), dim3(256), 0,
+                           ctx->stream, f->thr.p, f->mglo.p, f->mghi.p, f->nodes, (const TK*)Pq, nq, f->T, f->L,
+                           f->min_leaf, f->n, hdr.p, roff.p, rlen.p, ovf + 1, ovf, cand_total);
+        RPT_HIP(hipGetLastError());
+        const bool one_batch = (int64_t)f->T * (leaf > 0 ? leaf : 1) <= kWC;
+        const size_t smem2 = 4 * shard_wave_bytes(data->d, sizeof(TA), one_batch ? 128 : 256);
+        auto kern = sh8    ? (one_batch ? knn_shard_wave_kernel<TD, 3, 128, 4> : knn_shard_wave_kernel<TD, 3, 256, 3>)
+                    : sh16 ? (one_batch ? knn_shard_wave_kernel<TD, 2, 128, 4> : knn_shard_wave_kernel<TD, 2, 256, 3>)
+                           : (one_batch ? knn_shard_wave_kernel<TD, 1, 128, 4> : knn_shard_wave_kernel<TD, 1, 256, 3>);
+        if (smem2 > 64 * 1024)
+          RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+        const int r1_pct = ctx->opt.tune0 > 0 ? (int)ctx->opt.tune0 : 110;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem2, ctx->stream, (const TD*)data->X,
+                           data->d, (const TD*)q->X, f->perm.p, nq, k, hdr.p, roff.p, rlen.p, ids, dist, cnt,
+                           ovf + 1, cand_total, shadow, data->max_norm, s8, r1_pct, dbg);
+        RPT_HIP(hipGetLastError());
+        return RPT_OK;
+      }
       if (pre32 || sh16 || sh8) {
         auto kern = sh8 ? knn_fused_wave_kernel<TD, TK, true, true> : knn_fused_wave_kernel<TD, TK, true, false>;
         if (smem > 64 * 1024)

@@ -598,7 +598,7 @@ __global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, 
   }
 }
 
-template <class TIn, class TC, int D, int CBT, bool CODES = false>
+template <class TIn, class TC, int D, int CBT, bool CODES = false, bool NT = false>
 __device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_t n,
                                                const TC* __restrict__ Apad, int c0,
                                                int ncol, TC* __restrict__ P,
@@ -655,9 +655,16 @@ __device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PIECES_PER_ROW;
       row = row < last_row ? row : last_row;
-      if ((p % PIECES_PER_ROW) * PIECE < kvalid)
-        stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
-      else
+      if ((p % PIECES_PER_ROW) * PIECE < kvalid) {
+        if constexpr (NT) {  // experiment: streaming loads of X (read once per launch)
+          typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+          const u4 raw = __builtin_nontemporal_load(
+              reinterpret_cast<const u4*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE));
+          __builtin_memcpy(&stage[i], &raw, 16);
+        } else {
+          stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
+        }
+      } else
         stage[i] = Raw{};  // past the end of a short row: kvalid is a multiple of PIECE
     }
   };
@@ -697,7 +704,7 @@ __device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_
   }
 }
 
-template <class TIn, class TC, int D, int CBT, bool CODES = false>
+template <class TIn, class TC, int D, int CBT, bool CODES = false, bool NT = false>
 __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0, int ncol,
                                                          TC* __restrict__ P, int64_t ldp, int64_t ntiles,
@@ -705,8 +712,8 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
                                                          uint16_t* __restrict__ Cd, int64_t ldc,
                                                          const unsigned long long* __restrict__ cmm,
                                                          int cL, int cLc) {
-  proj_fast_body<TIn, TC, D, CBT, CODES>(X, n, Apad, c0, ncol, P, ldp, ntiles, ldx, accumulate, kvalid, Cd,
-                                         ldc, cmm, cL, cLc);
+  proj_fast_body<TIn, TC, D, CBT, CODES, NT>(X, n, Apad, c0, ncol, P, ldp, ntiles, ldx, accumulate, kvalid, Cd,
+                                             ldc, cmm, cL, cLc);
 }
 
 // Few rows, many hyperplanes (a query batch against every (tree, level) of a forest): ALL column
@@ -1406,14 +1413,15 @@ int32_t launch_wide(rpt_ctx* ctx, const rpt_dataset* ds, int k0, int kvalid, int
   constexpr int WPB = 8;
   constexpr size_t smem = wide_smem_bytes<TC, D, CBT, KS, WPB>();
   static DeviceOnce attr_once;  // per device: one process may drive several (rpt_comm_init)
-  if (attr_once.first(ctx->device)) {
+  RPT_TRY(attr_once.run(ctx->device, [&]() -> int32_t {
     RPT_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     RPT_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  }
+    return RPT_OK;
+  }));
   if (co)
     hipLaunchKernelGGL((proj_mfma_wide<TIn, TC, D, CBT, KS, WPB, true>), dim3((unsigned)blocks),
                        dim3(WPB * 64), smem, ctx->stream, (const TIn*)ds->X + k0, ds->n, Ab, c0,
@@ -1548,7 +1556,12 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                      cop ? cop->ld : (int64_t)0, cop ? cop->mm : (const unsigned long long*)nullptr, \
                      cop ? cop->L : 1, cop ? cop->Lc : 0)
           if (ps.ncol > 16) {
-            if (cop) RPT_FAST(2, true);
+            if (ctx->opt.tune2 == 1 && !cop)  // experiment: nontemporal X loads
+              hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2, false, true>), dim3((unsigned)blocks), dim3(256), 0,
+                                 ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n, ntiles,
+                                 (int64_t)ds->d, accumulate, kvalid, (uint16_t*)nullptr, (int64_t)0,
+                                 (const unsigned long long*)nullptr, 1, 0);
+            else if (cop) RPT_FAST(2, true);
             else RPT_FAST(2, false);
           } else {
             if (cop) RPT_FAST(1, true);
@@ -1593,12 +1606,13 @@ int32_t launch_bf16x3_pass(rpt_ctx* ctx, const rpt_dataset* ds, const uint4* Aim
   if (blocks < 1) blocks = 1;
   constexpr size_t smem = (size_t)2 * kB3KC * 3 * CBT * 64 * 16;
   static DeviceOnce attr_once;
-  if (attr_once.first(ctx->device)) {
+  RPT_TRY(attr_once.run(ctx->device, [&]() -> int32_t {
     RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  }
+    return RPT_OK;
+  }));
   if (nch == 2)
     hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), smem,
                        ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
@@ -1736,9 +1750,11 @@ int32_t launch_csr(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int
     const size_t smem = whole ? tile32 : half32;
     auto kern = fused ? proj_csr_lds32<T, true> : proj_csr_lds32<T, false>;
     static DeviceOnce attr_once[2];
-    if (attr_once[fused].first(ctx->device))
+    RPT_TRY(attr_once[fused].run(ctx->device, [&]() -> int32_t {
       RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kLdsMax));
+      return RPT_OK;
+    }));
     for (int b = 0; b < nblk; ++b) {
       const int c0 = b * CB;
       const int ncol = C - c0 < CB ? C - c0 : CB;

@@ -213,6 +213,86 @@ def test_failed_rank_poisons_the_exchange_instead_of_hanging(rp, ctx, case):
         comm.close()
 
 
+def test_a_failed_batch_is_reported_after_later_batches_succeeded(rp, ctx, case):
+    """The failed word of an exchange accumulates until rpt_comm_sync reads it: batch 1 fails, batch 2
+    succeeds, ONE sync after both still names the rank; the sync resets the word."""
+    import torch
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    k, nq = 5, 64
+    comm = sharded.Comm.rank(ctx, 1, 0, sharded.Comm.unique_id())
+    old = ctx.set_option("comm_force_exchange", 1)
+    try:
+        ds = rp.Dataset.dense(ctx, X)
+        qs = rp.Dataset.dense(ctx, Q[:nq])
+        sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+        bufs = [(torch.zeros((nq, k), dtype=torch.int32, device="cuda"),
+                 torch.zeros((nq, k), dtype=torch.float64, device="cuda"),
+                 torch.zeros((nq,), dtype=torch.int32, device="cuda")) for _ in range(2)]
+        torch.cuda.synchronize()
+        ctx.set_option("comm_inject_failure", 1)
+        with pytest.raises(rp.RPTError, match="comm_inject_failure"):
+            sf.knn_dev([qs], k, 0, *[[b.data_ptr()] for b in bufs[0]])
+        ctx.set_option("comm_inject_failure", 0)
+        sf.knn_dev([qs], k, 0, *[[b.data_ptr()] for b in bufs[1]])       # a good batch, no sync in between
+        with pytest.raises(rp.RPTError, match="rank 0 failed"):
+            comm.sync()
+        assert (bufs[0][2].cpu().numpy() == -1).all()
+        plain, _, _ = sf.local(0)
+        wi, wd, wc = rp.knnBatch(k, plain, Q[:nq])
+        assert np.array_equal(bufs[1][0].cpu().numpy(), wi) and np.array_equal(bufs[1][2].cpu().numpy(), wc)
+        sf.knn_dev([qs], k, 0, *[[b.data_ptr()] for b in bufs[1]])
+        comm.sync()                                                       # the word was reset: no stale report
+        sf.close()
+        ds.close()
+        qs.close()
+    finally:
+        ctx.set_option("comm_inject_failure", 0)
+        ctx.set_option("comm_force_exchange", old)
+        comm.close()
+
+
+def test_a_stalled_exchange_aborts_the_communicator_instead_of_hanging(rp, ctx, case):
+    """rpt_comm_sync polls hipStreamQuery + ncclCommGetAsyncError under a deadline instead of blocking in
+    hipStreamSynchronize (a peer that never joins leaves an RCCL collective spinning).
+    comm_stall_test makes a pending exchange count as past its deadline: the local communicator is
+    aborted, the call returns RPT_E_INTERNAL, later sharded calls fail fast."""
+    import torch
+    from rptree_amd import sharded
+    X, Q, R, L, ml = case
+    k = 10
+    Qbig = np.concatenate([Q] * 40)[:10_000]
+    nq = len(Qbig)
+    comm = sharded.Comm.rank(ctx, 1, 0, sharded.Comm.unique_id())
+    old = ctx.set_option("comm_force_exchange", 1)
+    try:
+        ds = rp.Dataset.dense(ctx, X)
+        qs = rp.Dataset.dense(ctx, Qbig)
+        sf = sharded.ShardedForest(comm, [ds], R, L, ml)
+        oi = torch.zeros((nq, k), dtype=torch.int32, device="cuda")
+        od = torch.zeros((nq, k), dtype=torch.float64, device="cuda")
+        oc = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+        comm.sync()                                                       # the normal path: polls to completion
+        ctx.set_option("comm_stall_test", 1)
+        sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+        with pytest.raises(rp.RPTError, match="did not complete|aborted"):
+            comm.sync()
+        ctx.set_option("comm_stall_test", 0)
+        with pytest.raises(rp.RPTError, match="aborted"):
+            sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
+        ctx.sync()
+        sf.close()
+        ds.close()
+        qs.close()
+    finally:
+        ctx.set_option("comm_stall_test", 0)
+        ctx.set_option("comm_force_exchange", old)
+        comm.close()
+
+
+
 def test_comm_argument_errors(rp, ctx, case):
     from rptree_amd import _lib, sharded
     L_ = _lib.lib()

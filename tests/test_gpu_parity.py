@@ -1112,3 +1112,118 @@ def test_knn_many_trees_slots_and_second_traversal(rp, ctx, oracle, option, T):
         wi, wd = oracle.knn_dense(fo, X, Q[i], k)
         assert got[2][i] == len(wi) and np.array_equal(got[0][i, :got[2][i]], wi)
         assert np.array_equal(got[1][i, :got[2][i]], wd)
+
+
+# ------------------------------------------------------------------ round 4: small-shard query kernels
+def _tier_and_uncertified(ctx):
+    import ctypes as C
+    from rptree_amd import _lib
+    tier, unc = C.c_int32(-1), C.c_int64(-1)
+    _lib.check(_lib.lib().rpt_knn_last_tier(ctx._h, C.byref(tier)))
+    _lib.check(_lib.lib().rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
+    return tier.value, unc.value
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", [(20000, 128, 4, 100), (20000, 128, 8, 100), (12000, 64, 3, 60),
+                                   (9000, 208, 5, 90)])
+@pytest.mark.parametrize("kind", ["cont", "ties", "self"])
+def test_knn_shard_kernels_are_exact(rp, ctx, oracle, option, dtype, shape, kind):
+    """Small tree shards (what one of G GPUs holds) are answered by shard_ranges_kernel (traversal,
+    lane = (query, tree)) + knn_shard_wave_kernel (one wave per query; exact distances only for the
+    candidates the tier's bounds cannot exclude).  Same answers, bit for bit, as the round-3 one-wave
+    kernel, the workgroup kernel, the all-exact kernel and (f64) the oracle: every ranking tier, one
+    batch and several (8 x ~78 candidates > 512), three trees (63 lanes of the traversal), rows of
+    4 / 8 / 13 sixteen-byte pieces, continuous / rounded data and queries that ARE data points (one
+    copy per tree at distance 0)."""
+    n, d, T, ml = shape
+    X = oracle.data_normal_dense2(41, n, d)
+    if kind == "ties":
+        X = np.round(X * 2) / 2
+    rng = np.random.default_rng(5)
+    Q = X[rng.integers(0, n, 48)].copy()
+    if kind != "self":
+        Q += 0.004
+    if dtype == "f32":
+        X, Q = X.astype(np.float32), Q.astype(np.float32)
+    cfg = rp.rpTreeCfg(ml, n, d)
+    L, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+    R, _ = oracle.forest_hyperplanes(9, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    fo = oracle.forest_build_dense(X.astype(np.float64), R, ml) if dtype == "f64" else None
+    tiers_seen = set()
+    for k in (1, 10, 40):
+        with option("knn_no_pre32", 1):
+            ref = rp.knnBatch(k, f, Q)                       # all-exact distances
+        variants = [("int8", {}), ("half", {"knn_no_pre8": 1})]
+        if dtype == "f64":
+            variants.append(("f32", {"knn_no_pre16": 1}))
+        for name, opts in variants:
+            import contextlib
+            with contextlib.ExitStack() as st:
+                st.enter_context(option("knn_wave", 1))
+                for o, v in opts.items():
+                    st.enter_context(option(o, v))
+                got = rp.knnBatch(k, f, Q)
+                tiers_seen.add(_tier_and_uncertified(ctx)[0])
+                with option("knn_shard_old", 1):
+                    old = rp.knnBatch(k, f, Q)
+            for a, b, c in zip(got, ref, old):
+                assert np.array_equal(a, b), (name, k, kind)
+                assert np.array_equal(a, c), (name, k, kind)
+        if fo is not None:
+            ids, dist, cnt = ref
+            for i in range(0, len(Q), 6):
+                wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+                assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+                assert np.array_equal(dist[i, :cnt[i]], wd)
+    assert tiers_seen & {2, 3}, tiers_seen
+
+
+def test_knn_shard_list_overflow_goes_to_the_exact_kernel(rp, ctx, oracle, option):
+    """More candidates inside the band of the k-th estimate than the carried list holds (here: every
+    point of a leaf is one of three values, hundreds of equal estimates) flag the query; the exact
+    kernel answers it — the oracle's ids (ties in position order) and distances."""
+    n, d, T, ml, k = 6000, 16, 4, 400, 10
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((3, d))
+    X = base[rng.integers(0, 3, n)].copy()
+    Q = base[[0, 1, 2, 0]] + 0.01
+    cfg = rp.rpTreeCfg(ml, n, d)
+    L, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+    R, _ = oracle.forest_hyperplanes(4, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    fo = oracle.forest_build_dense(X, R, ml)
+    with option("knn_wave", 1):
+        ids, dist, cnt = rp.knnBatch(k, f, Q)
+        tier, unc = _tier_and_uncertified(ctx)
+    assert tier >= 1 and unc > 0, (tier, unc)
+    for i in range(len(Q)):
+        wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+        assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
+        assert np.array_equal(dist[i, :cnt[i]], wd)
+
+
+@pytest.mark.parametrize("wave", [1, 0])
+@pytest.mark.parametrize("pre", [1, 0])
+def test_knn_nan_query_is_answered_and_hurts_nobody(rp, ctx, oracle, option, wave, pre):
+    """A NaN in one query (the rank counting of the exact stage gave every NaN distance
+    rank 0 and read uninitialised slots).  NaN distances now have a total order (behind every number,
+    by position): the NaN query gets k in-range ids, the other queries of the batch their usual answers."""
+    n, d, T, ml, k = 20000, 32, 4, 100, 10
+    X = oracle.data_normal_dense2(8, n, d)
+    Q = oracle.data_normal_dense2(9, 16, d)
+    cfg = rp.rpTreeCfg(ml, n, d)
+    L, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+    R, _ = oracle.forest_hyperplanes(2, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    with option("knn_wave", wave), option("knn_no_pre32", 0 if pre else 1):
+        clean = rp.knnBatch(k, f, Q)
+        Qn = Q.copy()
+        Qn[5, 7] = np.nan
+        ids, dist, cnt = rp.knnBatch(k, f, Qn)
+    keep = np.arange(len(Q)) != 5
+    for a, b in zip((ids, dist, cnt), clean):
+        assert np.array_equal(a[keep], b[keep])
+    assert cnt[5] == k and np.all((ids[5] >= 0) & (ids[5] < n)) and len(set(ids[5].tolist())) >= 1
+    assert np.all(np.isnan(dist[5]))

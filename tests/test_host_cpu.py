@@ -30,6 +30,27 @@ def test_library_exports_every_declared_symbol(rp):
     assert L.rpt_abi_version() == 1
 
 
+def test_header_is_plain_c99():
+    """The drop-in boundary is a C ABI: include/rptree_hip.h must compile as C99 on its own (what a
+    `foreign import ccall` / cgo / ctypes binding generator sees), with warnings as errors."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "rptree_hip.h")
+    for std in ("c99", "c11"):
+        pr = subprocess.run([gcc, "-std=" + std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                             "-x", "c", hdr], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert pr.returncode == 0, pr.stdout.decode()
+    # ... and as C++ (the host mirror includes it)
+    gxx = shutil.which("g++")
+    if gxx:
+        pr = subprocess.run([gxx, "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert pr.returncode == 0, pr.stdout.decode()
+
+
 def test_no_device_fails_loudly(rp):
     """There is no CPU fallback: without a HIP device compute entry points return an error."""
     import torch
