@@ -288,6 +288,10 @@ int32_t rpt_knn_last_candidates(rpt_ctx* ctx, int64_t* total);
 /* ... and how many of its queries the f32 prefilter could not certify (equal distances at its
  * cut) and were answered again with all-f64 distances; 0 when the prefilter was not used */
 int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total);
+/* ... and how many took the in-kernel second attempt (a cut the first, narrower selection could not
+ * certify, retried with three times the kept entries by the same workgroup).  Telemetry: a forest whose
+ * batches retry often starts its later batches wider. */
+int32_t rpt_knn_last_retries(rpt_ctx* ctx, int64_t* total);
 /* ... and the shadow its candidates were ranked on: 0 = none (all-f64 distances), 1 = the f32 copy
  * of the dataset, 2 = its IEEE-half copy (round 3: a quarter of the f64 bytes; keeps k + max(8, k / 2)
  * entries for the exact pass, same certificate with the half rounding in the error bound), 3 = its

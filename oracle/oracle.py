@@ -62,6 +62,7 @@ def lib():
         L.rpo_knn_h_dense.restype = C.c_int64
         L.rpo_knn_h_csr.restype = C.c_int64
         L.rpo_candidates_h_dense.restype = C.c_int64
+        L.rpo_stream_knn_h_dense.restype = C.c_int64
         L.rpo_data_normal_sparse2.restype = C.c_int64
         L.rpo_data_sparse_uniform.restype = C.c_int64
         L.rpo_next_double.restype = C.c_double
@@ -459,6 +460,30 @@ def stream_forest_dense(X, R, min_leaf, chunk):
     return StreamForest(N, L, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids, held)
 
 
+def stream_forest_csr(rowptr, col, val, d, R, min_leaf, chunk):
+    """Conduit.hs:104-121 `forest` on a source of SVector rows (CSR arrays), chunks of `chunk` rows"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    N = len(rowptr) - 1
+    T, L, _ = R.shape
+    S = (1 << (L + 1)) - 1
+    kind = np.zeros((T, S), dtype=np.int8)
+    thr, mglo, mghi = (np.empty((T, S), dtype=np.float64) for _ in range(3))
+    leaf_off = np.zeros((T, S), dtype=np.int64)
+    leaf_len = np.zeros((T, S), dtype=np.int64)
+    leaf_ids = np.full((T, max(N, 1)), -1, dtype=np.int32)
+    held = np.zeros(T, dtype=np.int64)
+    lib().rpo_stream_forest_csr(_p(rowptr, _i64p), _p(col, _i32p), _p(val, _f64p), C.c_int64(N), C.c_int32(d),
+                                _p(R, _f64p), C.c_int32(T), C.c_int32(L), C.c_int32(min_leaf),
+                                C.c_int64(chunk), kind.ctypes.data_as(C.POINTER(C.c_int8)),
+                                _p(thr, _f64p), _p(mglo, _f64p), _p(mghi, _f64p),
+                                _p(leaf_off, _i64p), _p(leaf_len, _i64p), _p(leaf_ids, _i32p),
+                                _p(held, _i64p))
+    return StreamForest(N, L, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids, held)
+
+
 def _sargs(sf):
     i8p = C.POINTER(C.c_int8)
     return (sf.kind.ctypes.data_as(i8p), _p(sf.thr, _f64p), _p(sf.mglo, _f64p), _p(sf.mghi, _f64p),
@@ -489,6 +514,24 @@ def stream_knn_dense(sf, R, X, q, k, dedup=0):
                                    _p(R, _f64p), C.c_int32(T), C.c_int32(L), *_sargs(sf),
                                    C.c_int32(k), C.c_int32(int(dedup)), _p(ids, _i32p), _p(dist, _f64p))
     return ids[:m], dist[:m]
+
+
+def stream_knn_h_dense(sf, R, X, q, k):
+    """RPTree.hs:199-217 `knnH metricL2` over a streamed forest -> (ids, dist): whole buckets, unsorted"""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    T, L, d = R.shape
+    cap = 4096
+    while True:
+        ids = np.empty(cap, dtype=np.int32)
+        dist = np.empty(cap, dtype=np.float64)
+        m = lib().rpo_stream_knn_h_dense(_p(X, _f64p), C.c_int64(sf.N), C.c_int32(d), _p(q, _f64p),
+                                         _p(R, _f64p), C.c_int32(T), C.c_int32(L), *_sargs(sf),
+                                         C.c_int32(k), _p(ids, _i32p), _p(dist, _f64p), C.c_int64(cap))
+        if m <= cap:
+            return ids[:m].copy(), dist[:m].copy()
+        cap = int(m)
 
 
 def brute_knn_dense(X, q, k):

@@ -360,7 +360,9 @@ std::vector<LeafEntry> knn_h_select(std::vector<LeafEntry> es, int32_t k) {
   int64_t n = 0;
   for (const LeafEntry& e : es) {
     const int64_t ntot = e.n + n;
-    if (ntot > k && !acc.empty()) break;
+    // `not (null acc)`: acc is the vector of POINTS taken so far (:216) — an empty bucket (a streamed
+    // tree can hold one) does not count as "at least one"; batch forests have no empty leaves
+    if (ntot > k && n > 0) break;
     acc.insert(acc.begin(), e);
     n = ntot;
   }
@@ -1205,6 +1207,17 @@ void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double
 }
 
 
+// the same fold over SVector rows (`forest` is polymorphic in Inner SVector v, Conduit.hs:104-113):
+// every inner product is innerSS (Internal.hs:351-366)
+void rpo_stream_forest_csr(const int64_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                           int32_t d, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                           int64_t chunk, int8_t* kind, double* thr, double* mglo, double* mghi,
+                           int64_t* leaf_off, int64_t* leaf_len, int32_t* leaf_ids, int64_t* held) {
+  CsrData D{rowptr, col, val, N, d};
+  stream_forest(D, R, T, L, minLeaf, chunk, kind, thr, mglo, mghi, leaf_off, leaf_len, leaf_ids,
+                held);
+}
+
 // ---- queries on a streamed tree: RPTree.hs:289-314 `candidates` / :168-176 `knn` walk the RPT
 // value whatever built it; on the heap arrays of rpo_stream_forest_dense a Tip is kind 2 with
 // its payload at leaf_off / leaf_len, a Bin kind 1; kind 0 never hangs below a Bin.
@@ -1265,6 +1278,59 @@ int32_t rpo_stream_knn_dense(const double* X, int64_t N, int32_t d, const double
   return topk_from(cs, k, dedup, out_ids, out_dist);
 }
 
+
+// knnH (RPTree.hs:199-217) over a streamed forest: candidatesH (:318-342) walks the RPT value whatever
+// built it — on the heap arrays a Tip is kind 2 (its bucket at leaf_off / leaf_len, possibly empty),
+// a Bin kind 1 — then the same bucket selection as the batch forests' (knn_h_select).
+int64_t rpo_stream_knn_h_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                               int32_t T, int32_t L, const int8_t* kind, const double* thr,
+                               const double* mglo, const double* mghi, const int64_t* leaf_off,
+                               const int64_t* leaf_len, const int32_t* leaf_ids, int32_t k,
+                               int32_t* out_ids, double* out_dist, int64_t cap) {
+  const int64_t slots = ((int64_t)1 << (L + 1)) - 1;
+  std::vector<SparseVec> all = sparsify(R, T, L, d);
+  std::vector<LeafEntry> es;
+  std::vector<double> projq((size_t)L);
+  for (int32_t t = 0; t < T; ++t) {
+    for (int32_t l = 0; l < L; ++l) {
+      const SparseVec& r = all[(size_t)t * L + l];
+      projq[l] = rpo_inner_sd((int64_t)r.idx.size(), r.idx.data(), r.val.data(), d, q);
+    }
+    const int8_t* kd = kind + t * slots;
+    const double *th = thr + t * slots, *lo = mglo + t * slots, *hi = mghi + t * slots;
+    const int64_t *lo_off = leaf_off + t * slots, *ln = leaf_len + t * slots;
+    std::function<void(int32_t, int64_t, double)> go = [&](int32_t level, int64_t h, double p) {
+      if (kd[h] != 1) {  // :323 Tip -> insertp p xs
+        if (kd[h] == 2) es.push_back(LeafEntry{p, t, lo_off[h], ln[h]});
+        return;
+      }
+      const double proj = projq[level];
+      const double dl = std::fabs(lo[h] - proj), dr = std::fabs(hi[h] - proj);  // :330-331
+      const double pl = p <= dl ? p : dl, pr = p <= dr ? p : dr;                // :332-333
+      if (proj < th[h] && dl > dr) {  // :335-336
+        go(level + 1, 2 * h + 1, pl);
+        go(level + 1, 2 * h + 2, pr);
+      } else if (proj < th[h]) {  // :337
+        go(level + 1, 2 * h + 1, pl);
+      } else if (proj > th[h] && dl < dr) {  // :338-339
+        go(level + 1, 2 * h + 1, pl);
+        go(level + 1, 2 * h + 2, pr);
+      } else {  // :340
+        go(level + 1, 2 * h + 2, pr);
+      }
+    };
+    go(0, 0, std::numeric_limits<double>::infinity());  // :320
+  }
+  int64_t m = 0;
+  for (const LeafEntry& e : knn_h_select(es, k))
+    for (int64_t i = 0; i < e.n; ++i, ++m)
+      if (m < cap) {
+        const int32_t id = leaf_ids[(int64_t)e.tree * N + e.off + i];
+        out_ids[m] = id;
+        out_dist[m] = rpo_metric_dd(d, X + (int64_t)id * d, q);
+      }
+  return m;
+}
 
 // metricDDL2 with the squares through THIS box's libm pow (what a GHC-compiled reference calls);
 // the exponent is volatile so that the compiler cannot fold the call into a multiplication.

@@ -227,6 +227,11 @@ void rpo_stream_forest_dense(const double* X, int64_t N, int32_t d, const double
                              int32_t L, int32_t minLeaf, int64_t chunk, int8_t* kind, double* thr,
                              double* mglo, double* mghi, int64_t* leaf_off, int64_t* leaf_len,
                              int32_t* leaf_ids, int64_t* held);
+void rpo_stream_forest_csr(const int64_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                           int32_t d, const double* R, int32_t T, int32_t L, int32_t minLeaf,
+                           int64_t chunk, int8_t* kind, double* thr, double* mglo, double* mghi,
+                           int64_t* leaf_off, int64_t* leaf_len, int32_t* leaf_ids, int64_t* held);
+
 
 /* `** 2` is the host libm's pow in the reference; see sq() in the .cpp.  rpo_metric_dd_libm folds
  * through this box's pow; rpo_pow2_mismatches counts arguments where pow(t, 2.0) != t * t. */
@@ -245,6 +250,14 @@ int32_t rpo_stream_knn_dense(const double* X, int64_t N, int32_t d, const double
                              const double* mglo, const double* mghi, const int64_t* leaf_off,
                              const int64_t* leaf_len, const int32_t* leaf_ids, int32_t k,
                              int32_t dedup, int32_t* out_ids, double* out_dist);
+/* knnH (RPTree.hs:199-217) over a streamed forest: whole buckets in increasing margin priority,
+ * neither sorted nor cut to k; returns the number of results (may exceed cap: call again). */
+int64_t rpo_stream_knn_h_dense(const double* X, int64_t N, int32_t d, const double* q, const double* R,
+                               int32_t T, int32_t L, const int8_t* kind, const double* thr,
+                               const double* mglo, const double* mghi, const int64_t* leaf_off,
+                               const int64_t* leaf_len, const int32_t* leaf_ids, int32_t k,
+                               int32_t* out_ids, double* out_dist, int64_t cap);
+
 
 #ifdef __cplusplus
 }

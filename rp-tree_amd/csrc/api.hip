@@ -784,7 +784,6 @@ int32_t rpt_forest_stream_build(rpt_ctx* ctx, const rpt_dataset* ds, const doubl
     RPT_ARG(min_leaf >= 0, "minLeaf must be >= 0");
     RPT_ARG(chunk >= 1, "chunk size must be >= 1");
     RPT_ARG(ds->ctx == ctx, "dataset belongs to another context");
-    RPT_ARG(!ds->csr, "the streaming build takes dense rows");
     RPT_HIP(hipSetDevice(ctx->device));
     rpt_forest* f = new (std::nothrow) rpt_forest();
     if (!f) return fail(RPT_E_NOMEM, "out of host memory");
@@ -995,7 +994,6 @@ int32_t rpt_knnh_host(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data,
     RPT_ARG(data->csr == queries->csr, "data and queries must both be dense or both CSR");
     RPT_ARG(k >= 1, "k must be >= 1");
     RPT_ARG(total, "total is NULL");
-    if (f->xtopo) return fail(RPT_E_UNSUPPORTED, "knnH on a streamed forest is not implemented");
     return knn_h(ctx, f, data, queries, k, off_host, ids_host, dist_host, cap, total);
   });
 }
@@ -1055,6 +1053,14 @@ int32_t rpt_knn_last_uncertified(rpt_ctx* ctx, int64_t* total) {
   return guarded([&]() -> int32_t {
     RPT_ARG(ctx && total, "NULL argument");
     *total = ctx->last_uncertified;
+    return RPT_OK;
+  });
+}
+
+int32_t rpt_knn_last_retries(rpt_ctx* ctx, int64_t* total) {
+  return guarded([&]() -> int32_t {
+    RPT_ARG(ctx && total, "NULL argument");
+    *total = ctx->last_retries;
     return RPT_OK;
   });
 }

@@ -180,6 +180,7 @@ struct rpt_ctx {
   size_t pin_cap = 0, pin_off = 0;
   int64_t last_uncertified = 0;  // queries of the last kNN call re-run with all-f64 distances
   int64_t last_candidates = 0;
+  int64_t last_retries = 0;      // queries of the last fused kNN call that took the in-kernel wider second attempt
   int32_t last_tier = 0;  // ranking tier of the last fused kNN call: 0 exact, 1 f32 shadow, 2 half, 3 int8
   // last build: nodes csub_kernel handed back to the general kernels (pivot codes shared by more
   // points than its pool), and how many of those for a histogram that contradicted the node
@@ -284,6 +285,7 @@ struct rpt_forest {
   bool prefilter_off = false;
   bool pre8_off = false;   // ... and one more: the int8 shadow failed too many cuts here
   bool pre16_off = false;  // ... the same one tier up: the f16 shadow failed too many cuts here
+  double kp8_boost = 1.0;  // int8 tier: factor on the kept entries, raised when a batch retried often
   int64_t nodes = 0;         // 2^L - 1
   rpt::DevBuf<int32_t> perm;  // [T][N] final leaf-ordered permutation
   rpt::DevBuf<double> thr, mglo, mghi;  // [T][nodes]

@@ -339,6 +339,59 @@ __global__ void ranges_h_kernel(const double* __restrict__ thr, const double* __
   }
 }
 
+// ... and over an EXPLICIT topology (streamed forests): candidatesH walks the RPT value whatever built
+// it (RPTree.hs:318-342); a Tip's bucket may be empty, its entry is inserted all the same (:323)
+template <class TK>
+__global__ void ranges_hx_kernel(const double* __restrict__ thr, const double* __restrict__ mglo,
+                                 const double* __restrict__ mghi, int64_t nodes,
+                                 const int8_t* __restrict__ kind, const TK* Pq, int64_t nq, int T, int L,
+                                 const int64_t* __restrict__ rng_off /*[nq*T+1]*/, double* __restrict__ prio) {
+  const int64_t q = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    int64_t r = rng_off[q * T + t];
+    const double *th = thr + t * nodes, *lo = mglo + t * nodes, *hi = mghi + t * nodes;
+    const TK* pq = Pq + (int64_t)t * L * nq + q;
+    int s_level[32];
+    unsigned int s_heap[32];
+    double s_p[32];
+    int sp = 1;
+    s_level[0] = 0;
+    s_heap[0] = 0;
+    s_p[0] = __longlong_as_double(0x7ff0000000000000LL);  // :320 infty = 1 / 0
+    while (sp > 0) {
+      --sp;
+      int level = s_level[sp];
+      unsigned int heap = s_heap[sp];
+      double p = s_p[sp];
+      for (;;) {
+        if (kind[heap] != 1) {  // :323 Tip (an absent slot holds nothing: the same test as traverse_x)
+          if (kind[heap] == 2) prio[r++] = p;
+          break;
+        }
+        const double proj = (double)pq[(int64_t)level * nq];
+        const double dl = fabs(lo[heap] - proj), dr = fabs(hi[heap] - proj);  // :330-331
+        const double pl = p <= dl ? p : dl, pr = p <= dr ? p : dr;            // :332-333
+        const bool both = (proj < th[heap] && dl > dr) || (proj > th[heap] && dl < dr);  // :335-339
+        if (both) {  // push right, continue left
+          s_level[sp] = level + 1;
+          s_heap[sp] = 2 * heap + 2;
+          s_p[sp] = pr;
+          ++sp;
+          heap = 2 * heap + 1;
+          p = pl;
+        } else if (proj < th[heap]) {
+          heap = 2 * heap + 1;
+          p = pl;
+        } else {
+          heap = 2 * heap + 2;
+          p = pr;
+        }
+        ++level;
+      }
+    }
+  }
+}
+
 // candidate ids for rpt_candidates: one block per (query, tree) range list
 __global__ void expand_kernel(const int32_t* __restrict__ perm, const Range* __restrict__ ranges,
                               const int64_t* __restrict__ rng_off, const int64_t* __restrict__ cand_off,
@@ -724,6 +777,49 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
 // tiers' (knn_fused_kernel), and an uncertified query is answered by the exact kernel.
 struct Sh8 {
   double s, emax;  // scale, max row error; s == 0: the tier is not in use
+};
+
+// What a ranking tier knows about the exact distance D of a row from its estimate Dh (round 4):
+//     lower(Dh) <= D <= upper(Dh),  lower(Dh) = (Dh - A - Bt Dh)(1 - Bf),  upper(Dh) = (Dh + A + Bt Dh)(1 + Bf)
+//   f32 shadow : A = 2.1 u (xmax + |q|) + sqrt(d) 4e-23,             Bt = (d + 2) u   (rounded inputs,
+//                differences, f32 accumulation, products in the subnormal range; knn_fused_kernel)
+//   half shadow: A = 1.05 2^-11 xmax + 2.1 u |q| + sqrt(d) 3.1e-8,   Bt = (d + 2) u
+//   int8 shadow: A = eq + emax (triangle inequality, Sh8), Bt = 0;  Dh = (s / 256) sqrt(I) and the
+//                value kept is I rounded to f32 (rnd = 1.2e-7 covers it)
+//   f32 DATA   : "exact" is the f32 distance the all-f32 kernel ranks on, within Bf = (d + 2) u of D
+// The stored ranking value v is a non-negative float (a squared distance, or I); Dh = g sqrt(v).
+struct TierBounds {
+  double A, Bt, Bf, g, rnd;
+  __device__ static TierBounds make(int tier /* 1 f32, 2 half, 3 int8 */, bool f64_data, int d, double xmax,
+                                    double qnorm, double q8eq, Sh8 sh8) {
+    const double u = 5.9604644775390625e-08;
+    TierBounds b;
+    b.A = tier == 3   ? (q8eq + sh8.emax) * (1.0 + 1e-12) + 1e-300
+          : tier == 2 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * qnorm + sqrt((double)d) * 3.1e-8
+                      : 2.1 * u * (xmax + qnorm) + sqrt((double)d) * 4e-23;
+    b.Bt = tier == 3 ? 0.0 : (double)(d + 2) * u;
+    b.Bf = f64_data ? 0.0 : (double)(d + 2) * u * 1.01;
+    b.g = tier == 3 ? sh8.s * (1.0 / 256.0) : 1.0;
+    b.rnd = tier == 3 ? 1.2e-7 : 0.0;
+    return b;
+  }
+  // the estimate of a stored value (its bits), rounded up
+  __device__ double dh_up(unsigned int vb) const {
+    return g * sqrt((double)__uint_as_float(vb) * (1.0 + rnd)) * (1.0 + 1e-15);
+  }
+  __device__ double upper(double dh) const { return (dh + A + Bt * dh) * (1.0 + Bf) * (1.0 + 1e-15); }
+  // a row may be dropped against the bound Ulim on the exact k-th distance iff lower(Dh) > Ulim, i.e.
+  // iff Dh > (Ulim / (1 - Bf) + A) / (1 - Bt); every stored value at or below the returned bits is KEPT
+  __device__ unsigned int keep_bits(double Ulim) const {
+    const double dstar = (Ulim / (1.0 - Bf) + A) / (1.0 - Bt) * (1.0 + 1e-15);
+    const double t = (dstar / g) * (dstar / g) / (1.0 - rnd) * (1.0 + 1e-15);
+    if (!(t < 3.0e38)) return 0x7fc00000u;  // inf / NaN: keep everything that is a number
+    float tf = (float)t;
+    if ((double)tf < t) tf = __uint_as_float(__float_as_uint(tf) + 1u);  // round up (t >= 0)
+    return __float_as_uint(tf);
+  }
+  // may a row whose stored value is vb be dropped against Ulim?  (the certificate of a fixed cut)
+  __device__ bool dropped_ok(unsigned int vb, double Ulim) const { return vb > keep_bits(Ulim); }
 };
 
 // quantised query -> planes[0 .. d/4) = hu words, planes[d/4 .. d/2) = lo words; the caller sums
@@ -1826,6 +1922,11 @@ retry_wider:
     }
   } else if constexpr (PRE32) {
     // ---- refine: exact distances of the entries the f32 pass kept; certify the cut ----
+    // (Round 4, measured and dropped HERE: the shard kernel's two-round refinement — exact distances
+    // first for the entries near the k-th estimate, then for those a bound U on the k-th exact distance
+    // cannot exclude: ~ 20 rows instead of 58 at C2.  The 58 rows are one lane-parallel round trip of a
+    // workgroup that waits at barriers either way; the second round and its counting passes cost more
+    // than the 35 KB they save: 1.288 against 1.274 ms per 10 000 queries on one box.)
     // The f32 distance of a row differs from the exact one by at most
     //   err(x) = 2.1 u (|x| + |q|) + (d + 2) u dist32,  u = 2^-24
     // (inputs rounded to f32, the differences, the f32 accumulation), so every candidate the
@@ -1895,6 +1996,8 @@ retry_wider:
       if (!(s_qn < 1e18) || !(F < 1e30) || !(F - err2 > bdist[best - 1])) {
         if (k1 < k1_retry) {  // (uniform: shared values decide)
           k1 = k1_retry;
+          // (counted: a forest whose batches retry often gets a wider first attempt, knn_dev)
+          if (tid == 0 && !rerun) atomicAdd(reinterpret_cast<unsigned int*>(cand_total) + 4, 1u);
           __syncthreads();
           goto retry_wider;
         }
@@ -2560,20 +2663,9 @@ __global__ __launch_bounds__(256, MINB) void knn_shard_wave_kernel(
   wave_sync();
   KSTAMP();  // 1: ranges + query
 
-  // ---- the tier's bounds: lower(Dh) <= D <= upper(Dh) for the exact distance D of a row whose
-  // estimate is Dh;  lower(Dh) = (Dh - A - Bt Dh)(1 - Bf),  upper(Dh) = (Dh + A + Bt Dh)(1 + Bf)
-  //   f32 shadow : A = 2.1 u (xmax + |q|) + sqrt(d) 4e-23,  Bt = (d + 2) u       (knn_fused_kernel)
-  //   half shadow: A = 1.05 2^-11 xmax + 2.1 u |q| + sqrt(d) 3.1e-8,  Bt = (d + 2) u
-  //   int8 shadow: A = eq + emax,  Bt = 0;  Dh = (s / 256) sqrt(I), the stored value is I rounded to f32
-  //   f32 DATA   : "exact" is the f32 distance the all-f32 kernel ranks on, within Bf = (d + 2) u of D
-  const double u = 5.9604644775390625e-08;
-  const double A = TIER == 3   ? (q8eq + sh8.emax) * (1.0 + 1e-12) + 1e-300
-                   : TIER == 2 ? 1.05 * 4.8828125e-4 * xmax + 2.1 * u * qnorm + sqrt((double)d) * 3.1e-8
-                               : 2.1 * u * (xmax + qnorm) + sqrt((double)d) * 4e-23;
-  const double Bt = TIER == 3 ? 0.0 : (double)(d + 2) * u;
-  const double Bf = std::is_same<TD, double>::value ? 0.0 : (double)(d + 2) * u * 1.01;
-  const double g = TIER == 3 ? sh8.s * (1.0 / 256.0) : 1.0;       // estimate = g sqrt(value)
-  const double rnd = TIER == 3 ? 1.2e-7 : 0.0;                    // the stored value against the integer
+  // ---- the tier's bounds (TierBounds) ----
+  const TierBounds tb = TierBounds::make(TIER, std::is_same<TD, double>::value, d, xmax, qnorm, q8eq, sh8);
+  const double A = tb.A, Bt = tb.Bt, Bf = tb.Bf;
   // squares outside the f32 range, NaN: no bound holds — the exact kernel answers (as before)
   if (!(qnorm < 1e18) || !(A == A)) {
     if (lane == 0) {
@@ -2582,20 +2674,9 @@ __global__ __launch_bounds__(256, MINB) void knn_shard_wave_kernel(
     }
     return;
   }
-  auto dh_up = [&](unsigned int vb) -> double {  // the estimate of a stored value, rounded up
-    return g * sqrt((double)__uint_as_float(vb) * (1.0 + rnd)) * (1.0 + 1e-15);
-  };
-  // keep-threshold in stored-value bits: a candidate may be dropped iff lower(Dh) > Ulim, i.e. iff
-  // Dh > (Ulim / (1 - Bf) + A) / (1 - Bt); everything at or below the returned bits is KEPT
-  auto keep_bits = [&](double Ulim) -> unsigned int {
-    const double dstar = (Ulim / (1.0 - Bf) + A) / (1.0 - Bt) * (1.0 + 1e-15);
-    const double t = (dstar / g) * (dstar / g) / (1.0 - rnd) * (1.0 + 1e-15);
-    if (!(t < 3.0e38)) return 0x7fc00000u;  // inf / NaN: keep everything that is a number
-    float tf = (float)t;
-    if ((double)tf < t) tf = __uint_as_float(__float_as_uint(tf) + 1u);  // round up (t >= 0)
-    return __float_as_uint(tf);
-  };
-  auto upper = [&](double dh) -> double { return (dh + A + Bt * dh) * (1.0 + Bf) * (1.0 + 1e-15); };
+  auto dh_up = [&](unsigned int vb) -> double { return tb.dh_up(vb); };
+  auto keep_bits = [&](double Ulim) -> unsigned int { return tb.keep_bits(Ulim); };
+  auto upper = [&](double dh) -> double { return tb.upper(dh); };
 
   constexpr int E = kWC / 64;
   int n_list = 0, pos_base = 0;
@@ -3677,7 +3758,13 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const int kcap8 = wave ? 48 : kBK;
   // (the width of the band at the cut grows with the square root of the row length: sqrt(d / 128)
   // times the margin that certifies C2's 128-element rows)
-  const int margin8 = (int)((k > 48 ? k : 48) * (data->d > 128 ? std::sqrt((double)data->d / 128.0) : 1.0));
+  // ... and with the number of candidates (the band holds a share of them: 48 certify C2's 3922 and a
+  // C4 forest's 3686 per query, not the 4915 of C4's 64 trees, where most queries took the in-kernel
+  // retry — a second pass over all candidates: 3.5 ms per 10 000 queries against 2.0 with 100 kept),
+  // and with what the forest's earlier batches reported (kp8_boost: retries counted by the kernel)
+  const double cand_scale = est_cand > 4000 ? (double)est_cand / 4000.0 : 1.0;
+  const int margin8 = (int)((k > 48 ? k : 48) * (data->d > 128 ? std::sqrt((double)data->d / 128.0) : 1.0) *
+                            cand_scale * f->kp8_boost);
   int kp8 = kp8_env > k && kp8_env < kcap8 ? kp8_env : k + margin8;
   if (kp8 > kcap8 - 1) kp8 = kcap8 - 1;
   const bool sh8 = !data->csr && data->shadow8 && !ctx->opt.knn_no_pre8 && !f->pre8_off &&
@@ -3964,6 +4051,7 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
   std::memcpy(tot, hctl, 16);
   ctx->last_candidates = (int64_t)tot[0];
   ctx->last_uncertified = (int64_t)tot[1];
+  ctx->last_retries = 0;
   if (novf && vote > 0)
     return fail(RPT_E_UNSUPPORTED,
                 "RPT_KNN_VOTE: a query reaches more than 16384 candidates or 512 leaves");
@@ -3977,6 +4065,11 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
     else f->prefilter_off = true;
   }
   ctx->last_tier = tier;
+  // a batch in which more than an eighth of the queries needed the wider second attempt: the next
+  // batches on this forest start wider (the int8 tier's kept entries; capped by the kernel's list)
+  ctx->last_retries = (int64_t)hctl[4];
+  if (tier == 3 && (unsigned long long)hctl[4] * 8 > (unsigned long long)nq && f->kp8_boost < 4.0)
+    f->kp8_boost *= 1.5;
   if (tot[1]) {  // queries with equal distances at the prefilter's cut: the all-f64 kernel, them only
     RPT_TRY(launch(true));
     RPT_HIP(stream_sync(ctx->stream));  // Pq / ovf are released on return
@@ -4006,7 +4099,14 @@ int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_da
   DevBuf<double> prio;
   RPT_TRY(prio.alloc((size_t)pl.total_rng));
   const int threads = T <= 64 ? 64 : (T <= 128 ? 128 : 256);
-  if (f->pdtype == RPT_F64)
+  if (f->xtopo) {  // streamed forest: the same walk over the stored topology (ranges in traverse_x's order)
+    if (f->pdtype == RPT_F64)
+      hipLaunchKernelGGL(ranges_hx_kernel<double>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p, f->mglo.p,
+                         f->mghi.p, f->nodes, f->xkind.p, (const double*)pl.Pq.p, nq, T, f->L, pl.rng_off.p, prio.p);
+    else
+      hipLaunchKernelGGL(ranges_hx_kernel<float>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p, f->mglo.p,
+                         f->mghi.p, f->nodes, f->xkind.p, (const float*)pl.Pq.p, nq, T, f->L, pl.rng_off.p, prio.p);
+  } else if (f->pdtype == RPT_F64)
     hipLaunchKernelGGL(ranges_h_kernel<double>, dim3((unsigned)nq), dim3(threads), 0, st, f->thr.p,
                        f->mglo.p, f->mghi.p, f->nodes, (const double*)pl.Pq.p, nq, T, f->L,
                        f->min_leaf, f->n, pl.rng_off.p, prio.p);
@@ -4035,7 +4135,9 @@ int32_t knn_h(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_da
     int64_t n = 0;
     for (int64_t r : order) {  // :209-217
       const int64_t ntot = hr[(size_t)r].n + n;
-      if (ntot > k && !taken.empty()) break;
+      // `not (null acc)` (:216) is about the POINTS taken so far: an empty bucket (streamed trees can
+      // hold one) does not count as "at least one"
+      if (ntot > k && n > 0) break;
       taken.push_back(r);
       n = ntot;
     }

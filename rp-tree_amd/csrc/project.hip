@@ -598,7 +598,7 @@ __global__ void pad_A_kernel(const double* __restrict__ R, int C, int d, int D, 
   }
 }
 
-template <class TIn, class TC, int D, int CBT, bool CODES = false, bool NT = false>
+template <class TIn, class TC, int D, int CBT, bool CODES = false>
 __device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_t n,
                                                const TC* __restrict__ Apad, int c0,
                                                int ncol, TC* __restrict__ P,
@@ -655,16 +655,9 @@ __device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_
       const int p = i * 64 + lane;
       int64_t row = row0 + p / PIECES_PER_ROW;
       row = row < last_row ? row : last_row;
-      if ((p % PIECES_PER_ROW) * PIECE < kvalid) {
-        if constexpr (NT) {  // experiment: streaming loads of X (read once per launch)
-          typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-          const u4 raw = __builtin_nontemporal_load(
-              reinterpret_cast<const u4*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE));
-          __builtin_memcpy(&stage[i], &raw, 16);
-        } else {
-          stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
-        }
-      } else
+      if ((p % PIECES_PER_ROW) * PIECE < kvalid)
+        stage[i] = *reinterpret_cast<const Raw*>(X + row * ldx + (p % PIECES_PER_ROW) * PIECE);
+      else
         stage[i] = Raw{};  // past the end of a short row: kvalid is a multiple of PIECE
     }
   };
@@ -704,7 +697,7 @@ __device__ __forceinline__ void proj_fast_body(const TIn* __restrict__ X, int64_
   }
 }
 
-template <class TIn, class TC, int D, int CBT, bool CODES = false, bool NT = false>
+template <class TIn, class TC, int D, int CBT, bool CODES = false>
 __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__ X, int64_t n,
                                                          const TC* __restrict__ Apad, int c0, int ncol,
                                                          TC* __restrict__ P, int64_t ldp, int64_t ntiles,
@@ -712,8 +705,8 @@ __global__ __launch_bounds__(256, 2) void proj_mfma_fast(const TIn* __restrict__
                                                          uint16_t* __restrict__ Cd, int64_t ldc,
                                                          const unsigned long long* __restrict__ cmm,
                                                          int cL, int cLc) {
-  proj_fast_body<TIn, TC, D, CBT, CODES, NT>(X, n, Apad, c0, ncol, P, ldp, ntiles, ldx, accumulate, kvalid, Cd,
-                                             ldc, cmm, cL, cLc);
+  proj_fast_body<TIn, TC, D, CBT, CODES>(X, n, Apad, c0, ncol, P, ldp, ntiles, ldx, accumulate, kvalid, Cd,
+                                         ldc, cmm, cL, cLc);
 }
 
 // Few rows, many hyperplanes (a query batch against every (tree, level) of a forest): ALL column
@@ -1556,12 +1549,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
                      cop ? cop->ld : (int64_t)0, cop ? cop->mm : (const unsigned long long*)nullptr, \
                      cop ? cop->L : 1, cop ? cop->Lc : 0)
           if (ps.ncol > 16) {
-            if (ctx->opt.tune2 == 1 && !cop)  // experiment: nontemporal X loads
-              hipLaunchKernelGGL((proj_mfma_fast<TIn, TC, D, 2, false, true>), dim3((unsigned)blocks), dim3(256), 0,
-                                 ctx->stream, (const TIn*)ds->X + k0, n, Ab, ps.c0, ps.ncol, P, n, ntiles,
-                                 (int64_t)ds->d, accumulate, kvalid, (uint16_t*)nullptr, (int64_t)0,
-                                 (const unsigned long long*)nullptr, 1, 0);
-            else if (cop) RPT_FAST(2, true);
+            if (cop) RPT_FAST(2, true);
             else RPT_FAST(2, false);
           } else {
             if (cop) RPT_FAST(1, true);

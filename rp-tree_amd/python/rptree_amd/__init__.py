@@ -530,13 +530,12 @@ def forest(seed, maxd, minl, ntrees, chunksize, pnz, dim, src, *, ctx=None, mode
     split at its OWN median and averaged into the threshold, a part that meets a Tip is put in
     front of its points, an empty part that meets a Bin drops the subtree (the reference's
     data-loss quirk, kept; `dropped` counts it).  Hyperplanes are sampled exactly like
-    forestBatch's (same draw order, Conduit.hs:116-118).  Dense data.  With chunksize >= the
+    forestBatch's (same draw order, Conduit.hs:116-118).  Dense rows or SVector rows (a (rowptr, col,
+    val, dim) tuple: `forest` is polymorphic in `Inner SVector v`, Conduit.hs:104-113).  With chunksize >= the
     number of points the result is forestBatch's forest (as a streamed-forest handle)."""
     ctx = ctx or default_context()
-    xs = src if isinstance(src, (np.ndarray, Dataset)) else list(src)
+    xs = src if isinstance(src, (np.ndarray, Dataset, tuple)) else list(src)    # (tuple: CSR arrays + dim)
     ds = Dataset.of(ctx, xs)
-    if ds.is_csr:
-        raise NotImplementedError("the streaming build takes dense rows")
     if hyperplanes is None:
         _, R = gen.forest_hyperplanes(seed, ntrees, maxd, pnz, dim)
     else:

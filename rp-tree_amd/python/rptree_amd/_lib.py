@@ -66,6 +66,7 @@ SYMBOLS = {
     "rpt_knn_last_tier": (i32, [vp, p_i32]),
     "rpt_build_last_handed_back": (i32, [vp, p_i64, p_i64]),
     "rpt_knn_last_uncertified": (i32, [vp, p_i64]),
+    "rpt_knn_last_retries": (i32, [vp, p_i64]),
     "rpt_knn_merge_dev": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp]),
     "rpt_knn_record_layout": (i32, [i64, i32, vp, vp, vp, vp]),
     "rpt_knn_merge_records_dev": (i32, [vp, vp, i64, i32, i64, i32, i32, vp, vp, vp]),

@@ -862,8 +862,53 @@ def test_queries_on_a_streamed_forest(rp, ctx, oracle):
             wi, wd = oracle.stream_knn_dense(so, R, X, Q[i], k, dedup=int(dedup))
             assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
             assert np.array_equal(dist[i, :cnt[i]], wd)
-    with pytest.raises(rp.RPTError, match="streamed"):
-        rp.knnHBatch(k, f, Q[:2])
+    # knnH walks any RPT too (RPTree.hs:199-217 over candidatesH :318-342): whole buckets in increasing
+    # margin priority, the bucket taken last first, unsorted, not cut to k
+    for kk in (1, k, 60, 400):
+        hoff, hids, hdist = rp.knnHBatch(kk, f, Q[:16])
+        for i in range(16):
+            wi, wd = oracle.stream_knn_h_dense(so, R, X, Q[i], kk)
+            assert np.array_equal(hids[hoff[i]:hoff[i + 1]], wi), (kk, i)
+            assert np.array_equal(hdist[hoff[i]:hoff[i + 1]], wd)
+
+
+@pytest.mark.parametrize("chunk", [100, 37, 3000])
+def test_streaming_forest_of_svector_rows(rp, ctx, oracle, chunk):
+    """`forest` is polymorphic in `Inner SVector v` (Conduit.hs:104-113): SVector rows go through the
+    same fold of `insert` over chunks with innerSS as the inner product (Internal.hs:351-366).  Device
+    == the oracle's fold bit for bit (kinds, offsets, Tip contents, thresholds, margins) when the chunk
+    divides n, when it does not (data-loss branch) and for one chunk; candidates / kNN on the result
+    == the oracle's walk wherever the distances separate."""
+    n, d, T, ml, k = 3000, 24, 3, 20, 6
+    rowptr, col, val = oracle.data_normal_sparse2(15, n, d, 0.3)
+    L, _, pnz = oracle.tree_cfg(ml, n, d)
+    R, _ = oracle.forest_hyperplanes(5, T, L, pnz, d)
+    so = oracle.stream_forest_csr(rowptr, col, val, d, R, ml, chunk)
+    f = rp.forest(0, L, ml, T, chunk, pnz, d, (rowptr, col, val, d), ctx=ctx, hyperplanes=R)
+    assert_stream_equal(f, so, T)
+    if chunk >= n:
+        fb = rp.forestBatch(0, L, ml, T, pnz, d, (rowptr, col, val, d), ctx=ctx, hyperplanes=R)
+        for t in range(T):
+            assert np.array_equal(np.concatenate(rp.leaves(f[t])), fb.perm[t])
+    elif n % chunk == 0:
+        assert f.held == n
+    else:
+        assert f.held < n                            # the reference's data-loss quirk on SVector rows too
+    # queries: SVector queries against the oracle's walk with the query dense-ified (a zero of the query
+    # contributes an exact zero to innerSD's sum: the same projections, the same decisions)
+    qr, qc, qv = oracle.data_normal_sparse2(16, 8, d, 0.3)
+    Qd = np.zeros((8, d))
+    for i in range(8):
+        Qd[i, qc[qr[i]:qr[i + 1]]] = qv[qr[i]:qr[i + 1]]
+    off, cids = rp.candidatesBatch(f, (qr, qc, qv, d))
+    ids, dist, cnt = rp.knnBatch(k, f, (qr, qc, qv, d))
+    for i in range(8):
+        for t in range(T):
+            want = oracle.stream_candidates_dense(so, R, Qd[i], t)
+            assert np.array_equal(cids[off[i * T + t]:off[i * T + t + 1]], want), (i, t)
+        cand = cids[off[i * T]:off[(i + 1) * T]]
+        assert cnt[i] == min(k, len(cand)) and set(ids[i, :cnt[i]].tolist()) <= set(cand.tolist())
+        assert (np.diff(dist[i, :cnt[i]]) >= 0).all()
 
 
 # ------------------------------------------------------------------ fallback paths

@@ -41,10 +41,11 @@ def run(f, reps=10):
         if it >= 2:
             best = min(best, t)
             tot += t
-    unc, tier = C.c_int64(), C.c_int32()
+    unc, tier, ret = C.c_int64(), C.c_int32(), C.c_int64()
+    _lib.check(L_.rpt_knn_last_retries(ctx._h, C.byref(ret)))
     _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
     _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
-    return best * 1e3, tot / reps * 1e3, unc.value, tier.value, (ids.cpu().numpy().copy(), dist.cpu().numpy().copy(), cnt.cpu().numpy().copy())
+    return best * 1e3, tot / reps * 1e3, (unc.value, ret.value), tier.value, (ids.cpu().numpy().copy(), dist.cpu().numpy().copy(), cnt.cpu().numpy().copy())
 
 
 for T in trees:
@@ -69,6 +70,6 @@ for T in trees:
         if ref is None:
             ref = got
         same = all(np.array_equal(a, b) for a, b in zip(got, ref))
-        print("%s T=%2d nq=%d %-24s best %.3f mean %.3f ms  tier %d  uncertified %4d  identical: %s" % (
+        print("%s T=%2d nq=%d %-24s best %.3f mean %.3f ms  tier %d  uncertified / retried %s  identical: %s" % (
             dt, T, nq, name, best, mean, tier, unc, same), flush=True)
     f.close()
