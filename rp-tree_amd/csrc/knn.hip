@@ -730,10 +730,24 @@ __device__ __forceinline__ void batch_distances(const TD* __restrict__ X, int d,
     constexpr int V = 16 / (int)sizeof(TD);
     if ((d % V) == 0) {
       struct alignas(16) Raw { TD v[V]; };
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       for (int j = lane * V; j < d; j += 64 * V) {
+        // All eight row loads are issued before the first is used.  That has to be SAID: at the
+        // register cap of several instantiations (168 VGPRs at three workgroups per CU) the scheduler
+        // turned this loop into load / wait / load / wait — one or two rows in flight instead of eight
+        // — which is the whole of round 3's "66 -> 119 ms" cliff of the bf16 kernel under the
+        // consecutive-slot fill (the fill cost 3 registers, the gathers lost their memory
+        // parallelism) and had silently hit the f32 / half-tier kernels on rows beyond 512 bytes.
+        // The group barrier keeps the eight VMEM reads one scheduling group ahead of the arithmetic;
+        // the waits stay progressive (vmcnt 7, 6, ... as the rows are consumed).
+        u32x4 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const u32x4*>(rows[u] + j);
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);          // eight VMEM reads ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 8 * V * 3, 0);  // ... then the VALU work on them
         Raw x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const Raw*>(rows[u] + j);
+        for (int u = 0; u < 8; ++u) __builtin_memcpy(&x[u], &raw[u], 16);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -1285,6 +1299,10 @@ constexpr int kFKx = kFK + kLfMargin;  // capacity of the running best list (see
 // the same whatever it keeps, and the int8 tier needs a wide margin at the cut (see Sh8)
 constexpr int kBK = 224;
 constexpr int kBKx = kBK + kLfMargin;
+#ifndef RPT_CONSEC_FILL
+#define RPT_CONSEC_FILL 0
+#endif
+constexpr bool kConsecFill = RPT_CONSEC_FILL != 0;  // consecutive-slot fill in the non-WIDE instantiations too
 constexpr int kSelList = 512;  // select_packed's candidate list (in the idle distance slab)
 constexpr int kVoteCap = 16384;  // candidates of one query the voting mode can count (64 KB of LDS)
 
@@ -1784,7 +1802,8 @@ retry_wider:
       // leaf range holds ~100 candidates: a boundary or two per thread) — sixteen independent
       // nine-step searches per thread were 13 % of a C2 query's life
       int64_t addr[EF];
-      if constexpr (!WIDE) {
+      constexpr bool CONSEC = WIDE || kConsecFill;
+      if constexpr (!CONSEC) {
 #pragma unroll
         for (int e = 0; e < EF; ++e) {
           const int s2 = tid + 256 * e;
@@ -1824,10 +1843,10 @@ retry_wider:
       }
       int32_t idv[EF];
 #pragma unroll
-      for (int e = 0; e < EF; ++e) idv[e] = (WIDE ? tid * EF + e : tid + 256 * e) < take ? perm[addr[e]] : 0;
+      for (int e = 0; e < EF; ++e) idv[e] = (CONSEC ? tid * EF + e : tid + 256 * e) < take ? perm[addr[e]] : 0;
 #pragma unroll
       for (int e = 0; e < EF; ++e) {
-        const int s2 = WIDE ? tid * EF + e : tid + 256 * e;
+        const int s2 = CONSEC ? tid * EF + e : tid + 256 * e;
         if (s2 < take) {
           cid[fill + s2] = idv[e];
           if constexpr (!WIDE) cpos[fill + s2] = pos_base + s2;
