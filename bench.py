@@ -47,7 +47,8 @@ MFMA_F64_PEAK_TF = 78.6
 MFMA_F64_STREAM_TF = 46.2
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix = FP32 vector rate
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (no sparsity)
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
+             "r01_pmc_traffic.json")   # newest first
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1106,7 +1107,7 @@ def main():
         topk_ms = prof["knn_topk"][0] / max(args.steps, 1)
         knn_bytes = nq * (cand_q * d * sb + kp * d * 8) if pre32 else nq * cand_q * d * 8
         if tier != 3:
-            knn_traffic = None                          # the committed PMC passes (r03) are the int8 tier's
+            knn_traffic = None                          # the committed PMC passes (r03, r04) are the int8 tier's
         knn_ach = knn_bytes / (topk_ms * 1e-3) / 1e9 if topk_ms > 0 else 0.0
         roof_knn = {"bound": "hbm", "achieved": knn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": knn_ach / HBM_PEAK_GBS, "traffic": knn_traffic,

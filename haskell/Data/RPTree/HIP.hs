@@ -6,7 +6,8 @@
 -- It shows the binding a maintainer would add next to src/Data/RPTree/Batch.hs; the tested
 -- mirrors of exactly this call sequence are rp-tree_amd/python/rptree_amd/__init__.py and
 -- rp-tree_amd/host/rptree.hpp.
-module Data.RPTree.HIP (forestBatchHIP, forestHIP, withDeviceForest, knnHIP, FlatForest(..), DeviceForest(..)) where
+module Data.RPTree.HIP (forestBatchHIP, forestBatchHIPWith, forestHIP, withDeviceData, withDeviceForest,
+                        withDeviceForestOn, knnHIP, ProjMode(..), FlatForest(..), DeviceForest(..), DeviceData(..)) where
 
 import Control.Exception (Exception, bracket, throwIO)
 import Control.Monad (when)
@@ -55,6 +56,17 @@ foreign import ccall safe "rpt_forest_build_sharded" c_build_sharded  :: Ptr Com
 foreign import ccall safe "rpt_sharded_forest_free"  c_sharded_free   :: Ptr ShardedForest -> IO Int32
 foreign import ccall safe "rpt_knn_sharded"          c_knn_sharded    :: Ptr Comm -> Ptr ShardedForest -> Ptr (Ptr Dataset) -> Ptr (Ptr Dataset) -> Int32 -> Int32 -> Ptr Int32 -> Ptr Double -> Ptr Int32 -> IO Int32
 
+-- | Projection kernel of a build (include/rptree_hip.h RPT_PROJ_*).  'ProjAuto' on Double data is the
+-- exact-order kernel (separate multiply and add in innerSD's order, Internal.hs:369-382: leaf
+-- assignments identical to the pure library's); 'ProjMfma' is the matrix-core kernel bench.py times
+-- (projection values within 1e-5 |x||r|, a handful of leaf flips per million points at most).
+data ProjMode = ProjAuto | ProjExact | ProjMfma deriving (Eq, Show)
+
+projFlag :: ProjMode -> Int32
+projFlag ProjAuto = 0
+projFlag ProjExact = 1
+projFlag ProjMfma = 2
+
 newtype RPTHipError = RPTHipError String deriving Show
 instance Exception RPTHipError          -- next to RPTError (Internal.hs:66-72)
 
@@ -77,7 +89,15 @@ denseOf dim (SV _ vv) = VS.replicate dim 0 VS.// VU.toList vv
 forestBatchHIP :: Word64 -> Int -> Int -> Int -> Double -> Int
                -> V.Vector (Embed DVector Double x)
                -> RPForest Double (V.Vector (Embed DVector Double x))
-forestBatchHIP seed maxd minl ntrees pnz dim src = unsafePerformIO $ do
+forestBatchHIP = forestBatchHIPWith ProjAuto
+
+-- | ... with the projection kernel chosen by the caller ('ProjMfma' = the timed one).  One context and
+-- one upload per call: a host that builds several forests over the same points, or queries the
+-- forest afterwards, uses 'withDeviceData' / 'withDeviceForestOn' instead and pays the upload once.
+forestBatchHIPWith :: ProjMode -> Word64 -> Int -> Int -> Int -> Double -> Int
+                   -> V.Vector (Embed DVector Double x)
+                   -> RPForest Double (V.Vector (Embed DVector Double x))
+forestBatchHIPWith mode seed maxd minl ntrees pnz dim src = unsafePerformIO $ do
   -- hyperplanes: sampled by the HOST exactly as Batch.hs:59-61 does
   let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))
       rflat = VS.concat [ denseOf dim r | rvs <- V.toList rvss, r <- V.toList rvs ]     -- R[T][L][d]
@@ -88,7 +108,7 @@ forestBatchHIP seed maxd minl ntrees pnz dim src = unsafePerformIO $ do
   ff <- bracket (acquire (c_ctx_create 0)) c_ctx_destroy $ \ctx ->
         bracket (acquire (\pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral n) (fromIntegral dim) 0 pp)))
                 c_dataset_free $ \ds ->
-        bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) 0 pp)))
+        bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) (projFlag mode) pp)))
                 c_forest_free $ \f -> do
           perm <- VSM.new (ntrees * n); thr <- VSM.new (ntrees * nodes); lo <- VSM.new (ntrees * nodes); hi <- VSM.new (ntrees * nodes)
           VSM.unsafeWith perm (c_forest_perm f) >>= check
@@ -156,18 +176,32 @@ forestHIP seed maxd minl ntrees chunk pnz dim src = unsafePerformIO $ do
 -- callback; queries go through 'knnHIP' without re-uploading anything.
 data DeviceForest = DeviceForest { dfCtx :: Ptr Ctx, dfData :: Ptr Dataset, dfForest :: Ptr Forest }
 
-withDeviceForest :: Word64 -> Int -> Int -> Int -> Double -> Int -> V.Vector (Embed DVector Double x)
-                 -> (DeviceForest -> IO a) -> IO a
-withDeviceForest seed maxd minl ntrees pnz dim src act = do
-  let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))
-      rflat = VS.concat [ denseOf dim r | rvs <- V.toList rvss, r <- V.toList rvs ]
-      xflat = VS.concat [ VS.convert v | Embed (DV v) _ <- V.toList src ]
+-- | A context and the packed point set on the device, for the extent of the callback: the upload
+-- (1 GB at C2: 18 ms over PCIe against a 5 ms build) is paid once however many forests are built.
+data DeviceData = DeviceData { ddCtx :: Ptr Ctx, ddData :: Ptr Dataset, ddDim :: Int }
+
+withDeviceData :: Int -> V.Vector (Embed DVector Double x) -> (DeviceData -> IO a) -> IO a
+withDeviceData dim src act = do
+  let xflat = VS.concat [ VS.convert v | Embed (DV v) _ <- V.toList src ]
       acquire mk = alloca $ \pp -> mk pp >>= check >> peek pp
   bracket (acquire (c_ctx_create 0)) c_ctx_destroy $ \ctx ->
     bracket (acquire (\pp -> VS.unsafeWith xflat (\px -> c_dataset_dense ctx px (fromIntegral (V.length src)) (fromIntegral dim) 0 pp)))
-            c_dataset_free $ \ds ->
-    bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) 0 pp)))
-            c_forest_free $ \f -> act (DeviceForest ctx ds f)
+            c_dataset_free $ \ds -> act (DeviceData ctx ds dim)
+
+-- | One forest over device-resident points (any number of these per 'withDeviceData').
+withDeviceForestOn :: DeviceData -> ProjMode -> Word64 -> Int -> Int -> Int -> Double
+                   -> (DeviceForest -> IO a) -> IO a
+withDeviceForestOn (DeviceData ctx ds dim) mode seed maxd minl ntrees pnz act = do
+  let rvss = sample seed $ V.replicateM ntrees (V.replicateM maxd (sparse pnz dim stdNormal))
+      rflat = VS.concat [ denseOf dim r | rvs <- V.toList rvss, r <- V.toList rvs ]
+      acquire mk = alloca $ \pp -> mk pp >>= check >> peek pp
+  bracket (acquire (\pp -> VS.unsafeWith rflat (\pr -> c_forest_build ctx ds pr (fromIntegral ntrees) (fromIntegral maxd) (fromIntegral minl) (projFlag mode) pp)))
+          c_forest_free $ \f -> act (DeviceForest ctx ds f)
+
+withDeviceForest :: Word64 -> Int -> Int -> Int -> Double -> Int -> V.Vector (Embed DVector Double x)
+                 -> (DeviceForest -> IO a) -> IO a
+withDeviceForest seed maxd minl ntrees pnz dim src act =
+  withDeviceData dim src $ \dd -> withDeviceForestOn dd ProjAuto seed maxd minl ntrees pnz act
 
 -- | 'knn metricL2 k' (RPTree.hs:168-176) for a batch of dense queries: ids and distances.
 knnHIP :: Ptr Ctx -> Ptr Forest -> Ptr Dataset -> Ptr Dataset -> Int -> Int -> IO (VS.Vector Int32, VS.Vector Double, VS.Vector Int32)
