@@ -438,7 +438,8 @@ def shard_sweep(which, steps):
     ctx = comm.contexts[0]
     dev = torch.device("cuda", ctx.device)
     out = {"note": "one GPU, tree shards of the whole point set (what 1 of G GPUs holds); kNN through "
-                   "rpt_knn_sharded_dev with comm_force_exchange = 1 (one-rank ncclAllGather + merge); "
+                   "rpt_knn_sharded_dev with comm_force_exchange = 1 (one-rank ncclAllGather + merge); every "
+                   "figure is the best of the timed calls (the mean is next to it: *_mean); "
                    "projected_speedup_8gpu = whole forest on one GPU / the T/8 shard, a projection",
            "steps": steps}
 
@@ -454,13 +455,16 @@ def shard_sweep(which, steps):
             try:
                 sharded.ShardedForest(comm, [ds], R[:T], maxd, min_leaf, mode).close()      # warm
                 comm.sync()
-                t0 = time.perf_counter()
-                for _ in range(steps):
+                tb = []
+                for _ in range(steps):                 # timed one by one: a 40 GB forest's first
+                    t0 = time.perf_counter()           # allocations can stall a build by 100 ms
                     sf = sharded.ShardedForest(comm, [ds], R[:T], maxd, min_leaf, mode)
+                    comm.sync()
+                    tb.append((time.perf_counter() - t0) * 1e3)
                     if _ < steps - 1:
                         sf.close()
-                comm.sync()
-                row["build_ms"] = (time.perf_counter() - t0) / steps * 1e3
+                row["build_ms"] = min(tb)
+                row["build_ms_mean"] = sum(tb) / len(tb)
                 for nq, Qd in Qs:
                     qs = rp.Dataset.from_torch(ctx, Qd)
                     oi = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -472,12 +476,15 @@ def shard_sweep(which, steps):
                         for _ in range(2):
                             sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
                             comm.sync()
-                        t0 = time.perf_counter()
+                        tq = []
                         for _ in range(max(steps, 5)):
+                            t0 = time.perf_counter()
                             sf.knn_dev([qs], k, 0, [oi.data_ptr()], [od.data_ptr()], [oc.data_ptr()])
                             comm.sync()
-                        row["knn_ms_nq%d%s" % (nq, "_forced_exchange" if force else "")] = \
-                            (time.perf_counter() - t0) / max(steps, 5) * 1e3
+                            tq.append((time.perf_counter() - t0) * 1e3)
+                        key = "knn_ms_nq%d%s" % (nq, "_forced_exchange" if force else "")
+                        row[key] = min(tq)
+                        row[key + "_mean"] = sum(tq) / len(tq)
                     ctx.set_option("comm_force_exchange", 0)
                     tier = C.c_int32()
                     _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))

@@ -2070,7 +2070,7 @@ constexpr int kWT = 64;   // trees (lane = tree)
 // answers an 8-tree shard of C2 (8 x 122 candidates) in 0.67 ms, this one in 0.96; the 8 x 76 of a
 // C4 shard stay here: 3.2 against 5.9 ms per 100 000 queries)
 constexpr int64_t kWaveCandidates = 700;
-constexpr int64_t kShardCandidates = 1100;  // ... and the round-4 shard kernels (see launch_fused)
+constexpr int64_t kShardCandidates = 2100;  // ... and the round-4 shard kernels (see launch_fused)
 
 __device__ inline void wave_sync() {  // LDS writes of the wave visible to all its lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -3721,7 +3721,9 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
   const int64_t est_cand = (int64_t)f->T * (leaf > 0 ? leaf : 1);
   bool wave = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 && est_cand <= kWaveCandidates;
   // the round-4 shard kernels (traversal as its own launch, adaptive certified set) stay ahead of the
-  // workgroup kernel for longer: an 8-tree C2 shard (980 candidates) 0.42 against 0.65 ms per 10 000 queries
+  // workgroup kernel for longer: an 8-tree C2 shard (980 candidates) 0.42 against 0.65 ms per 10 000
+  // queries, 16 trees (1950) 0.73 against 0.86 (5.7 against 7.9 ms per 100 000); at 32 trees the
+  // workgroup kernel is level or ahead
   bool wave_shard = f->T >= 1 && f->T <= kWT && wbytes <= 16 * 1024 && est_cand <= kShardCandidates;
   if (force >= 0) wave = wave_shard = force == 1 && f->T >= 1 && f->T <= kWT && wbytes <= 40 * 1024;
   if (vote > 0 || data->csr) wave = wave_shard = false;

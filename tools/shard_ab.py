@@ -58,7 +58,7 @@ for T in trees:
                        ("shard kernels", {"knn_wave": 1}),
                        ("shard, half tier", {"knn_wave": 1, "knn_no_pre8": 1}),
                        ("shard, f32 tier", {"knn_wave": 1, "knn_no_pre16": 1})]:
-        if T > 8 and "shard" in name:
+        if T > 32 and "shard" in name:
             continue
         if dt == "f32" and "f32 tier" in name:
             continue
