@@ -238,6 +238,39 @@ def other_configs(which, steps, with_cpu):
                                          "nq x (candidates x %d slots x 4 B + %d x mean row nonzeros x 12 B)"
                                          % (ell_w, kp) if tier.value == 2
                                          else "nq x candidates x mean row nonzeros x 12 B")}
+            # side leg: the tolerance mode (RPT_PROJ_MFMA on SVector rows = dense-ified bf16 x 2 rows on
+            # the matrix pipe, values within 1e-5 |x||r|; the timed C3 mode above stays the exact one)
+            try:
+                rp._build(ctx, ds, R, maxd, min_leaf, rp.RPT_PROJ_MFMA).close()
+                _lib.check(L_.rpt_prof_reset(ctx._h))
+                _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+                ctx.sync()
+                t0 = time.perf_counter()
+                fm = None
+                for _ in range(steps):
+                    if fm is not None:
+                        fm.close()
+                    fm = rp._build(ctx, ds, R, maxd, min_leaf, rp.RPT_PROJ_MFMA)
+                ctx.sync()
+                tm = (time.perf_counter() - t0) / steps * 1e3
+                pm = _prof_read(L_, _lib, C, ctx)
+                _lib.check(L_.rpt_prof_enable(ctx._h, 0))
+                topo = f.topology()
+                leaf_off = np.array([o for (_, _, o, nn, lf) in topo if lf], dtype=np.int64)
+                pe, pmm = f.perm[0], fm.perm[0]
+                ie = np.empty(n, dtype=np.int64); ie[pe] = np.arange(n)
+                im = np.empty(n, dtype=np.int64); im[pmm] = np.arange(n)
+                flips = float((np.searchsorted(leaf_off, ie, side="right") !=
+                               np.searchsorted(leaf_off, im, side="right")).mean())
+                fm.close()
+                res["tolerance_mode"] = {
+                    "mode": "RPT_PROJ_MFMA on CSR rows: rows dense-ified as two bf16 terms, hyperplanes as "
+                            "three, v_mfma_f32_16x16x32_bf16, f32 accumulation (1e-5 |x||r|)",
+                    "build_ms": tm, "projection_ms": pm["project"][0] / steps, "split_ms": pm["split"][0] / steps,
+                    "projection_launches_per_build": pm["project"][1] / steps,
+                    "leaf_flip_rate_vs_exact_tree0": flips}
+            except Exception as e:      # noqa: BLE001
+                res["tolerance_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if with_cpu:
                 from oracle import oracle as orc
                 hr, hc, hv = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()

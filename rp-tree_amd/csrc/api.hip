@@ -227,6 +227,7 @@ const OptDesc kOptions[] = {
     {"no_pcodes", &rpt_options::no_pcodes},
     {"proj_narrow", &rpt_options::proj_narrow},
     {"proj_bf16_f32", &rpt_options::proj_bf16_f32},
+    {"proj_csr_nodense", &rpt_options::proj_csr_nodense},
     {"knn_wave", &rpt_options::knn_wave},
     {"knn_kp", &rpt_options::knn_kp},
     {"knn_no_pre32", &rpt_options::knn_no_pre32},
@@ -634,6 +635,7 @@ int32_t rpt_dataset_free(rpt_dataset* ds) {
     if (ds->shadow_col16) dev_free(ds->shadow_col16);
     if (ds->shadow_ell) dev_free(ds->shadow_ell);
     if (ds->csr_split) dev_free(ds->csr_split);
+    if (ds->csr_dense) dev_free(ds->csr_dense);
     if (ds->owns) {
       (void)hipSetDevice(ds->ctx->device);
       (void)stream_sync(ds->ctx->stream);

@@ -151,6 +151,8 @@ struct rpt_options {
   int64_t no_pcodes = 0;        // split: no codes for projection kernels without a code epilogue
   int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only
   int64_t proj_bf16_f32 = 0;    // projection: bf16 rows through the f32-MFMA kernels
+  int64_t proj_csr_nodense = 0; // projection: RPT_PROJ_MFMA on CSR rows stays on the segmented CSR kernel (one FMA per
+                                // term) instead of the dense-ified bf16 matrix-pipe formulation
   int64_t knn_wave = -1;        // kNN: -1 auto, 0 workgroup-per-query, 1 wave-per-query kernel
   int64_t knn_kp = 0;           // kNN: entries the f32 prefilter keeps (0 = k + max(6, k/2))
   int64_t knn_no_pre32 = 0;     // kNN: no f32 prefilter (all-f64 distances)
@@ -271,6 +273,12 @@ struct rpt_dataset {
   // whole: index of every row's first nonzero with column >= csr_split_k (project.hip)
   mutable int64_t* csr_split = nullptr;
   mutable int csr_split_k = -1;
+  // round 4, tolerance-mode projection of SVector rows on the matrix pipe (project.hip
+  // launch_csr_dense_mfma): the rows dense-ified as TWO bf16 terms x = x_hi + x_lo (16 significant
+  // bits), [2][n][d] bf16, built by the first RPT_PROJ_MFMA projection of a CSR dataset with
+  // d % 8 == 0 that fits; csr_dense_state: 0 untried, 1 built, -1 unavailable
+  mutable uint16_t* csr_dense = nullptr;
+  mutable int csr_dense_state = 0;
 };
 
 struct rpt_forest {

@@ -921,10 +921,11 @@ __global__ void split_A_bf16x3(const double* __restrict__ R, int d, int c0, int 
 }
 
 template <int CBT, int NT /* 16-point tiles per wave */, bool RESIDENT /* d <= 128: both chunks stay in LDS */,
-          int WAVES /* per workgroup */>
+          int WAVES /* per workgroup */, class TP = float /* type of P */,
+          int NTERM = 1 /* bf16 terms of a row: X[term][n][d]; 2 = dense-ified SVector rows (launch_csr_dense_mfma) */>
 __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
     const __hip_bfloat16* __restrict__ X, int64_t n, int d, const uint4* __restrict__ Aimg,
-    int nch /* even */, int c0, int ncol, float* __restrict__ P, int64_t ldp, int64_t ntiles) {
+    int nch /* even */, int c0, int ncol, TP* __restrict__ P, int64_t ldp, int64_t ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds_a[];  // [2][CH16]
   constexpr int CH16 = kB3KC * 3 * CBT * 64;  // uint4 per chunk
   constexpr int kB3NT = NT, kB3Pts = WAVES * NT * 16, NTHR = WAVES * 64;  // points per workgroup tile
@@ -940,20 +941,22 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
   __syncthreads();
 
   // B fragment of k-step ks of tile t for n-tile nt: zero past d; rows past n clamped
-  auto load_b = [&](int64_t t, int ks, int nt) -> uint4 {
+  auto load_b = [&](int64_t t, int ks, int nt, int term) -> uint4 {
     const int k = ks * 32 + kg;
     if (t >= ntiles || k >= d) return make_uint4(0, 0, 0, 0);
     int64_t row = t * kB3Pts + wave * (kB3NT * 16) + nt * 16 + (lane & 15);
     row = row < n ? row : n - 1;
-    return *reinterpret_cast<const uint4*>(X + row * (int64_t)d + k);
+    return *reinterpret_cast<const uint4*>(X + ((int64_t)term * n + row) * (int64_t)d + k);
   };
 
   int64_t tile = blockIdx.x;
-  uint4 bf[4][kB3NT];  // ring: k-step s lives in bf[s & 3]
+  uint4 bf[4][NTERM][kB3NT];  // ring: k-step s lives in bf[s & 3]
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int nt = 0; nt < kB3NT; ++nt) bf[u][nt] = load_b(tile, u, nt);
+    for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+      for (int nt = 0; nt < kB3NT; ++nt) bf[u][tm][nt] = load_b(tile, u, nt, tm);
 
   for (; tile < ntiles; tile += gridDim.x) {
     f32x4 acc[CBT][kB3NT];
@@ -975,25 +978,32 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
 #pragma unroll
         for (int ks = 0; ks < kB3KC; ++ks) {
           const int u = h * 2 + ks;
-          bf16x8 b[kB3NT];
+          bf16x8 b[NTERM][kB3NT];
 #pragma unroll
-          for (int nt = 0; nt < kB3NT; ++nt) b[nt] = __builtin_bit_cast(bf16x8, bf[u][nt]);
+          for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+            for (int nt = 0; nt < kB3NT; ++nt) b[tm][nt] = __builtin_bit_cast(bf16x8, bf[u][tm][nt]);
           // refill the ring slot four k-steps ahead (the next tile's first k-steps at the end)
           {
             const int sn = c * kB3KC + ks + 4;
             const int64_t tn = sn >= nks ? tile + gridDim.x : tile;
             const int kn = sn >= nks ? sn - nks : sn;
 #pragma unroll
-            for (int nt = 0; nt < kB3NT; ++nt) bf[u][nt] = load_b(tn, kn, nt);
+            for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+              for (int nt = 0; nt < kB3NT; ++nt) bf[u][tm][nt] = load_b(tn, kn, nt, tm);
           }
 #pragma unroll 1  // (unrolled, the 24 fragment reads of a k-step are hoisted together and spill)
           for (int p3 = 0; p3 < 3; ++p3)
 #pragma unroll
             for (int mt = 0; mt < CBT; ++mt) {
               const bf16x8 a = __builtin_bit_cast(bf16x8, ab[((ks * 3 + p3) * CBT + mt) * 64 + lane]);
+              // (two row terms: one fragment read feeds 2 NT MFMAs — the LDS reads per MFMA halve)
 #pragma unroll
-              for (int nt = 0; nt < kB3NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mt][nt], 0, 0, 0);
+              for (int tm = 0; tm < NTERM; ++tm)
+#pragma unroll
+                for (int nt = 0; nt < kB3NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[tm][nt], acc[mt][nt], 0, 0, 0);
             }
         }
         if constexpr (!resident) {
@@ -1013,7 +1023,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int col = mt * 16 + 4 * (lane >> 4) + r;
-            if (col < ncol) P[(int64_t)(c0 + col) * ldp + pt] = acc[mt][nt][r];
+            if (col < ncol) P[(int64_t)(c0 + col) * ldp + pt] = (TP)acc[mt][nt][r];
           }
       }
     }
@@ -1586,34 +1596,36 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
 }
 
 // bf16 rows of 16-byte granularity on the bf16 matrix pipe (see proj_bf16x3)
-template <int CBT, int NT, int WAVES>
-int32_t launch_bf16x3_pass(rpt_ctx* ctx, const rpt_dataset* ds, const uint4* Aimg, int nch, int c0,
-                           int ncol, float* P) {
-  const int64_t ntiles = (ds->n + WAVES * NT * 16 - 1) / (WAVES * NT * 16);
+template <int CBT, int NT, int WAVES, class TP, int NTERM>
+int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const uint4* Aimg, int nch,
+                           int c0, int ncol, TP* P) {
+  const int64_t ntiles = (n + WAVES * NT * 16 - 1) / (WAVES * NT * 16);
   int64_t blocks = ntiles < ctx->n_cu ? ntiles : ctx->n_cu;
   if (blocks < 1) blocks = 1;
   constexpr size_t smem = (size_t)2 * kB3KC * 3 * CBT * 64 * 16;
   static DeviceOnce attr_once;
   RPT_TRY(attr_once.run(ctx->device, [&]() -> int32_t {
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     return RPT_OK;
   }));
   if (nch == 2)
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), smem,
-                       ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
-                       P, ds->n, ntiles);
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM>), dim3((unsigned)blocks), dim3(WAVES * 64),
+                       smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
   else
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), smem,
-                       ctx->stream, (const __hip_bfloat16*)ds->X, ds->n, ds->d, Aimg, nch, c0, ncol,
-                       P, ds->n, ntiles);
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM>), dim3((unsigned)blocks), dim3(WAVES * 64),
+                       smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
   return RPT_OK;
 }
 
-int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, float* P) {
-  int nch = (ds->d + 32 * kB3KC - 1) / (32 * kB3KC);
+// P[C][n] = the rows X[NTERM][n][d] (NTERM bf16 terms each) against the hyperplanes R_dev[C][d] split into
+// three bf16 terms
+template <class TP, int NTERM>
+int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const double* R_dev,
+                           int32_t C, TP* P) {
+  int nch = (d + 32 * kB3KC - 1) / (32 * kB3KC);
   nch += nch & 1;  // even: chunk c always lives in LDS buffer c & 1
   struct Pass {
     int c0, ncol, cbt;
@@ -1631,7 +1643,7 @@ int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, 
   RPT_TRY(Aimg.alloc(total16));
   size_t off = 0;
   for (const Pass& ps : passes) {
-    hipLaunchKernelGGL(split_A_bf16x3, dim3(64), dim3(256), 0, ctx->stream, R_dev, ds->d, ps.c0,
+    hipLaunchKernelGGL(split_A_bf16x3, dim3(64), dim3(256), 0, ctx->stream, R_dev, d, ps.c0,
                        ps.ncol, ps.cbt, nch, Aimg.p + off);
     off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
   }
@@ -1645,15 +1657,91 @@ int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, 
     // eight waves of 32 points (4 M x 128 x 416: 2.98 -> 2.56 ms); with the chunked A stream of
     // longer rows the single wave per SIMD hides less and loses (2 M x 768 x 256: 3.09 -> 3.27 ms)
     if (ps.cbt == 8 && nch == 2)
-      RPT_TRY((launch_bf16x3_pass<8, 4, 4>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
-    else if (ps.cbt == 8)
-      RPT_TRY((launch_bf16x3_pass<8, 2, 8>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, NTERM>(ctx, X, n, d, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+    else if (ps.cbt == 8)  // (two row terms: 24 spilled registers at the 256 cap, and still ahead of one point
+                           // tile per wave without spills: 5.15 against 6.87 ms per C3 forest)
+      RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, NTERM>(ctx, X, n, d, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
     else
-      RPT_TRY((launch_bf16x3_pass<4, 2, 8>(ctx, ds, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, NTERM>(ctx, X, n, d, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
     off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
   }
   RPT_HIP(hipGetLastError());
   return RPT_OK;  // the image returns to the stream-ordered allocator
+}
+
+int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, float* P) {
+  return launch_bf16x3_rows<float, 1>(ctx, (const __hip_bfloat16*)ds->X, ds->n, ds->d, R_dev, C, P);
+}
+
+// ---- SVector rows on the matrix pipe (round 4; RPT_PROJ_MFMA = the tolerance mode on CSR data) ----
+// The segmented CSR kernel is instruction-issue bound (one multiply-add per (nonzero, hyperplane):
+// 10.6 ms per C3 forest with FMAs).  Dense-ified, the same contraction is proj_bf16x3's: the rows as
+// TWO bf16 terms x = x_hi + x_lo (|x - x_hi - x_lo| <= 2^-18 |x|), each multiplied with the hyperplanes'
+// three bf16 terms (24 bits) on v_mfma_f32_16x16x32_bf16 in ONE pass (proj_bf16x3<..., NTERM = 2>: both
+// row terms ride the B ring, an A fragment feeds four MFMAs), f32 accumulation:
+// |P - r.x| <= 2^-18 sum |x_i||r_i| + the f32 accumulation <= 1e-5 |x||r|
+// (north_star's tolerance; tests/test_gpu_parity.py::test_project_csr_dense_mfma).  The dense terms
+// ([2][n][d] bf16: 3.1 GB at C3 against 1.8 GB of CSR arrays) are built once per dataset.
+template <class T>
+__global__ __launch_bounds__(256) void csr_densify_bf16x2_kernel(const int64_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col,
+                                                                 const T* __restrict__ val, int64_t n, int d,
+                                                                 uint16_t* __restrict__ out /* [2][n][d], zeroed */) {
+  // one wave per row: the row's nonzeros, two bf16 terms each
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = wave_g; row < n; row += nwaves) {
+    const int64_t a = rowptr[row], b = rowptr[row + 1];
+    for (int64_t j = a + lane; j < b; j += 64) {
+      const int c = col[j];
+      if (c < 0 || c >= d) continue;  // (unchecked SVector invariants, Internal.hs:106-131: ignored like innerSS would)
+      const double v = (double)val[j];
+      const __hip_bfloat16 hi = __float2bfloat16((float)v);
+      const double rest = v - (double)__bfloat162float(hi);
+      const __hip_bfloat16 lo = __float2bfloat16((float)rest);
+      out[row * (int64_t)d + c] = __builtin_bit_cast(unsigned short, hi);
+      out[((int64_t)n + row) * (int64_t)d + c] = __builtin_bit_cast(unsigned short, lo);
+    }
+  }
+}
+
+// optional memory: anything that fails leaves the dataset on the segmented kernel
+template <class T>
+void ensure_csr_dense(rpt_ctx* ctx, const rpt_dataset* ds) {
+  if (ds->csr_dense_state != 0) return;
+  ds->csr_dense_state = -1;
+  if (ds->d % 8 != 0 || ds->n <= 0) return;
+  const size_t bytes = (size_t)2 * (size_t)ds->n * (size_t)ds->d * 2;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (bytes + ((size_t)8 << 30) > free_b) return;  // leave room for the build itself
+  void* p = nullptr;
+  if (dev_alloc(&p, bytes) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (hipMemsetAsync(p, 0, bytes, ctx->stream) != hipSuccess) {
+    dev_free(p);
+    return;
+  }
+  hipLaunchKernelGGL(csr_densify_bf16x2_kernel<T>, dim3((unsigned)(ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                     ds->rowptr, ds->col, (const T*)ds->val, ds->n, ds->d, (uint16_t*)p);
+  if (hipGetLastError() != hipSuccess) {
+    dev_free(p);
+    return;
+  }
+  ds->csr_dense = (uint16_t*)p;
+  ds->csr_dense_state = 1;
+}
+
+template <class T>
+int32_t launch_csr_dense_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, T* P) {
+  return launch_bf16x3_rows<T, 2>(ctx, reinterpret_cast<const __hip_bfloat16*>(ds->csr_dense), ds->n, ds->d,
+                                  R_dev, C, P);
 }
 
 template <class T>
@@ -1825,6 +1913,16 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
     // CSR x dense is not MFMA shaped: both modes use the segmented kernel, RPT_PROJ_MFMA (the
     // tolerance mode) with one fused multiply-add per term instead of the reference's two roundings
     const bool fused = mode == RPT_PROJ_MFMA;
+    // ... and, when the rows fit dense-ified (d % 8 == 0, memory), the tolerance mode runs on the
+    // matrix pipe (launch_csr_dense_mfma); few rows (query batches) stay on the segmented kernel
+    if (fused && !ctx->opt.proj_csr_nodense && ds->n >= 65536) {
+      if (ds->dtype == RPT_F64) ensure_csr_dense<double>(ctx, ds);
+      else ensure_csr_dense<float>(ctx, ds);
+      if (ds->csr_dense_state == 1) {
+        if (ds->dtype == RPT_F64) return launch_csr_dense_mfma<double>(ctx, ds, R_dev, C, (double*)P_dev);
+        return launch_csr_dense_mfma<float>(ctx, ds, R_dev, C, (float*)P_dev);
+      }
+    }
     if (ds->dtype == RPT_F64) return launch_csr<double>(ctx, ds, R_dev, C, (double*)P_dev, fused);
     return launch_csr<float>(ctx, ds, R_dev, C, (float*)P_dev, fused);
   }

@@ -152,6 +152,50 @@ def test_project_csr_exact(rp, ctx, oracle):
             assert P[c, i] == oracle.inner_ss(idx, R[c, idx], col[a:b], val[a:b])
 
 
+@pytest.mark.parametrize("d,dtype", [(784, np.float64), (64, np.float64), (200, np.float32)])
+def test_project_csr_dense_mfma(rp, ctx, oracle, option, d, dtype):
+    """RPT_PROJ_MFMA on SVector rows (the tolerance mode): from 65 536 rows on, rows of d % 8 == 0
+    elements are dense-ified as two bf16 terms and projected on the bf16 matrix pipe against the
+    hyperplanes' three bf16 terms (launch_csr_dense_mfma).  Values within north_star's 1e-5 |x||r| of
+    the f64 contraction — like the segmented kernel's one-FMA-per-term form (proj_csr_nodense), which
+    the same call falls back to — and a forest built on them is a valid tree whose leaf assignment
+    differs from the exact build's for < 1e-3 of the points."""
+    n, C = 70000, 45
+    rng = np.random.default_rng(7)
+    nnz_row = max(3, d // 5)
+    cols = np.sort(np.stack([rng.choice(d, nnz_row, replace=False) for _ in range(2000)]), axis=1)
+    cols = cols[rng.integers(0, 2000, n)]
+    rowptr = np.arange(n + 1, dtype=np.int64) * nnz_row
+    col = cols.reshape(-1).astype(np.int32)
+    val = (1.0 - rng.random(n * nnz_row)).astype(dtype)                 # U(0, 1] like C3
+    R = sparse_R(rng, C, d, 0.35)
+    ds = rp.Dataset.csr(ctx, rowptr, col, val, d)
+    X = np.zeros((n, d))
+    X[np.repeat(np.arange(n), nnz_row), col] = val.astype(np.float64)
+    want = R @ X.T
+    scale = np.linalg.norm(R, axis=1)[:, None] * np.linalg.norm(X, axis=1)[None, :]
+    P = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    err = np.abs(P - want) / scale
+    assert err.max() <= 1e-5, err.max()
+    with option("proj_csr_nodense", 1):
+        P2 = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+    assert (np.abs(P2 - want) <= 1e-5 * scale).all()
+    assert not np.array_equal(P, P2)                                    # two different kernels did run
+    if d == 784:
+        cfg = rp.rpTreeCfg(100, n, d)
+        L, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+        Rf, _ = oracle.forest_hyperplanes(3, 2, L, pnz, d)
+        fe = rp.forestBatch(0, L, 100, 2, pnz, d, ds, ctx=ctx, hyperplanes=Rf, mode=rp.RPT_PROJ_EXACT)
+        fm = rp.forestBatch(0, L, 100, 2, pnz, d, ds, ctx=ctx, hyperplanes=Rf, mode=rp.RPT_PROJ_MFMA)
+        leaf_off = np.array([o for (_, _, o, m, lf) in fe.topology() if lf])
+        for t in range(2):
+            assert np.array_equal(np.sort(fm.perm[t]), np.arange(n))
+            inv_e = np.empty(n, np.int64); inv_e[fe.perm[t]] = np.arange(n)
+            inv_m = np.empty(n, np.int64); inv_m[fm.perm[t]] = np.arange(n)
+            flips = (np.searchsorted(leaf_off, inv_e, side="right") != np.searchsorted(leaf_off, inv_m, side="right")).mean()
+            assert flips < 1e-3, flips
+
+
 # ------------------------------------------------------------------ split on identical inputs
 def test_split_segments_matches_partition_at_median(rp, ctx, oracle):
     rng = np.random.default_rng(11)
@@ -1223,6 +1267,34 @@ def test_knn_shard_kernels_are_exact(rp, ctx, oracle, option, dtype, shape, kind
                 assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi)
                 assert np.array_equal(dist[i, :cnt[i]], wd)
     assert tiers_seen & {2, 3}, tiers_seen
+
+
+@pytest.mark.parametrize("T,nq", [(1, 5), (2, 1), (33, 64), (64, 37), (7, 130)])
+def test_knn_shard_kernels_any_tree_count_and_batch_size(rp, ctx, oracle, option, T, nq):
+    """shard_ranges_kernel packs 64 / T queries into a wave (lane = (query, tree)): one tree, trees that
+    do not divide 64, 33 and 64 trees (one query per wave), query counts that leave the last wave and
+    the last workgroup partly empty — the oracle's answers, every tier."""
+    n, d, ml, k = 12000, 32, 25, 9
+    X = oracle.data_normal_dense2(51, n, d)
+    Q = oracle.data_normal_dense2(52, nq, d) * 0.9 + 0.1
+    cfg = rp.rpTreeCfg(ml, n, d)
+    L, pnz = cfg.fpMaxTreeDepth, cfg.fpProjNzDensity
+    R, _ = oracle.forest_hyperplanes(13, T, L, pnz, d)
+    f = rp.forestBatch(0, L, ml, T, pnz, d, X, ctx=ctx, hyperplanes=R, mode=rp.RPT_PROJ_EXACT)
+    fo = oracle.forest_build_dense(X, R, ml)
+    for opts in ({}, {"knn_no_pre8": 1}, {"knn_no_pre16": 1}):
+        import contextlib
+        with contextlib.ExitStack() as st:
+            st.enter_context(option("knn_wave", 1))
+            for o, v in opts.items():
+                st.enter_context(option(o, v))
+            ids, dist, cnt = rp.knnBatch(k, f, Q)
+            tier, _ = _tier_and_uncertified(ctx)
+        assert tier in (1, 2, 3)
+        for i in range(nq):
+            wi, wd = oracle.knn_dense(fo, X, Q[i], k)
+            assert cnt[i] == len(wi) and np.array_equal(ids[i, :cnt[i]], wi), (T, i, opts)
+            assert np.array_equal(dist[i, :cnt[i]], wd)
 
 
 def test_knn_shard_list_overflow_goes_to_the_exact_kernel(rp, ctx, oracle, option):

@@ -22,7 +22,9 @@ ctx = rp.default_context()
 ds = rp.Dataset.csr(ctx, rowptr, col, val, d)
 _, R = rp.gen.forest_hyperplanes(5, T, cfg.fpMaxTreeDepth, cfg.fpProjNzDensity, d)
 L_ = _lib.lib()
-for name, mode, opts in [("exact, 32 per pass", rp.RPT_PROJ_EXACT, {}), ("fused, 32 per pass", rp.RPT_PROJ_MFMA, {}),
+for name, mode, opts in [("exact, 32 per pass", rp.RPT_PROJ_EXACT, {}),
+                         ("dense bf16x2 on MFMA", rp.RPT_PROJ_MFMA, {}),
+                         ("fused, 32 per pass", rp.RPT_PROJ_MFMA, {"proj_csr_nodense": 1}),
                          ("exact, 16 per pass", rp.RPT_PROJ_EXACT, {"proj_narrow": 1})]:
     for k, v in opts.items():
         ctx.set_option(k, v)
@@ -39,7 +41,7 @@ for name, mode, opts in [("exact, 32 per pass", rp.RPT_PROJ_EXACT, {}), ("fused,
             print("   (build failed: %s)" % str(e)[:80])
         ctx.sync()
         ms, cnt = C.c_double(), C.c_int64()
-        _lib.check(L_.rpt_prof_get(ctx._h, 0, C.byref(ms), C.byref(cnt)))
+        _lib.check(L_.rpt_prof_get(ctx._h, 0, C.byref(ms), C.byref(cnt)))        # (class 0 includes the wide launches of class 4)
         if ms.value < best:
             best, bw = ms.value, wall
     print("%-20s projection %.2f ms in %d launches, build %.2f ms" % (name, best, cnt.value, bw), flush=True)
