@@ -1497,6 +1497,12 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
         } else if (left <= 128) {
           take = left;
           tiles = 8;
+        } else if (sizeof(TC) == 4 && left <= 160) {
+          // f32 fragments are half the size: up to ten column tiles fit the LDS, and what is left of
+          // a 10 M-point shard's 136 columns after a 96-column pass (40) is a pass bound by its read of X
+          // (round 4; C4 shard build 14.7 / 14.9 -> 14.4 / 13.8 ms on one box)
+          take = left;
+          tiles = left <= 144 ? 9 : 10;
         } else {
           take = 96;
           tiles = 6;
@@ -1538,6 +1544,17 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
           // resolved into class 0 as well
           ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
           switch (ps.tiles) {
+            case 10:
+            case 9:
+              if constexpr (sizeof(TC) == 4) {
+                if (ps.tiles == 10)
+                  RPT_TRY((launch_wide<TIn, TC, D, 10, 4>(ctx, ds, k0, kvalid, accumulate, ps.c0, ps.ncol, Ab, P,
+                                                          ntiles, wblocks, cop)));
+                else
+                  RPT_TRY((launch_wide<TIn, TC, D, 9, 4>(ctx, ds, k0, kvalid, accumulate, ps.c0, ps.ncol, Ab, P,
+                                                         ntiles, wblocks, cop)));
+              }
+              break;
             case 8:
               RPT_TRY((launch_wide<TIn, TC, D, 8, KS8>(ctx, ds, k0, kvalid, accumulate, ps.c0,
                                                        ps.ncol, Ab, P, ntiles, wblocks, cop)));
