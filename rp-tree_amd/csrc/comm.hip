@@ -441,6 +441,7 @@ int32_t rpt_comm_sync(rpt_comm* comm) {
         // the first few thousand turns spin (a batch is a fraction of a millisecond), then back off
         if (++spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
       }
+      (void)hipGetLastError();  // hipErrorNotReady of the polls must not surface at a later launch check
     }
     for (rpt_ctx* x : comm->ctx) RPT_TRY(rpt_ctx_sync(x));  // (returns at once after the poll; recycles the allocator's blocks)
     // the status words of the exchanges since the last sync (failure protocol, top of this file)

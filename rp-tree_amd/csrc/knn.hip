@@ -2595,8 +2595,8 @@ __global__ __launch_bounds__(256) void shard_ranges_kernel(
   if (lane == 0 && visited) atomicAdd(cand_total, visited);
 }
 
-__host__ __device__ inline size_t shard_wave_bytes(int d, size_t acc_size, int kSL) {
-  const size_t b = (size_t)kWC * 8 + (size_t)kWR * 8 + (size_t)(kWR + 4) * 4 + (size_t)kSL * 20 + 16 +
+__host__ __device__ inline size_t shard_wave_bytes(int d, size_t acc_size, int kSL, int WC) {
+  const size_t b = (size_t)WC * 8 + (size_t)kWR * 8 + (size_t)(kWR + 4) * 4 + (size_t)kSL * 20 + 16 +
                    (((size_t)d * acc_size + 15) & ~(size_t)15) + (size_t)d * 4;
   return (b + 15) & ~(size_t)15;
 }
@@ -2605,8 +2605,10 @@ __host__ __device__ inline size_t shard_wave_bytes(int d, size_t acc_size, int k
 // kSL: slots of the carried list (a multiple of 64); MINB: workgroups per CU the register budget allows.
 // Two shapes are instantiated: (128, 4) for shards whose candidates are one batch, (256, 3) beyond
 // (the first batch's threshold comes from per-lane minima and lets more of a 980-candidate query
-// through than 128 slots hold: 1.6 % of the queries of an 8-tree C2 shard)
-template <class TD, int TIER, int kSL, int MINB>
+// through than 128 slots hold: 1.6 % of the queries of an 8-tree C2 shard).  WC = candidates per
+// batch: 512, and 640 in the second shape — a C4 shard's 610 candidates per query are one batch
+// instead of 512 + 98 (a batch costs a fill and a list update whatever it holds).
+template <class TD, int TIER, int kSL, int MINB, int WC>
 __global__ __launch_bounds__(256, MINB) void knn_shard_wave_kernel(
     const TD* __restrict__ X, int d, const TD* __restrict__ Q, const int32_t* __restrict__ perm, int64_t nq,
     int k, const int2* __restrict__ hdr, const int64_t* __restrict__ rng_off, const int* __restrict__ rng_n,
@@ -2626,15 +2628,15 @@ __global__ __launch_bounds__(256, MINB) void knn_shard_wave_kernel(
   const int nr_tot = h.x, nc_tot = h.y;
   if (nr_tot > kWR) return;  // flagged by shard_ranges_kernel: the general path answers it
   constexpr int kSLpl = kSL / 64;  // list entries per lane
-  unsigned char* base = smem + (size_t)wave * shard_wave_bytes(d, sizeof(TA), kSL);
+  unsigned char* base = smem + (size_t)wave * shard_wave_bytes(d, sizeof(TA), kSL, WC);
   unsigned long long* lkey = reinterpret_cast<unsigned long long*>(base);           // [kSL] (value bits << 32 | position)
   double* rdist = reinterpret_cast<double*>(lkey + kSL);                              // [kSL] exact distances
   int64_t* rpoff = reinterpret_cast<int64_t*>(rdist + kSL);                           // [kWR]
   TA* qs = reinterpret_cast<TA*>(rpoff + kWR);                                        // [d]
   float* cval = reinterpret_cast<float*>(base + (size_t)kSL * 16 + (size_t)kWR * 8 +
-                                         (((size_t)d * sizeof(TA) + 15) & ~(size_t)15));  // [kWC] ranking values
-  int* cid = reinterpret_cast<int*>(cval + kWC);                                      // [kWC]
-  int* rstart = cid + kWC;                                                            // [kWR + 1]
+                                         (((size_t)d * sizeof(TA) + 15) & ~(size_t)15));  // [WC] ranking values
+  int* cid = reinterpret_cast<int*>(cval + WC);                                       // [WC]
+  int* rstart = cid + WC;                                                            // [kWR + 1]
   int* lid = rstart + kWR + 4;                                                        // [kSL]
   unsigned int* lcnt = reinterpret_cast<unsigned int*>(lid + kSL);                    // [4]
   float* qs32 = reinterpret_cast<float*>(lcnt + 4);                                   // [d] f32 copy / byte planes
@@ -2697,11 +2699,11 @@ __global__ __launch_bounds__(256, MINB) void knn_shard_wave_kernel(
   auto keep_bits = [&](double Ulim) -> unsigned int { return tb.keep_bits(Ulim); };
   auto upper = [&](double dh) -> double { return tb.upper(dh); };
 
-  constexpr int E = kWC / 64;
+  constexpr int E = WC / 64;
   int n_list = 0, pos_base = 0;
   while (pos_base < nc_tot) {
     // ---- fill: candidate s of the batch by position (a search over rstart, the perm loads in flight together)
-    const int take = nc_tot - pos_base < kWC ? nc_tot - pos_base : kWC;
+    const int take = nc_tot - pos_base < WC ? nc_tot - pos_base : WC;
     {
       int64_t addr[E];
 #pragma unroll
@@ -3803,7 +3805,7 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
     if (wave_shard && !wave && !((pre32 || sh16 || sh8) && k <= kSKmax && !ctx->opt.knn_shard_old))
       wave_shard = false;  // (only the prefiltered instantiations have the shard kernels)
     // (a forced wave variant on very long rows: the shard kernels' slab must fit the CU's LDS)
-    if (wave_shard && 4 * shard_wave_bytes(data->d, sizeof(TA), 256) > 160 * 1024) wave_shard = false;
+    if (wave_shard && 4 * shard_wave_bytes(data->d, sizeof(TA), 256, 640) > 160 * 1024) wave_shard = false;
   } else {
     wave_shard = false;
   }
@@ -3827,10 +3829,11 @@ static int32_t launch_fused(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data
                            f->min_leaf, f->n, hdr.p, roff.p, rlen.p, ovf + 1, ovf, cand_total);
         RPT_HIP(hipGetLastError());
         const bool one_batch = (int64_t)f->T * (leaf > 0 ? leaf : 1) <= kWC;
-        const size_t smem2 = 4 * shard_wave_bytes(data->d, sizeof(TA), one_batch ? 128 : 256);
-        auto kern = sh8    ? (one_batch ? knn_shard_wave_kernel<TD, 3, 128, 4> : knn_shard_wave_kernel<TD, 3, 256, 3>)
-                    : sh16 ? (one_batch ? knn_shard_wave_kernel<TD, 2, 128, 4> : knn_shard_wave_kernel<TD, 2, 256, 3>)
-                           : (one_batch ? knn_shard_wave_kernel<TD, 1, 128, 4> : knn_shard_wave_kernel<TD, 1, 256, 3>);
+        const size_t smem2 = 4 * (one_batch ? shard_wave_bytes(data->d, sizeof(TA), 128, 512)
+                                            : shard_wave_bytes(data->d, sizeof(TA), 256, 640));
+        auto kern = sh8    ? (one_batch ? knn_shard_wave_kernel<TD, 3, 128, 4, 512> : knn_shard_wave_kernel<TD, 3, 256, 3, 640>)
+                    : sh16 ? (one_batch ? knn_shard_wave_kernel<TD, 2, 128, 4, 512> : knn_shard_wave_kernel<TD, 2, 256, 3, 640>)
+                           : (one_batch ? knn_shard_wave_kernel<TD, 1, 128, 4, 512> : knn_shard_wave_kernel<TD, 1, 256, 3, 640>);
         if (smem2 > 64 * 1024)
           RPT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
         const int r1_pct = 110;  // (100 / 110 / 130 measured: 0.281 / 0.279 / 0.283 ms per 10 000 queries)
