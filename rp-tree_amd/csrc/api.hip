@@ -227,6 +227,7 @@ const OptDesc kOptions[] = {
     {"no_pcodes", &rpt_options::no_pcodes},
     {"proj_narrow", &rpt_options::proj_narrow},
     {"proj_bf16_f32", &rpt_options::proj_bf16_f32},
+    {"proj_bf16_terms", &rpt_options::proj_bf16_terms},
     {"proj_csr_nodense", &rpt_options::proj_csr_nodense},
     {"knn_wave", &rpt_options::knn_wave},
     {"knn_kp", &rpt_options::knn_kp},

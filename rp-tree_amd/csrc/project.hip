@@ -887,23 +887,24 @@ __global__ __launch_bounds__(WPB * 64, 1) void proj_mfma_wide(const TIn* __restr
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kB3KC = 2;     // k-steps (32 k each) per A chunk
+constexpr int kB3KC = 2;     // k-steps (32 k each) per A chunk with three hyperplane terms (four with two terms)
 
 // hyperplanes [c0, c0 + ncol) as three bf16 terms in fragment order:
 // out[chunk][ks][part][mt][lane] (16 bytes = 8 bf16): R[c0 + 16 mt + (lane & 15)][k .. k + 7],
 // k = 32 (2 chunk + ks) + 8 (lane >> 4); zero outside the columns / past d.
 __global__ void split_A_bf16x3(const double* __restrict__ R, int d, int c0, int ncol, int cbt,
-                               int nch, uint4* __restrict__ out) {
-  const int per_chunk = kB3KC * 3 * cbt * 64;
-  const int total = nch * kB3KC * cbt * 64;
+                               int nch, int kc /* k-steps per chunk */, int np /* terms kept: 2 or 3 */,
+                               uint4* __restrict__ out) {
+  const int per_chunk = kc * np * cbt * 64;
+  const int total = nch * kc * cbt * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63;
     int r = i >> 6;
     const int mt = r % cbt;
     r /= cbt;
-    const int ks = r % kB3KC, ch = r / kB3KC;
+    const int ks = r % kc, ch = r / kc;
     const int col = mt * 16 + (lane & 15);
-    const int k0 = (ch * kB3KC + ks) * 32 + 8 * (lane >> 4);
+    const int k0 = (ch * kc + ks) * 32 + 8 * (lane >> 4);
     unsigned int w[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int j = 0; j < 8; ++j) {
       double v = (col < ncol && k0 + j < d) ? R[(int64_t)(c0 + col) * d + k0 + j] : 0.0;
@@ -914,24 +915,27 @@ __global__ void split_A_bf16x3(const double* __restrict__ R, int d, int c0, int 
         w[p3][j >> 1] |= bits << ((j & 1) * 16);
       }
     }
-    for (int p3 = 0; p3 < 3; ++p3)
-      out[(size_t)ch * per_chunk + ((ks * 3 + p3) * cbt + mt) * 64 + lane] =
+    for (int p3 = 0; p3 < np; ++p3)
+      out[(size_t)ch * per_chunk + ((ks * np + p3) * cbt + mt) * 64 + lane] =
           make_uint4(w[p3][0], w[p3][1], w[p3][2], w[p3][3]);
   }
 }
 
-template <int CBT, int NT /* 16-point tiles per wave */, bool RESIDENT /* d <= 128: both chunks stay in LDS */,
+template <int CBT, int NT /* 16-point tiles per wave, even */, bool RESIDENT /* both chunks stay in LDS */,
           int WAVES /* per workgroup */, class TP = float /* type of P */,
-          int NTERM = 1 /* bf16 terms of a row: X[term][n][d]; 2 = dense-ified SVector rows (launch_csr_dense_mfma) */>
+          int NTERM = 1 /* bf16 terms of a row: X[term][n][d]; 2 = dense-ified SVector rows (launch_csr_dense_mfma) */,
+          int NP = 3 /* bf16 terms of a hyperplane */, int KC = kB3KC /* k-steps per A chunk: 2 or 4 */>
 __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
     const __hip_bfloat16* __restrict__ X, int64_t n, int d, const uint4* __restrict__ Aimg,
     int nch /* even */, int c0, int ncol, TP* __restrict__ P, int64_t ldp, int64_t ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds_a[];  // [2][CH16]
-  constexpr int CH16 = kB3KC * 3 * CBT * 64;  // uint4 per chunk
+  constexpr int CH16 = KC * NP * CBT * 64;    // uint4 per chunk
   constexpr int kB3NT = NT, kB3Pts = WAVES * NT * 16, NTHR = WAVES * 64;  // points per workgroup tile
   constexpr int ST = CH16 / NTHR;              // uint4 a thread stages per chunk
+  static_assert(KC == 2 || KC == 4, "the B ring is addressed by (chunk parity, k-step)");
+  static_assert(NT % 2 == 0 && CH16 % NTHR == 0, "point tiles are stored in pairs; whole staging rounds");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nks = nch * kB3KC;                // k-steps per tile, a multiple of 4
+  const int nks = nch * KC;                   // k-steps per tile, a multiple of 4
   constexpr bool resident = RESIDENT;
   const int kg = 8 * (lane >> 4);             // the lane's k offset inside a k-step
   // prologue: chunk 0 (and chunk 1 when resident) into LDS
@@ -976,8 +980,8 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
         }
         const uint4* ab = lds_a + h * CH16;
 #pragma unroll
-        for (int ks = 0; ks < kB3KC; ++ks) {
-          const int u = h * 2 + ks;
+        for (int ks = 0; ks < KC; ++ks) {
+          const int u = (h * KC + ks) & 3;
           bf16x8 b[NTERM][kB3NT];
 #pragma unroll
           for (int tm = 0; tm < NTERM; ++tm)
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
             for (int nt = 0; nt < kB3NT; ++nt) b[tm][nt] = __builtin_bit_cast(bf16x8, bf[u][tm][nt]);
           // refill the ring slot four k-steps ahead (the next tile's first k-steps at the end)
           {
-            const int sn = c * kB3KC + ks + 4;
+            const int sn = c * KC + ks + 4;
             const int64_t tn = sn >= nks ? tile + gridDim.x : tile;
             const int kn = sn >= nks ? sn - nks : sn;
 #pragma unroll
@@ -993,11 +997,11 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
 #pragma unroll
               for (int nt = 0; nt < kB3NT; ++nt) bf[u][tm][nt] = load_b(tn, kn, nt, tm);
           }
-#pragma unroll 1  // (unrolled, the 24 fragment reads of a k-step are hoisted together and spill)
-          for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll 1  // (unrolled, the fragment reads of a k-step are hoisted together: no faster, or spills)
+          for (int p3 = 0; p3 < NP; ++p3)
 #pragma unroll
             for (int mt = 0; mt < CBT; ++mt) {
-              const bf16x8 a = __builtin_bit_cast(bf16x8, ab[((ks * 3 + p3) * CBT + mt) * 64 + lane]);
+              const bf16x8 a = __builtin_bit_cast(bf16x8, ab[((ks * NP + p3) * CBT + mt) * 64 + lane]);
               // (two row terms: one fragment read feeds 2 NT MFMAs — the LDS reads per MFMA halve)
 #pragma unroll
               for (int tm = 0; tm < NTERM; ++tm)
@@ -1013,18 +1017,52 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
         }
       }
     }
-    // D[row = 4 (lane >> 4) + r][col = lane & 15]: hyperplane, point
+    // D[row = 4 (lane >> 4) + r][col = lane & 15] = (hyperplane, point).
+    // ONE running pointer per point tile: the sixty-four addresses of the straightforward loop are hoisted out of
+    // the tile loop (60 registers; with two row terms they spilled, and a scratch reload waits for every row
+    // request in flight: 5.15 -> 4.75 ms per C3 forest without them).
+    if constexpr (sizeof(TP) == 4) {
+      // 4-byte P: two neighbouring point tiles swap their odd / even lane rows (v_permlane16_swap), lanes 0..31 then
+      // hold 32 consecutive points of ONE hyperplane and a store writes whole 128-byte lines (half lines:
+      // WRITE_SIZE 6.6 GB for 5.1 GB of P, and 3 % of the pass).  (8-byte P has whole lines already.)
 #pragma unroll
-    for (int nt = 0; nt < kB3NT; ++nt) {
-      const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + nt * 16 + (lane & 15);
-      if (pt < n) {
+      for (int np2 = 0; np2 < kB3NT; np2 += 2) {
+        const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + np2 * 16 + (lane & 31);
+        int col = 8 * (lane >> 5);
+        TP* dst = P + (int64_t)(c0 + col) * ldp + pt;
 #pragma unroll
-        for (int mt = 0; mt < CBT; ++mt)
+        for (int mt = 0; mt < CBT; ++mt) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              // (the swap is redone for hf = 1: a VALU move against eight more live registers)
+              const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][np2][r]),
+                                                               __float_as_uint(acc[mt][np2 + 1][r]), false, false);
+              if (pt < n && col + 4 * hf + r < ncol) *dst = (TP)__uint_as_float(sw[hf]);
+              dst += ldp;
+            }
+          }
+          col += 16;
+          dst += 8 * ldp;  // the other lane half holds the hyperplanes 8 .. 15 of the tile
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < kB3NT; ++nt) {
+        const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + nt * 16 + (lane & 15);
+        int col = 4 * (lane >> 4);
+        TP* dst = P + (int64_t)(c0 + col) * ldp + pt;
+#pragma unroll
+        for (int mt = 0; mt < CBT; ++mt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int col = mt * 16 + 4 * (lane >> 4) + r;
-            if (col < ncol) P[(int64_t)(c0 + col) * ldp + pt] = (TP)acc[mt][nt][r];
+            if (pt < n && col + r < ncol) *dst = (TP)acc[mt][nt][r];
+            dst += ldp;
           }
+          col += 16;
+          dst += 12 * ldp;
+        }
       }
     }
   }
@@ -1613,36 +1651,46 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
 }
 
 // bf16 rows of 16-byte granularity on the bf16 matrix pipe (see proj_bf16x3)
-template <int CBT, int NT, int WAVES, class TP, int NTERM>
+template <int CBT, int NT, int WAVES, class TP, int NTERM, int NP = 3, int KC = kB3KC>
 int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const uint4* Aimg, int nch,
                            int c0, int ncol, TP* P) {
   const int64_t ntiles = (n + WAVES * NT * 16 - 1) / (WAVES * NT * 16);
   int64_t blocks = ntiles < ctx->n_cu ? ntiles : ctx->n_cu;
   if (blocks < 1) blocks = 1;
-  constexpr size_t smem = (size_t)2 * kB3KC * 3 * CBT * 64 * 16;
+  constexpr size_t smem = (size_t)2 * KC * NP * CBT * 64 * 16;
+  static_assert(smem <= 160 * 1024, "two A chunks in LDS");
   static DeviceOnce attr_once;
   RPT_TRY(attr_once.run(ctx->device, [&]() -> int32_t {
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM, NP, KC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM, NP, KC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     return RPT_OK;
   }));
   if (nch == 2)
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM>), dim3((unsigned)blocks), dim3(WAVES * 64),
-                       smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM, NP, KC>), dim3((unsigned)blocks),
+                       dim3(WAVES * 64), smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
   else
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM>), dim3((unsigned)blocks), dim3(WAVES * 64),
-                       smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
+    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM, NP, KC>), dim3((unsigned)blocks),
+                       dim3(WAVES * 64), smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
   return RPT_OK;
 }
 
 // P[C][n] = the rows X[NTERM][n][d] (NTERM bf16 terms each) against the hyperplanes R_dev[C][d] split into
-// three bf16 terms
+// bf16 terms.  bf16 DATA (NTERM = 1) takes TWO hyperplane terms: r = r_hi + r_mid + e with |e_i| <= 2^-18 |r_i|
+// (two roundings to 8 significant bits), every product x_i * r_part exact in f32, so
+// |P - x.r| <= 2^-18 sum |x_i||r_i| <= 3.9e-6 |x||r| by Cauchy-Schwarz, inside north_star's 1e-5 with the f32
+// accumulation (measured: 4.6e-7 |x||r| at d = 768; three terms: 1.0e-7) — a third less matrix-pipe and LDS work
+// than three terms (6.7 -> 5.0 ms per 128 hyperplanes over 10 M x 768).  Option proj_bf16_terms = 3 keeps the
+// third term.  Dense-ified SVector rows (NTERM = 2) already spend their 2^-18 on the ROW split and keep three.
 template <class TP, int NTERM>
 int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const double* R_dev,
                            int32_t C, TP* P) {
-  int nch = (d + 32 * kB3KC - 1) / (32 * kB3KC);
+  const bool two = NTERM == 1 && ctx->opt.proj_bf16_terms != 3;
+  const int np = two ? 2 : 3;
+  // two terms leave room for chunks of four k-steps (128 KB of LDS for 128 hyperplanes): half the barriers
+  const int kc = (two && d > 128) ? 4 : kB3KC;
+  int nch = (d + 32 * kc - 1) / (32 * kc);
   nch += nch & 1;  // even: chunk c always lives in LDS buffer c & 1
   struct Pass {
     int c0, ncol, cbt;
@@ -1654,33 +1702,48 @@ int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
     passes.push_back(Pass{c0, take, take <= 64 ? 4 : 8});
     c0 += take;
   }
+  auto image16 = [&](const Pass& ps) { return (size_t)nch * kc * np * ps.cbt * 64; };
   size_t total16 = 0;
-  for (const Pass& ps : passes) total16 += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
+  for (const Pass& ps : passes) total16 += image16(ps);
   DevBuf<uint4> Aimg;
   RPT_TRY(Aimg.alloc(total16));
   size_t off = 0;
   for (const Pass& ps : passes) {
     hipLaunchKernelGGL(split_A_bf16x3, dim3(64), dim3(256), 0, ctx->stream, R_dev, d, ps.c0,
-                       ps.ncol, ps.cbt, nch, Aimg.p + off);
-    off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
+                       ps.ncol, ps.cbt, nch, kc, np, Aimg.p + off);
+    off += image16(ps);
   }
   off = 0;
   for (const Pass& ps : passes) {
     ProfScope pw(ctx, RPT_PROF_PROJECT_WIDE);
-    // (four 16-point tiles per wave would halve the LDS fragment traffic per MFMA, but with the
-    // 4-deep B ring that is 256 VGPRs + 300 bytes of scratch: two tiles it is)
+    const uint4* img = Aimg.p + off;
     // rows of up to 128 elements (A resident in LDS, no staging): four waves of 64 points each
     // — half the LDS fragment reads per MFMA, accumulators in AGPRs — are 14 % faster than
     // eight waves of 32 points (4 M x 128 x 416: 2.98 -> 2.56 ms); with the chunked A stream of
-    // longer rows the single wave per SIMD hides less and loses (2 M x 768 x 256: 3.09 -> 3.27 ms)
+    // longer rows the single wave per SIMD hides less and loses (2 M x 768 x 256: 3.09 -> 3.27 ms),
+    // and so do 64 points per wave at two waves per SIMD (spills), two waves per point group with 64
+    // hyperplanes each, twelve waves, and two workgroups of four waves
+    if constexpr (NTERM == 1) {
+      if (two) {
+        if (ps.cbt == 8 && nch == 2 && kc == 2)
+          RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+        else if (ps.cbt == 8)
+          RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+        else if (kc == 2)
+          RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+        else
+          RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+        off += image16(ps);
+        continue;
+      }
+    }
     if (ps.cbt == 8 && nch == 2)
-      RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, NTERM>(ctx, X, n, d, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
-    else if (ps.cbt == 8)  // (two row terms: 24 spilled registers at the 256 cap, and still ahead of one point
-                           // tile per wave without spills: 5.15 against 6.87 ms per C3 forest)
-      RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, NTERM>(ctx, X, n, d, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+    else if (ps.cbt == 8)
+      RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
     else
-      RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, NTERM>(ctx, X, n, d, Aimg.p + off, nch, ps.c0, ps.ncol, P)));
-    off += (size_t)nch * kB3KC * 3 * ps.cbt * 64;
+      RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+    off += image16(ps);
   }
   RPT_HIP(hipGetLastError());
   return RPT_OK;  // the image returns to the stream-ordered allocator

@@ -232,7 +232,7 @@ def test_c3_1m_x784_sparse(rp, oracle, torch):
 
 # ------------------------------------------------------------------------------------ C4
 def shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, seed, rel_gap, min_same_cands,
-                oracle_trees, min_positions, cut_nodes=12):
+                oracle_trees, min_positions, cut_nodes=12, min_close=0.97, tight=None):
     """Common part of C4 / C5: Xd = device tensor (f32 or bf16), Xh = the same rows on the host
     as float32 (exact).  Builds T trees in the default mode of the element type (MFMA) and checks
     all of them through their own projections and the trees `oracle_trees` against the oracle's
@@ -271,7 +271,25 @@ def shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, seed, rel_gap, mi
     rn = np.repeat(np.linalg.norm(R[ot], axis=2), [1 << l for l in range(f.L)], axis=1)
     xmax = float(np.linalg.norm(Xs, axis=1).max())
     close = np.abs(f.thr[ot] - fo.thr)[tt] <= 1e-5 * (xmax * rn)[tt]
-    assert close.mean() >= 0.97, close.mean()
+    print("thresholds within 1e-5 |x||r| of the oracle's: %.4f of the nodes" % close.mean())
+    assert close.mean() >= min_close, close.mean()
+    if tight:
+        # the same build under the tighter projection options (name -> (value, default)): its own bar
+        for name, (val, _) in tight.items():
+            ctx.set_option(name, val)
+        try:
+            f3 = rp._build(ctx, ds, R, cfg.fpMaxTreeDepth, min_leaf, rp.RPT_PROJ_AUTO)
+        finally:
+            for name, (_, dflt) in tight.items():
+                ctx.set_option(name, dflt)
+        for j, t in enumerate(ot):
+            fl3 = flip_rate(f3.perm[t], fo.perm[j], leaf_off)
+            print("tree %d under %s: leaf flips vs the oracle %.2e" % (t, sorted(tight), fl3))
+            assert fl3 < 1e-3, (t, fl3)
+        close3 = np.abs(f3.thr[ot] - fo.thr)[tt] <= 1e-5 * (xmax * rn)[tt]
+        print("thresholds under %s: %.4f of the nodes" % (sorted(tight), close3.mean()))
+        assert close3.mean() >= 0.97, close3.mean()
+        f3.close()
     del fo
     # queries: data points moved a little, in the data's element type
     qi = np.random.default_rng(seed + 2).choice(n, size=nq, replace=False)
@@ -334,8 +352,12 @@ def test_c5_10m_x768_bf16_depth16_k50(rp, oracle, torch):
     # k = 50 on unit-norm rows: the 58 oracle distances of a query lie within a few per cent of
     # each other, a near-tie (1e-5) somewhere in the list is likely; the prefix before it is
     # compared id by id: at least 50 % of all result positions (measured: 71 %)
+    # bf16 rows meet the hyperplanes as TWO bf16 terms (|error| <= 2^-18 |x||r|, measured 4.6e-7): more points
+    # within rounding of a median than under three terms (1.0e-7), so more nodes whose median rank moved —
+    # both modes are checked against the same oracle tree, each against its own bar
     shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, 1235137, 1e-5, 0.9,
-                oracle_trees=(T - 1,), min_positions=0.5, cut_nodes=8)
+                oracle_trees=(T - 1,), min_positions=0.5, cut_nodes=8, min_close=0.93,
+                tight={"proj_bf16_terms": (3, 0)})
 
 
 def test_bf16_forest_and_knn_small_all_paths(rp, oracle, torch):
