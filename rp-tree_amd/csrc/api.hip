@@ -228,6 +228,7 @@ const OptDesc kOptions[] = {
     {"proj_narrow", &rpt_options::proj_narrow},
     {"proj_bf16_f32", &rpt_options::proj_bf16_f32},
     {"proj_bf16_terms", &rpt_options::proj_bf16_terms},
+    {"proj_bf16_codes", &rpt_options::proj_bf16_codes},
     {"proj_csr_nodense", &rpt_options::proj_csr_nodense},
     {"knn_wave", &rpt_options::knn_wave},
     {"knn_kp", &rpt_options::knn_kp},

@@ -4069,7 +4069,10 @@ int32_t knn_dev(rpt_ctx* ctx, rpt_forest* f, const rpt_dataset* data, const rpt_
                                                count_dev, ovf_p, ctot_p, rerun, rerun ? nullptr : &tier);
   };
   RPT_TRY(launch(false));
-  unsigned int hctl[6] = {0, 0, 0, 0, 0, 0};
+  // (read back into the pinned arena: a pageable destination makes the copy a staged, blocking one)
+  unsigned int hctl_stack[6] = {0, 0, 0, 0, 0, 0};
+  unsigned int* hctl = reinterpret_cast<unsigned int*>(pin_alloc(ctx, 32));
+  if (!hctl) hctl = hctl_stack;
   RPT_HIP(hipMemcpyAsync(hctl, ctl.p, 24, hipMemcpyDeviceToHost, ctx->stream));
   RPT_HIP(stream_sync(ctx->stream));
   const unsigned int novf = hctl[5];

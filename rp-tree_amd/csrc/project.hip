@@ -924,10 +924,12 @@ __global__ void split_A_bf16x3(const double* __restrict__ R, int d, int c0, int 
 template <int CBT, int NT /* 16-point tiles per wave, even */, bool RESIDENT /* both chunks stay in LDS */,
           int WAVES /* per workgroup */, class TP = float /* type of P */,
           int NTERM = 1 /* bf16 terms of a row: X[term][n][d]; 2 = dense-ified SVector rows (launch_csr_dense_mfma) */,
-          int NP = 3 /* bf16 terms of a hyperplane */, int KC = kB3KC /* k-steps per A chunk: 2 or 4 */>
+          int NP = 3 /* bf16 terms of a hyperplane */, int KC = kB3KC /* k-steps per A chunk: 2 or 4 */,
+          bool CODES = false /* codes.h next to P for the columns whose level is streamed */>
 __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
     const __hip_bfloat16* __restrict__ X, int64_t n, int d, const uint4* __restrict__ Aimg,
-    int nch /* even */, int c0, int ncol, TP* __restrict__ P, int64_t ldp, int64_t ntiles) {
+    int nch /* even */, int c0, int ncol, TP* __restrict__ P, int64_t ldp, int64_t ntiles,
+    uint16_t* __restrict__ Cd, int64_t ldc, const unsigned long long* __restrict__ cmm, int cL, int cLc) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds_a[];  // [2][CH16]
   constexpr int CH16 = KC * NP * CBT * 64;    // uint4 per chunk
   constexpr int kB3NT = NT, kB3Pts = WAVES * NT * 16, NTHR = WAVES * 64;  // points per workgroup tile
@@ -938,6 +940,12 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
   const int nks = nch * KC;                   // k-steps per tile, a multiple of 4
   constexpr bool resident = RESIDENT;
   const int kg = 8 * (lane >> 4);             // the lane's k offset inside a k-step
+  CodeGeo<float> cgeo{1.f, 0.f};
+  unsigned int cmask = 0;  // bit mt: hyperplane mt * 16 + (lane & 15) of the pass gets codes
+  if constexpr (CODES) {
+    cgeo = code_geo<float>(cmm[0], cmm[1]);
+    cmask = code_lane_mask<CBT>(lane, c0, ncol, cL, cLc);
+  }
   // prologue: chunk 0 (and chunk 1 when resident) into LDS
   for (int s = 0; s < ST; ++s) lds_a[s * NTHR + tid] = Aimg[s * NTHR + tid];
   if constexpr (resident)
@@ -1007,7 +1015,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
               for (int tm = 0; tm < NTERM; ++tm)
 #pragma unroll
                 for (int nt = 0; nt < kB3NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[tm][nt], acc[mt][nt], 0, 0, 0);
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tm][nt], a, acc[mt][nt], 0, 0, 0);
             }
         }
         if constexpr (!resident) {
@@ -1017,51 +1025,76 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
         }
       }
     }
-    // D[row = 4 (lane >> 4) + r][col = lane & 15] = (hyperplane, point).
-    // ONE running pointer per point tile: the sixty-four addresses of the straightforward loop are hoisted out of
-    // the tile loop (60 registers; with two row terms they spilled, and a scratch reload waits for every row
-    // request in flight: 5.15 -> 4.75 ms per C3 forest without them).
-    if constexpr (sizeof(TP) == 4) {
-      // 4-byte P: two neighbouring point tiles swap their odd / even lane rows (v_permlane16_swap), lanes 0..31 then
-      // hold 32 consecutive points of ONE hyperplane and a store writes whole 128-byte lines (half lines:
-      // WRITE_SIZE 6.6 GB for 5.1 GB of P, and 3 % of the pass).  (8-byte P has whole lines already.)
+    // The rows are the MFMA's FIRST operand: D[row = 4 (lane >> 4) + r][col = lane & 15] = (point, hyperplane), a
+    // lane holds FOUR CONSECUTIVE POINTS of one hyperplane per (mt, nt): 16-byte stores, and the codes of a
+    // streamed level (codes.h) as 8-byte stores.  Two neighbouring point tiles then trade lane halves inside every
+    // row of sixteen lanes (DPP row_ror:8): lanes 0..7 of a row keep their own tile-0 values and lanes 8..15 take
+    // the tile-1 values of THE SAME eight hyperplanes, so that eight lanes hold 32 consecutive points of one
+    // hyperplane and a store writes whole 128-byte lines of P (half lines — straight from the accumulators, or
+    // hyperplane-major word stores —: WRITE_SIZE 6.6 GB for 5.1 GB of P, and 4 % of the pass).
+    // ONE running pointer: the addresses of the straightforward loop are hoisted out of the tile loop (60
+    // registers; with two row terms they spilled, and a scratch reload waits for every row request in flight).
+    {
+      const int hi8 = (lane >> 3) & 1;
+      const bool vec = (ldp & 3) == 0;  // 16-byte aligned runs
+      const bool cvec = CODES && (ldc & 3) == 0;
+      auto ror8 = [](float v) -> float {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
+      };
 #pragma unroll
       for (int np2 = 0; np2 < kB3NT; np2 += 2) {
-        const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + np2 * 16 + (lane & 31);
-        int col = 8 * (lane >> 5);
+        // this lane's four points: tile np2 + hi8, rows 4 q .. 4 q + 3
+        const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + (np2 + hi8) * 16 + 4 * (lane >> 4);
+        int col = lane & 7;  // ... of the hyperplanes col (first store) and col + 8 (second) of every column tile
         TP* dst = P + (int64_t)(c0 + col) * ldp + pt;
+        uint16_t* q = CODES ? Cd + (int64_t)(c0 + col) * ldc + pt : nullptr;
 #pragma unroll
         for (int mt = 0; mt < CBT; ++mt) {
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              // (the swap is redone for hf = 1: a VALU move against eight more live registers)
-              const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mt][np2][r]),
-                                                               __float_as_uint(acc[mt][np2 + 1][r]), false, false);
-              if (pt < n && col + 4 * hf + r < ncol) *dst = (TP)__uint_as_float(sw[hf]);
-              dst += ldp;
-            }
-          }
-          col += 16;
-          dst += 8 * ldp;  // the other lane half holds the hyperplanes 8 .. 15 of the tile
-        }
-      }
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < kB3NT; ++nt) {
-        const int64_t pt = tile * kB3Pts + wave * (kB3NT * 16) + nt * 16 + (lane & 15);
-        int col = 4 * (lane >> 4);
-        TP* dst = P + (int64_t)(c0 + col) * ldp + pt;
-#pragma unroll
-        for (int mt = 0; mt < CBT; ++mt) {
+          float lo[4], hi[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (pt < n && col + r < ncol) *dst = (TP)acc[mt][nt][r];
-            dst += ldp;
+            const float t0 = ror8(acc[mt][np2 + 1][r]), t1 = ror8(acc[mt][np2][r]);
+            lo[r] = hi8 ? t0 : acc[mt][np2][r];
+            hi[r] = hi8 ? acc[mt][np2 + 1][r] : t1;
+          }
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float(&v4)[4] = hf ? hi : lo;
+            if (col + 8 * hf < ncol) {
+              if (vec && pt + 3 < n) {
+                typename Vec4<TP>::type v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (TP)v4[r];
+                *reinterpret_cast<typename Vec4<TP>::type*>(dst) = v;
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (pt + r < n) dst[r] = (TP)v4[r];
+              }
+            }
+            if constexpr (CODES) {
+              // (cmask bit mt is about hyperplane mt * 16 + (lane & 15): the first store's for lanes 0..7 of a
+              // row, the second's for lanes 8..15 — the bit of lane ^ 8 comes through the same rotation)
+              const unsigned int mine = (cmask >> mt) & 1u;
+              const unsigned int other = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0x128, 0xf, 0xf, true);
+              const unsigned int want = hf == hi8 ? mine : other;
+              if (want) {
+                if (cvec && pt + 3 < n) {
+                  code4_t c4;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) c4[r] = code_of(v4[r], cgeo);
+                  *reinterpret_cast<code4_t*>(q) = c4;
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    if (pt + r < n) q[r] = code_of(v4[r], cgeo);
+                }
+              }
+              q += 8 * ldc;
+            }
+            dst += 8 * ldp;
           }
           col += 16;
-          dst += 12 * ldp;
         }
       }
     }
@@ -1653,26 +1686,47 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
 // bf16 rows of 16-byte granularity on the bf16 matrix pipe (see proj_bf16x3)
 template <int CBT, int NT, int WAVES, class TP, int NTERM, int NP = 3, int KC = kB3KC>
 int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const uint4* Aimg, int nch,
-                           int c0, int ncol, TP* P) {
+                           int c0, int ncol, TP* P, const CodeOut* co = nullptr) {
   const int64_t ntiles = (n + WAVES * NT * 16 - 1) / (WAVES * NT * 16);
   int64_t blocks = ntiles < ctx->n_cu ? ntiles : ctx->n_cu;
   if (blocks < 1) blocks = 1;
   constexpr size_t smem = (size_t)2 * KC * NP * CBT * 64 * 16;
   static_assert(smem <= 160 * 1024, "two A chunks in LDS");
+  constexpr bool kCanCode = std::is_same<TP, float>::value && NTERM == 1;  // (codes from the f32 sums)
+#define RPT_B3_KERNEL(RES, CODES) proj_bf16x3<CBT, NT, RES, WAVES, TP, NTERM, NP, KC, CODES>
   static DeviceOnce attr_once;
   RPT_TRY(attr_once.run(ctx->device, [&]() -> int32_t {
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM, NP, KC>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&RPT_B3_KERNEL(true, false)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM, NP, KC>),
+    RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&RPT_B3_KERNEL(false, false)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if constexpr (kCanCode) {
+      RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&RPT_B3_KERNEL(true, true)),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&RPT_B3_KERNEL(false, true)),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
     return RPT_OK;
   }));
+  const dim3 grid((unsigned)blocks), block(WAVES * 64);
+  if constexpr (kCanCode) {
+    if (co) {
+      if (nch == 2)
+        hipLaunchKernelGGL((RPT_B3_KERNEL(true, true)), grid, block, smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol,
+                           P, n, ntiles, co->codes, co->ld, co->mm, co->L, co->Lc);
+      else
+        hipLaunchKernelGGL((RPT_B3_KERNEL(false, true)), grid, block, smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol,
+                           P, n, ntiles, co->codes, co->ld, co->mm, co->L, co->Lc);
+      return RPT_OK;
+    }
+  }
   if (nch == 2)
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, true, WAVES, TP, NTERM, NP, KC>), dim3((unsigned)blocks),
-                       dim3(WAVES * 64), smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
+    hipLaunchKernelGGL((RPT_B3_KERNEL(true, false)), grid, block, smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P,
+                       n, ntiles, (uint16_t*)nullptr, (int64_t)0, (const unsigned long long*)nullptr, 1, 0);
   else
-    hipLaunchKernelGGL((proj_bf16x3<CBT, NT, false, WAVES, TP, NTERM, NP, KC>), dim3((unsigned)blocks),
-                       dim3(WAVES * 64), smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P, n, ntiles);
+    hipLaunchKernelGGL((RPT_B3_KERNEL(false, false)), grid, block, smem, ctx->stream, X, n, d, Aimg, nch, c0, ncol, P,
+                       n, ntiles, (uint16_t*)nullptr, (int64_t)0, (const unsigned long long*)nullptr, 1, 0);
+#undef RPT_B3_KERNEL
   return RPT_OK;
 }
 
@@ -1685,7 +1739,7 @@ int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
 // third term.  Dense-ified SVector rows (NTERM = 2) already spend their 2^-18 on the ROW split and keep three.
 template <class TP, int NTERM>
 int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const double* R_dev,
-                           int32_t C, TP* P) {
+                           int32_t C, TP* P, const CodeOut* co = nullptr) {
   const bool two = NTERM == 1 && ctx->opt.proj_bf16_terms != 3;
   const int np = two ? 2 : 3;
   // two terms leave room for chunks of four k-steps (128 KB of LDS for 128 hyperplanes): half the barriers
@@ -1726,31 +1780,35 @@ int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
     if constexpr (NTERM == 1) {
       if (two) {
         if (ps.cbt == 8 && nch == 2 && kc == 2)
-          RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+          RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
         else if (ps.cbt == 8)
-          RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+          RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
         else if (kc == 2)
-          RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+          RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
         else
-          RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+          RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
         off += image16(ps);
         continue;
       }
     }
     if (ps.cbt == 8 && nch == 2)
-      RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
     else if (ps.cbt == 8)
-      RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
     else
-      RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P)));
+      RPT_TRY((launch_bf16x3_pass<4, 2, 8, TP, NTERM>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
     off += image16(ps);
   }
   RPT_HIP(hipGetLastError());
   return RPT_OK;  // the image returns to the stream-ordered allocator
 }
 
-int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, float* P) {
-  return launch_bf16x3_rows<float, 1>(ctx, (const __hip_bfloat16*)ds->X, ds->n, ds->d, R_dev, C, P);
+int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, int32_t C, float* P,
+                      const CodeOut* co, bool* codes_written) {
+  if (!ctx->opt.proj_bf16_codes) co = nullptr;
+  RPT_TRY((launch_bf16x3_rows<float, 1>(ctx, (const __hip_bfloat16*)ds->X, ds->n, ds->d, R_dev, C, P, co)));
+  if (co && codes_written) *codes_written = true;
+  return RPT_OK;
 }
 
 // ---- SVector rows on the matrix pipe (round 4; RPT_PROJ_MFMA = the tolerance mode on CSR data) ----
@@ -1977,7 +2035,10 @@ bool project_writes_codes(const rpt_ctx* ctx, const rpt_dataset* ds, int32_t mod
   if (mode == RPT_PROJ_EXACT) return ds->dtype != RPT_BF16 && ds->d == 128;
   const int piece = 16 / (int)dtype_size(ds->dtype);
   if (ds->d % piece != 0) return false;
-  if (ds->dtype == RPT_BF16)  // the bf16x3 kernel has no code epilogue (yet)
+  // bf16 rows on the bf16 pipe: proj_bf16x3 HAS a code epilogue (option proj_bf16_codes), but its 8-byte code runs
+  // are half lines and the epilogue runs with the matrix pipe idle: +3.0 ms of projection per C5 shard build
+  // against the 2.4 ms of the coalesced pass over the stored keys (pcode_kernel) — the pass stays the default
+  if (ds->dtype == RPT_BF16 && !ctx->opt.proj_bf16_codes)
     return !(ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !ctx->opt.proj_bf16_f32);
   return true;
 }
@@ -2020,7 +2081,7 @@ int32_t project_columns(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev
   // bf16: three bf16 MFMAs per tile against the split hyperplanes when the rows allow 16-byte
   // fragment loads, else the f32-MFMA kernels on converted inputs (option proj_bf16_f32: force them)
   if (ds->d % 8 == 0 && (reinterpret_cast<uintptr_t>(ds->X) & 15) == 0 && !ctx->opt.proj_bf16_f32)
-    return launch_bf16x3(ctx, ds, R_dev, C, (float*)P_dev);
+    return launch_bf16x3(ctx, ds, R_dev, C, (float*)P_dev, co, codes_written);
   return launch_mfma<__hip_bfloat16, float>(ctx, ds, R_dev, C, (float*)P_dev, co, codes_written);
 }
 

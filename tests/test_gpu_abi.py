@@ -431,10 +431,10 @@ def test_streaming_on_16bit_codes_is_exact(rp, ctx, oracle, kind, mode):
 
 
 def test_codes_after_the_projection_for_csr_and_bf16_rows(rp, ctx, oracle):
-    """Projection kernels without a code epilogue (CSR rows, bf16 rows on the bf16 pipe) get their
-    16-bit codes from a pass over the stored keys (pcode_kernel): the streamed levels then run on
-    codes as for dense f64 / f32 rows.  CSR: the forest is the oracle's, with and without the pass;
-    bf16: identical forests with and without it (ties included: rounded values)."""
+    """Projection kernels without a code epilogue (CSR rows) get their 16-bit codes from a pass over
+    the stored keys (pcode_kernel): the streamed levels then run on codes as for dense rows.  CSR: the
+    forest is the oracle's, with and without the pass; bf16 rows: identical forests with the codes of
+    proj_bf16x3's epilogue, with the pass, and without codes (ties included: rounded values)."""
     n, d, T, ml = 160_000, 200, 2, 60
     rowptr, col, val = oracle.data_normal_sparse2(5, n, d, 0.1)
     val = np.round(val, 1)                                   # many equal projections
@@ -450,22 +450,27 @@ def test_codes_after_the_projection_for_csr_and_bf16_rows(rp, ctx, oracle):
         assert np.array_equal(f.perm, fo.perm), off
         for name in ("thr", "mglo", "mghi"):
             assert np.array_equal(getattr(f, name), getattr(fo, name), equal_nan=True), (name, off)
-    n, d, T, ml = 200_000, 64, 3, 50
-    rng = np.random.default_rng(4)
-    Xb = rp.to_bf16(np.round(rng.standard_normal((n, d)), 1).astype(np.float32))
-    ds = rp.Dataset.dense(ctx, Xb, dtype=rp.RPT_BF16)
-    L, _, pnz = oracle.tree_cfg(ml, n, d)
-    R, _ = oracle.forest_hyperplanes(3, T, L, pnz, d)
-    got = []
-    for off in (0, 1):
-        old = ctx.set_option("no_pcodes", off)
-        try:
-            f = rp._build(ctx, ds, R, L, ml, rp.RPT_PROJ_AUTO)
-        finally:
-            ctx.set_option("no_pcodes", old)
-        got.append((f.perm.copy(), f.thr.copy(), f.mglo.copy(), f.mghi.copy()))
-    for a, b in zip(got[0], got[1]):
-        assert np.array_equal(a, b, equal_nan=True)
+    # bf16 rows: codes from the stored keys (default), from proj_bf16x3's epilogue (proj_bf16_codes), or none —
+    # short rows (hyperplanes resident in LDS, 64-column pass) and long ones (chunks of four k-steps, 128 columns)
+    for (n, d, T, ml) in ((200_000, 64, 3, 50), (140_000, 264, 6, 40)):
+        rng = np.random.default_rng(4)
+        Xb = rp.to_bf16(np.round(rng.standard_normal((n, d)), 1).astype(np.float32))
+        ds = rp.Dataset.dense(ctx, Xb, dtype=rp.RPT_BF16)
+        L, _, pnz = oracle.tree_cfg(ml, n, d)
+        R, _ = oracle.forest_hyperplanes(3, T, L, pnz, d)
+        got = []
+        for opts in ({}, {"proj_bf16_codes": 1}, {"no_pcodes": 1}):
+            old = {k: ctx.set_option(k, v) for k, v in opts.items()}
+            try:
+                f = rp._build(ctx, ds, R, L, ml, rp.RPT_PROJ_AUTO)
+            finally:
+                for k, v in old.items():
+                    ctx.set_option(k, v)
+            got.append((f.perm.copy(), f.thr.copy(), f.mglo.copy(), f.mghi.copy()))
+            f.close()
+        for other in got[1:]:
+            for a, b in zip(got[0], other):
+                assert np.array_equal(a, b, equal_nan=True)
 
 
 @pytest.mark.parametrize("d,dtype", [(600, np.float64), (784, np.float64), (300, np.float64),
