@@ -2810,16 +2810,21 @@ __global__ __launch_bounds__(256) void stream_pick_big(int64_t N, int level, int
   }
 }
 
-template <class TK>
+// CODE = the code-mode instantiation (Cd != null): its tables are 8-byte thresholds and 32-bit range cells,
+// 68 KB of LDS instead of 100 — TWO blocks per CU, twice the waves to hide the pass's load latency behind
+template <class TK, bool CODE>
 __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     const TK* __restrict__ P, const uint16_t* __restrict__ Cd, uint16_t* __restrict__ node_of,
     int64_t N, int L, int level, int M, int B, int64_t per, int has_next, SNode<TK>* nd,
     int32_t* __restrict__ pool, TK* __restrict__ poolkey, unsigned long long* cmin_next,
     unsigned long long* cmax_next) {
-  __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[kStreamMaxNodes];
-  __shared__ __attribute__((aligned(16))) ABins nbin[kStreamMaxNodes];
+  // code mode: ngeo holds kStreamMaxNodes 8-byte words (cth), nbin nothing, smin / smax 2 M 32-bit cells in
+  // their first kStreamMaxNodes words and the pivot lists' per-node counters behind them
+  __shared__ __attribute__((aligned(16))) AGeom<TK> ngeo[CODE ? kStreamMaxNodes * 8 / sizeof(AGeom<TK>) : kStreamMaxNodes];
+  __shared__ __attribute__((aligned(16))) ABins nbin[CODE ? 1 : kStreamMaxNodes];
   __shared__ int nmidoff[kStreamMaxNodes];
-  __shared__ unsigned long long smin[2 * kStreamMaxNodes], smax[2 * kStreamMaxNodes];
+  __shared__ unsigned long long smin[CODE ? kStreamMaxNodes + kStreamMaxNodes / 2 : 2 * kStreamMaxNodes],
+      smax[CODE ? kStreamMaxNodes + kStreamMaxNodes / 2 : 2 * kStreamMaxNodes];
   const int t = blockIdx.y;
   SNode<TK>* ndt = nd + (int64_t)t * M;
   unsigned long long* cth = reinterpret_cast<unsigned long long*>(ngeo);  // code mode: code_thr
@@ -2832,7 +2837,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
     }
     nmidoff[j] = ndt[j].midoff;
   }
-  for (int c = threadIdx.x; c < 2 * M; c += kStreamThreads) {
+  for (int c = threadIdx.x; c < (CODE ? M : 2 * M); c += kStreamThreads) {  // (code mode: 2 M 32-bit cells)
     smin[c] = ~0ULL;
     smax[c] = 0ULL;
   }
@@ -2865,7 +2870,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   constexpr int kKeyList = 4096;
   __shared__ int32_t list_id[kKeyList];
   __shared__ unsigned int list_meta[kKeyList];
-  const bool klist = !Cd && M <= kStreamMaxNodes / 2;
+  const bool klist = !CODE && M <= kStreamMaxNodes / 2;
   int32_t* kid = list_id;
   unsigned int* kmeta = list_meta;
   unsigned int* kcnt = reinterpret_cast<unsigned int*>(nbin + kStreamMaxNodes / 2);  // [512]
@@ -2920,7 +2925,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_assign(
   // two consecutive points per thread and step: 16-byte key loads, 4-byte node loads/stores
   // (the key rows are 16-byte aligned when N is even and the block ranges start on even offsets)
   typedef TK key2_t __attribute__((ext_vector_type(2)));
-  if (Cd) {  // code mode: eight points per thread and step, 16-byte code and node loads / stores
+  if constexpr (CODE) {  // code mode: eight points per thread and step, 16-byte code and node loads / stores
     const uint16_t* Cl = Cd + ((int64_t)t * L + level) * N;
     const uint16_t* Cn = has_next ? Cl + N : Cl;
     // the pivot list's per-node counters live in LDS that code mode leaves unused: the upper halves
@@ -4211,7 +4216,10 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
     // block flushes 2 M range cells with global atomics and loads M node records: fewer blocks, less
     // of both — 4-tree shard 1.28 -> 1.23 ms, 8 trees 1.79 -> 1.74, 32 trees unchanged; two were
     // better while the pass waited on a returning atomic per pivot point)
-    const int64_t afac = ctx->opt.tune0 > 0 ? ctx->opt.tune0 : 1;
+    // ... and TWO again in code mode since round 4: its instantiation needs 68 KB of LDS, both blocks are
+    // resident and the pass has twice the waves to hide its loads behind (C2 build 4.55 -> 4.46 ms, C4 shard
+    // split 9.55 -> 9.2 ms, 4-tree shard unchanged; key mode: 100 KB, one block)
+    const int64_t afac = ctx->opt.tune0 > 0 ? ctx->opt.tune0 : ((Cd && Lstream <= Lc) ? 2 : 1);
     int64_t nblkA = (afac * (int64_t)ctx->n_cu + T - 1) / T;
     if (nblkA > (N + 8191) / 8192) nblkA = (N + 8191) / 8192;
     if (nblkA < 1) nblkA = 1;
@@ -4273,8 +4281,12 @@ int32_t build_forest_t(rpt_ctx* ctx, const rpt_dataset* ds, rpt_forest* f, int32
           }
         }
 #undef RPT_PICK
-        hipLaunchKernelGGL(stream_assign<TK>, agrid, dim3(kStreamThreads), 0, st, P, Cs, node_of.p, N,
-                           L, level, M, B, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
+        if (Cs)
+          hipLaunchKernelGGL((stream_assign<TK, true>), agrid, dim3(kStreamThreads), 0, st, P, Cs, node_of.p, N,
+                             L, level, M, B, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
+        else
+          hipLaunchKernelGGL((stream_assign<TK, false>), agrid, dim3(kStreamThreads), 0, st, P, Cs, node_of.p, N,
+                             L, level, M, B, perA, has_next, snodes.p, pool, poolkey.p, cminN, cmaxN);
         const size_t smem = (size_t)kSmallCap * (sizeof(TK) + 4);
         const int npb = M >= 16 ? 4 : 1;
         MidArgs<TK> ma{P,     Cs,   node_of.p, N,     L,        level,    M,
