@@ -401,12 +401,14 @@ def other_configs(which, steps, with_cpu):
                                                         min_leaf, k, steps)
             w_ms, w_n = pb["project_wide"]
             cols = T * maxd / max(w_n / steps, 1)
-            roof = _roof("proj_bf16x3 (bf16 rows x hyperplanes split into three bf16 terms, %.0f hyperplanes "
-                         "per launch)" % cols, w_ms / max(w_n, 1), int(w_n / steps),
+            terms = 3 if ctx.get_option("proj_bf16_terms") == 3 else 2
+            roof = _roof("proj_bf16x3 (bf16 rows x hyperplanes split into %d bf16 terms, %.0f hyperplanes "
+                         "per launch)" % (terms, cols), w_ms / max(w_n, 1), int(w_n / steps),
                          n * d * 2 + d * cols * 8 + n * cols * 4, 2.0 * n * d * cols, MFMA_BF16_PEAK_TF,
-                         "algorithmic flops 2*N*d*C against the dense bf16 MFMA peak; the kernel ISSUES three "
-                         "times that (r = r_hi + r_mid + r_lo keeps 24 bits: the 1e-5 tolerance)")
-            roof["mfma_issued_frac"] = 3.0 * roof["mfma_frac"]
+                         "algorithmic flops 2*N*d*C against the dense bf16 MFMA peak; the kernel ISSUES %d "
+                         "times that (r = r_hi + r_mid [+ r_lo]: |error| <= 2^-18 |x||r| with two terms, "
+                         "inside the 1e-5 tolerance; option proj_bf16_terms = 3 keeps 24 bits)" % terms)
+            roof["mfma_issued_frac"] = float(terms) * roof["mfma_frac"]
             tier, unc = C.c_int32(), C.c_int64()
             _lib.check(L_.rpt_knn_last_tier(ctx._h, C.byref(tier)))
             _lib.check(L_.rpt_knn_last_uncertified(ctx._h, C.byref(unc)))
@@ -415,7 +417,8 @@ def other_configs(which, steps, with_cpu):
             res = {"workload": "C5 shard: %d x %d bf16 unit-norm rows, %d of %d trees (one of %d GPUs), minLeaf %d, "
                                "maxDepth %d, pnz %.4f, k=%d, %d queries" %
                                (n, d, T, Tall, G, min_leaf, maxd, pnz, k, nq),
-                   "dtype": "bf16", "projection_mode": "mfma (bf16 MFMA 16x16x32, f32 accumulation, 1e-5 |x||r|)",
+                   "dtype": "bf16", "projection_mode": "mfma (bf16 MFMA 16x16x32, hyperplanes as %d bf16 terms, f32 accumulation, "
+                                                       "1e-5 |x||r|)" % terms,
                    "build_ms": b_ms, "value": n / (b_ms * 1e-3), "unit": "vectors/s",
                    "knn_ms_per_batch": q_ms, "knn_queries_per_s": nq / (q_ms * 1e-3),
                    "candidates_per_query": cand,
@@ -430,6 +433,42 @@ def other_configs(which, steps, with_cpu):
                                          steps, nq * cand * row_b, 0.0, 0.0,
                                          "nq x candidates x (d x 1 B int8 rows + k'/candidates x d x 2 B bf16 rows)"
                                          if tier.value == 3 else "nq x candidates x d x 2 B")}
+            # side leg: the same build with THREE bf16 terms per hyperplane (the rounds 1-3 kernel's accuracy):
+            # what the third term costs, and how many leaf assignments of tree 0 the two-term build moves
+            if terms == 2:
+                try:
+                    old = ctx.set_option("proj_bf16_terms", 3)
+                    try:
+                        rp._build(ctx, ds, R, maxd, min_leaf, rp.RPT_PROJ_AUTO).close()
+                        _lib.check(L_.rpt_prof_reset(ctx._h))
+                        _lib.check(L_.rpt_prof_enable(ctx._h, 1))
+                        ctx.sync()
+                        t0 = time.perf_counter()
+                        f3 = None
+                        for _ in range(steps):
+                            if f3 is not None:
+                                f3.close()
+                            f3 = rp._build(ctx, ds, R, maxd, min_leaf, rp.RPT_PROJ_AUTO)
+                        ctx.sync()
+                        t3 = (time.perf_counter() - t0) / steps * 1e3
+                        p3 = _prof_read(L_, _lib, C, ctx)
+                        _lib.check(L_.rpt_prof_enable(ctx._h, 0))
+                    finally:
+                        ctx.set_option("proj_bf16_terms", old)
+                    leaf_off = np.array([o for (_, _, o, nn, lf) in f.topology() if lf], dtype=np.int64)
+                    i2 = np.empty(n, dtype=np.int64); i2[f.perm[0]] = np.arange(n)
+                    i3 = np.empty(n, dtype=np.int64); i3[f3.perm[0]] = np.arange(n)
+                    flips = float((np.searchsorted(leaf_off, i2, side="right") !=
+                                   np.searchsorted(leaf_off, i3, side="right")).mean())
+                    f3.close()
+                    del i2, i3
+                    res["three_term_mode"] = {
+                        "mode": "option proj_bf16_terms = 3: hyperplanes as three bf16 terms (24 bits)",
+                        "build_ms": t3, "projection_ms": p3["project"][0] / steps,
+                        "split_ms": p3["split"][0] / steps,
+                        "leaf_flip_rate_two_vs_three_terms_tree0": flips}
+                except Exception as e:      # noqa: BLE001
+                    res["three_term_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if with_cpu:
                 from oracle import oracle as orc
                 Xh = np.empty((n, d), dtype=np.float32)
