@@ -61,9 +61,11 @@ extern "C" {
 #define RPT_PROJ_EXACT 1    /* f64 VALU, the reference's summation order and no FMA
                                (Internal.hs:382): bit-identical to innerSD/innerSS */
 #define RPT_PROJ_MFMA 2     /* MFMA tiles (f64/f32/bf16 inputs), k-ordered fma chain:
-                               within 1e-5*|x||r| of the reference value.  CSR rows: the
-                               exact-order kernel with ONE fused multiply-add per term
-                               instead of the reference's two roundings (same tolerance) */
+                               within 1e-5*|x||r| of the reference value.  CSR rows: dense-ified
+                               as two bf16 terms on the bf16 matrix pipe (from 65 536 rows on,
+                               d % 8 == 0), else the exact-order kernel with ONE fused
+                               multiply-add per term instead of the reference's two roundings
+                               (same tolerance) */
 
 /* knn flags */
 #define RPT_KNN_KEEP_DUPLICATES 0 /* the reference: RPTree.hs:174-176 never de-duplicates */
@@ -108,6 +110,10 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  *   no_wsort, no_wpack, no_csub, no_codes, no_pcodes
  *       median split: which regime handles which level
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
+ *   proj_bf16_terms (3), proj_bf16_codes, proj_csr_nodense
+ *       bf16 rows meet every hyperplane as TWO bf16 terms (|error| <= 2^-18 |x||r| by construction,
+ *       inside RPT_PROJ_MFMA's 1e-5); 3 keeps a third term (f32-level agreement, a third more
+ *       matrix-pipe work) / codes from the bf16 kernel's epilogue / CSR rows stay on the segmented kernel
  *   knn_wave (-1 auto, 0, 1), knn_kp, knn_kp16, knn_kp8, knn_no_pre32, knn_no_pre16, knn_no_pre8,
  *   knn_csr_pre32, knn_general
  *       query kernels; knn_kp8 > 0 also opts bf16 datasets into the int8 ranking tier
