@@ -2595,7 +2595,7 @@ __global__ __launch_bounds__(256) void stream_pick(int64_t N, int level, int M, 
     const uint16_t* p16 =
         reinterpret_cast<const uint16_t*>(part + (int64_t)t * nblk * (kStreamBins / 2)) +
         (int64_t)j * B + r * BPT;
-#pragma unroll 8
+#pragma unroll 4
     for (int p = 0; p < nblk; ++p) add_u16<BPT>(p16 + (int64_t)p * kStreamBins, c);
   }
   int64_t n = N;
@@ -2692,7 +2692,7 @@ __global__ __launch_bounds__(256) void stream_pick_sum(int MB2 /* M * B / 2 */, 
   if (i >= MB2) return;
   const unsigned int* p = part + (int64_t)t * nblk * (kStreamBins / 2) + i;
   unsigned int lo = 0, hi = 0;
-#pragma unroll 8
+#pragma unroll 4
   for (int b = 0; b < nblk; ++b) {
     const unsigned int w = p[(int64_t)b * (kStreamBins / 2)];
     lo += w & 0xffffu;
