@@ -925,7 +925,8 @@ template <int CBT, int NT /* 16-point tiles per wave, even */, bool RESIDENT /* 
           int WAVES /* per workgroup */, class TP = float /* type of P */,
           int NTERM = 1 /* bf16 terms of a row: X[term][n][d]; 2 = dense-ified SVector rows (launch_csr_dense_mfma) */,
           int NP = 3 /* bf16 terms of a hyperplane */, int KC = kB3KC /* k-steps per A chunk: 2 or 4 */,
-          bool CODES = false /* codes.h next to P for the columns whose level is streamed */>
+          bool CODES = false /* codes.h next to P for the columns whose level is streamed */,
+          int RD = 4 /* k-steps the row requests run ahead (2 or 4) */>
 __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
     const __hip_bfloat16* __restrict__ X, int64_t n, int d, const uint4* __restrict__ Aimg,
     int nch /* even */, int c0, int ncol, TP* __restrict__ P, int64_t ldp, int64_t ntiles,
@@ -962,9 +963,9 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
   };
 
   int64_t tile = blockIdx.x;
-  uint4 bf[4][NTERM][kB3NT];  // ring: k-step s lives in bf[s & 3]
+  uint4 bf[RD][NTERM][kB3NT];  // ring: k-step s lives in bf[s & (RD - 1)]
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < RD; ++u)
 #pragma unroll
     for (int tm = 0; tm < NTERM; ++tm)
 #pragma unroll
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
         const uint4* ab = lds_a + h * CH16;
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) {
-          const int u = (h * KC + ks) & 3;
+          const int u = (h * KC + ks) & (RD - 1);
           bf16x8 b[NTERM][kB3NT];
 #pragma unroll
           for (int tm = 0; tm < NTERM; ++tm)
@@ -997,7 +998,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_bf16x3(
             for (int nt = 0; nt < kB3NT; ++nt) b[tm][nt] = __builtin_bit_cast(bf16x8, bf[u][tm][nt]);
           // refill the ring slot four k-steps ahead (the next tile's first k-steps at the end)
           {
-            const int sn = c * KC + ks + 4;
+            const int sn = c * KC + ks + RD;
             const int64_t tn = sn >= nks ? tile + gridDim.x : tile;
             const int kn = sn >= nks ? sn - nks : sn;
 #pragma unroll
@@ -1684,7 +1685,7 @@ int32_t launch_mfma(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, in
 }
 
 // bf16 rows of 16-byte granularity on the bf16 matrix pipe (see proj_bf16x3)
-template <int CBT, int NT, int WAVES, class TP, int NTERM, int NP = 3, int KC = kB3KC>
+template <int CBT, int NT, int WAVES, class TP, int NTERM, int NP = 3, int KC = kB3KC, int RD = 4>
 int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const uint4* Aimg, int nch,
                            int c0, int ncol, TP* P, const CodeOut* co = nullptr) {
   const int64_t ntiles = (n + WAVES * NT * 16 - 1) / (WAVES * NT * 16);
@@ -1693,7 +1694,7 @@ int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
   constexpr size_t smem = (size_t)2 * KC * NP * CBT * 64 * 16;
   static_assert(smem <= 160 * 1024, "two A chunks in LDS");
   constexpr bool kCanCode = std::is_same<TP, float>::value && NTERM == 1;  // (codes from the f32 sums)
-#define RPT_B3_KERNEL(RES, CODES) proj_bf16x3<CBT, NT, RES, WAVES, TP, NTERM, NP, KC, CODES>
+#define RPT_B3_KERNEL(RES, CODES) proj_bf16x3<CBT, NT, RES, WAVES, TP, NTERM, NP, KC, CODES, RD>
   static DeviceOnce attr_once;
   RPT_TRY(attr_once.run(ctx->device, [&]() -> int32_t {
     RPT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&RPT_B3_KERNEL(true, false)),
@@ -1781,6 +1782,13 @@ int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
       if (two) {
         if (ps.cbt == 8 && nch == 2 && kc == 2)
           RPT_TRY((launch_bf16x3_pass<8, 4, 4, TP, 1, 2, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
+        else if (ps.cbt == 8 && ctx->opt.proj_bf16_terms != 8)
+          // sixteen waves (four per SIMD at 117 registers), rows requested TWO k-steps ahead: as many row
+          // requests in flight per CU and as far ahead in time as eight waves with four (more in flight is
+          // slower), but 512 points per workgroup tile — half the hyperplane image traffic and half
+          // the barriers per point: 5.05 -> 4.75 ms per 128 hyperplanes over 10 M x 768 (option value 8: the
+          // eight-wave shape)
+          RPT_TRY((launch_bf16x3_pass<8, 2, 16, TP, 1, 2, 4, 2>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
         else if (ps.cbt == 8)
           RPT_TRY((launch_bf16x3_pass<8, 2, 8, TP, 1, 2, 4>(ctx, X, n, d, img, nch, ps.c0, ps.ncol, P, co)));
         else if (kc == 2)

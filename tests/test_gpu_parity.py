@@ -123,6 +123,9 @@ def test_project_mfma_bf16_input(rp, ctx, option, n, d, C):
             P3 = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
         assert (np.abs(P3.T - want) <= 2e-6 * scale).all()
         assert np.abs(P3.T - want).max() <= np.abs(P.T - want).max() * 1.5 + 1e-12
+        with option("proj_bf16_terms", 8):   # the eight-wave workgroup shape: the same sums, bit for bit
+            P8 = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
+        assert np.array_equal(P8, P)
 
 
 def test_project_bf16_both_kernels_agree(rp, ctx, option):

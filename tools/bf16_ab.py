@@ -32,7 +32,7 @@ ctx = rp.Context(0)
 L_ = _lib.lib()
 ds = rp.Dataset.dense_device(ctx, X.data_ptr(), N, d, rp.RPT_BF16, keep=X)
 keep = {}
-for old in [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "3,0,3,0").split(",")]:
+for old in [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "3,8,0,8,0").split(",")]:
     ctx.set_option("proj_bf16_terms", old)
     ts = []
     for it in range(5):
