@@ -10,7 +10,7 @@ python bench.py > gpurun_out/r4z/bench.json 2> gpurun_out/r4z/bench.err; echo "b
 export PMC_SETS="$(cat tools/pmc_sets_bench.txt)"
 bash tools/prof_cmd.sh r04_main python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --other-configs none --shard-sweep none > gpurun_out/prof_r04_main.log 2>&1
 export PMC_SETS="$(cat tools/pmc_sets_bf16.txt)"
-bash tools/prof_cmd.sh r04_bf16 python3 $GRAFT_REPO_ROOT/tools/bf16_ab.py 10000000 768 128 0,3 > gpurun_out/prof_r04_bf16.log 2>&1
+bash tools/prof_cmd.sh r04_bf16 python3 $GRAFT_REPO_ROOT/tools/bf16_ab.py 10000000 768 128 0,8,3 > gpurun_out/prof_r04_bf16.log 2>&1
 export PMC_SETS="FETCH_SIZE
 WRITE_SIZE"
 for c in c3 c4 c5; do bash tools/prof_cmd.sh r04_$c python3 $GRAFT_REPO_ROOT/bench.py --_other-child --other-configs $c --no-cpu-baseline --steps 3 > gpurun_out/prof_r04_$c.log 2>&1; done
