@@ -406,7 +406,7 @@ def other_configs(which, steps, with_cpu):
                          "per launch)" % (terms, cols), w_ms / max(w_n, 1), int(w_n / steps),
                          n * d * 2 + d * cols * 8 + n * cols * 4, 2.0 * n * d * cols, MFMA_BF16_PEAK_TF,
                          "algorithmic flops 2*N*d*C against the dense bf16 MFMA peak; the kernel ISSUES %d "
-                         "times that (r = r_hi + r_mid [+ r_lo]: |error| <= 2^-18 |x||r| with two terms, "
+                         "times that (r = r_hi + r_mid [+ r_lo]: |error| <= 2^-17 |x||r| with two terms, "
                          "inside the 1e-5 tolerance; option proj_bf16_terms = 3 keeps 24 bits)" % terms)
             roof["mfma_issued_frac"] = float(terms) * roof["mfma_frac"]
             tier, unc = C.c_int32(), C.c_int64()

@@ -111,7 +111,7 @@ int32_t rpt_ctx_stream(rpt_ctx* ctx, void** hip_stream);
  *       median split: which regime handles which level
  *   proj_narrow, proj_bf16_f32     projection: 32 hyperplanes per pass only / bf16 rows on the f32 pipe
  *   proj_bf16_terms (3), proj_bf16_codes, proj_csr_nodense
- *       bf16 rows meet every hyperplane as TWO bf16 terms (|error| <= 2^-18 |x||r| by construction,
+ *       bf16 rows meet every hyperplane as TWO bf16 terms (|error| <= 2^-17 |x||r| by construction,
  *       inside RPT_PROJ_MFMA's 1e-5); 3 keeps a third term (f32-level agreement, a third more
  *       matrix-pipe work) / codes from the bf16 kernel's epilogue / CSR rows stay on the segmented kernel
  *   knn_wave (-1 auto, 0, 1), knn_kp, knn_kp16, knn_kp8, knn_no_pre32, knn_no_pre16, knn_no_pre8,

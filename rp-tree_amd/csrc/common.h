@@ -152,7 +152,7 @@ struct rpt_options {
   int64_t proj_narrow = 0;      // projection: 32 hyperplanes per pass only
   int64_t proj_bf16_f32 = 0;    // projection: bf16 rows through the f32-MFMA kernels
   int64_t proj_bf16_codes = 0;  // projection: bf16 rows get their codes from proj_bf16x3's epilogue, not from pcode_kernel
-  int64_t proj_bf16_terms = 0;  // projection: 3 = bf16 rows against THREE bf16 terms of a hyperplane (default two: 3.9e-6 |x||r|);
+  int64_t proj_bf16_terms = 0;  // projection: 3 = bf16 rows against THREE bf16 terms of a hyperplane (default two: 2^-17 |x||r|);
                                 // 8 = two terms on the eight-wave workgroup shape (A/B)
   int64_t proj_csr_nodense = 0; // projection: RPT_PROJ_MFMA on CSR rows stays on the segmented CSR kernel (one FMA per
                                 // term) instead of the dense-ified bf16 matrix-pipe formulation

@@ -1732,12 +1732,12 @@ int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
 }
 
 // P[C][n] = the rows X[NTERM][n][d] (NTERM bf16 terms each) against the hyperplanes R_dev[C][d] split into
-// bf16 terms.  bf16 DATA (NTERM = 1) takes TWO hyperplane terms: r = r_hi + r_mid + e with |e_i| <= 2^-18 |r_i|
+// bf16 terms.  bf16 DATA (NTERM = 1) takes TWO hyperplane terms: r = r_hi + r_mid + e with |e_i| <= 2^-17 |r_i|
 // (two roundings to 8 significant bits), every product x_i * r_part exact in f32, so
-// |P - x.r| <= 2^-18 sum |x_i||r_i| <= 3.9e-6 |x||r| by Cauchy-Schwarz, inside north_star's 1e-5 with the f32
+// |P - x.r| <= 2^-17 sum |x_i||r_i| <= 7.6e-6 |x||r| by Cauchy-Schwarz, inside north_star's 1e-5 with the f32
 // accumulation (measured: 4.6e-7 |x||r| at d = 768; three terms: 1.0e-7) — a third less matrix-pipe and LDS work
 // than three terms (6.7 -> 5.0 ms per 128 hyperplanes over 10 M x 768).  Option proj_bf16_terms = 3 keeps the
-// third term.  Dense-ified SVector rows (NTERM = 2) already spend their 2^-18 on the ROW split and keep three.
+// third term.  Dense-ified SVector rows (NTERM = 2) already spend their 2^-17 on the ROW split and keep three.
 template <class TP, int NTERM>
 int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const double* R_dev,
                            int32_t C, TP* P, const CodeOut* co = nullptr) {
@@ -1822,10 +1822,10 @@ int32_t launch_bf16x3(rpt_ctx* ctx, const rpt_dataset* ds, const double* R_dev, 
 // ---- SVector rows on the matrix pipe (round 4; RPT_PROJ_MFMA = the tolerance mode on CSR data) ----
 // The segmented CSR kernel is instruction-issue bound (one multiply-add per (nonzero, hyperplane):
 // 10.6 ms per C3 forest with FMAs).  Dense-ified, the same contraction is proj_bf16x3's: the rows as
-// TWO bf16 terms x = x_hi + x_lo (|x - x_hi - x_lo| <= 2^-18 |x|), each multiplied with the hyperplanes'
+// TWO bf16 terms x = x_hi + x_lo (|x - x_hi - x_lo| <= 2^-17 |x|), each multiplied with the hyperplanes'
 // three bf16 terms (24 bits) on v_mfma_f32_16x16x32_bf16 in ONE pass (proj_bf16x3<..., NTERM = 2>: both
 // row terms ride the B ring, an A fragment feeds four MFMAs), f32 accumulation:
-// |P - r.x| <= 2^-18 sum |x_i||r_i| + the f32 accumulation <= 1e-5 |x||r|
+// |P - r.x| <= 2^-17 sum |x_i||r_i| + the f32 accumulation <= 1e-5 |x||r|
 // (north_star's tolerance; tests/test_gpu_parity.py::test_project_csr_dense_mfma).  The dense terms
 // ([2][n][d] bf16: 3.1 GB at C3 against 1.8 GB of CSR arrays) are built once per dataset.
 template <class T>

@@ -352,7 +352,7 @@ def test_c5_10m_x768_bf16_depth16_k50(rp, oracle, torch):
     # k = 50 on unit-norm rows: the 58 oracle distances of a query lie within a few per cent of
     # each other, a near-tie (1e-5) somewhere in the list is likely; the prefix before it is
     # compared id by id: at least 50 % of all result positions (measured: 71 %)
-    # bf16 rows meet the hyperplanes as TWO bf16 terms (|error| <= 2^-18 |x||r|, measured 4.6e-7): more points
+    # bf16 rows meet the hyperplanes as TWO bf16 terms (|error| <= 2^-17 |x||r|, measured 4.6e-7): more points
     # within rounding of a median than under three terms (1.0e-7), so more nodes whose median rank moved —
     # both modes are checked against the same oracle tree, each against its own bar
     shard_check(rp, oracle, torch, Xd, Xh, T, min_leaf, k, nq, 1235137, 1e-5, 0.9,

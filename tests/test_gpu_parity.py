@@ -94,7 +94,7 @@ def test_project_mfma_within_tolerance(rp, ctx, dtype, tol, n, d, C):
     assert (err <= tol * scale + 1e-300).all(), float((err / (scale + 1e-300)).max())
 
 
-# d % 8 == 0: the bf16 matrix pipe with the hyperplanes split into TWO bf16 terms (|error| <= 2^-18 |x||r| by
+# d % 8 == 0: the bf16 matrix pipe with the hyperplanes split into TWO bf16 terms (|error| <= 2^-17 |x||r| by
 # construction; option proj_bf16_terms = 3: three terms, f32-level agreement) — 128-column passes, 64-column
 # tail, A resident in LDS up to d = 128 and streamed in chunks of four k-steps beyond, ragged last k-step,
 # fewer points than one 256-point tile; otherwise the f32-MFMA kernels
@@ -117,8 +117,9 @@ def test_project_mfma_bf16_input(rp, ctx, option, n, d, C):
     scale = np.linalg.norm(Xr, axis=1)[:, None] * np.linalg.norm(Rq, axis=1)[None, :]
     assert (np.abs(P.T - want) <= 1e-5 * scale).all()
     if d % 8 == 0:
-        # two terms: 2^-18 |x||r| = 3.8e-6 by Cauchy-Schwarz, plus the f32 accumulation
-        assert (np.abs(P.T - want) <= 4e-6 * scale).all()
+        # two terms: every element of r within 2^-17 of itself (two roundings to 8 significant bits), so
+        # 2^-17 |x||r| = 7.6e-6 by Cauchy-Schwarz, plus the f32 accumulation
+        assert (np.abs(P.T - want) <= 8e-6 * scale).all()
         with option("proj_bf16_terms", 3):   # 24 bits of R: f32-level agreement
             P3 = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
         assert (np.abs(P3.T - want) <= 2e-6 * scale).all()
@@ -144,7 +145,7 @@ def test_project_bf16_both_kernels_agree(rp, ctx, option):
         Pb = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
     Xr = xb.to(torch.float32).cpu().numpy().astype(np.float64)
     scale = np.linalg.norm(Xr, axis=1)[None, :] * np.linalg.norm(R, axis=1)[:, None]
-    assert (np.abs(Pa.astype(np.float64) - Pb) <= 4e-6 * scale).all()      # (two hyperplane terms: 2^-18)
+    assert (np.abs(Pa.astype(np.float64) - Pb) <= 8e-6 * scale).all()      # (two hyperplane terms: 2^-17)
     with option("proj_bf16_terms", 3):
         Pc = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
     assert (np.abs(Pc.astype(np.float64) - Pb) <= 2e-6 * scale).all()
