@@ -1741,7 +1741,9 @@ int32_t launch_bf16x3_pass(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int
 template <class TP, int NTERM>
 int32_t launch_bf16x3_rows(rpt_ctx* ctx, const __hip_bfloat16* X, int64_t n, int d, const double* R_dev,
                            int32_t C, TP* P, const CodeOut* co = nullptr) {
-  const bool two = NTERM == 1 && ctx->opt.proj_bf16_terms != 3;
+  // (rows shorter than 64 elements keep three terms: their few products do not average the split's error down —
+  // 7.1e-6 |x||r| was measured on rows of 8 — and cost next to nothing)
+  const bool two = NTERM == 1 && ctx->opt.proj_bf16_terms != 3 && d >= 64;
   const int np = two ? 2 : 3;
   // two terms leave room for chunks of four k-steps (128 KB of LDS for 128 hyperplanes): half the barriers
   const int kc = (two && d > 128) ? 4 : kB3KC;

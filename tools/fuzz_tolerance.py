@@ -50,7 +50,7 @@ while time.time() < t_end:
         X64 = xb.float().cpu().numpy().astype(np.float64)
         P = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
         e2 = rel_err(P, X64, R)
-        assert e2 <= 8e-6, ("bf16 two terms", n, d, C, e2)
+        assert e2 <= (8e-6 if d >= 64 else 2e-6), ("bf16 two terms (three below 64 elements)", n, d, C, e2)
         old = ctx.set_option("proj_bf16_terms", 8)
         P8 = rp.project(ds, R, mode=rp.RPT_PROJ_MFMA, ctx=ctx)
         ctx.set_option("proj_bf16_terms", 3)
